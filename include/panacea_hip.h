@@ -1,0 +1,186 @@
+/*
+ * panacea_hip.h — C-ABI of libpanacea_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the Panacea denoising hot path.  The reference
+ * (wenyuqing/panacea) ships no native code: every arithmetic call-site on the
+ * path is a PyTorch / xformers / cuDNN / cuBLAS call.  Each entry point below
+ * replaces one family of those call-sites; the citation after each prototype is
+ * the reference call-site (path relative to the reference root) it stands in for.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers (HBM);
+ *   - `stream` is a hipStream_t passed as void*; work is only enqueued, never
+ *     synchronised; no allocation, no global state -> safe under hipGraph capture;
+ *   - return value: 0 on success, a hipError_t (>0) from the launch, or a negative
+ *     PNC_E* code for an argument the kernel family does not support;
+ *   - activations are channels-last token matrices: row m = (frame f, y, x),
+ *     m = (f*H + y)*W + x, columns = channels.  fp16 operands, fp32 residual
+ *     stream ("h32") — see DESIGN.md §3.
+ */
+#ifndef PANACEA_HIP_H
+#define PANACEA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNC_OK 0
+#define PNC_EINVAL (-1)   /* unsupported shape / argument */
+#define PNC_EALIGN (-2)   /* pointer or leading dimension not 16-byte aligned */
+
+/* library / build identification: returns "panacea_hip <version> gfx950" */
+const char* pnc_version(void);
+
+/* ------------------------------------------------------------------------- *
+ * 1. MFMA GEMM family:  C[M,N] = gatherA[M,K] (fp16) x W[N,K]^T (fp16), fp32 acc
+ *
+ *   a_mode PNC_A_PLAIN   : A row-major [M][lda]
+ *     -> nn.Linear call-sites (sgm/modules/attention.py:94,107,113,220-225,
+ *        398-403,509-514,959,980,1040-1059) and 1x1 convs
+ *        (sgm/modules/diffusionmodules/openaimodel.py:486, controlmodel.py:81-84)
+ *   a_mode PNC_A_CONV3X3 : implicit GEMM over an NHWC fp16 image
+ *        [F][Hin][Win][Cin], K = 9*Cin ordered (ky,kx,ci), pad 1, stride 1|2,
+ *        optional nearest x2 upsample of the input
+ *     -> nn.Conv2d 3x3 (openaimodel.py:413,459,125 (Upsample),187 (Downsample),
+ *        974 (stem), 1251 (out); controlmodel.py:44-58 (hint stem))
+ *   a_mode PNC_A_CONV1D_T: temporal conv1d k=3 pad 1 over frames of one pixel,
+ *        rows m = (b*T+t)*Npix + p, K = 3*C ordered (dt,ci)
+ *     -> nn.Conv1d (openaimodel.py:418,469) applied on "(b h w) c t"
+ *
+ *   epilogue (all optional, applied in this order):
+ *     v = acc + bias[n] + rowbias[((m / rb_rows) % rb_mod)*N + n]
+ *     if geglu: v = value * gelu_erf(gate) on interleaved 32-column blocks
+ *               (attention.py:91-98); output has N/2 columns
+ *     if act == PNC_ACT_SILU: v = v*sigmoid(v)
+ *     v += res1[m*ldr1+n] + res2[m*ldr2+n]          (fp32 residual stream)
+ *     out32[m*ldc32+n] = v;  out16[m*ldc16+n] = (fp16)v  for n <  n_split
+ *     out16t[(m/t_rows)*t_gstride + (n-n_split)*ldt + m%t_rows] = (fp16)v for n >= n_split
+ * ------------------------------------------------------------------------- */
+enum { PNC_A_PLAIN = 0, PNC_A_CONV3X3 = 1, PNC_A_CONV1D_T = 2 };
+enum { PNC_ACT_NONE = 0, PNC_ACT_SILU = 1 };
+
+typedef struct PncGemmParams {
+    const void* A;          /* fp16 */
+    const void* W;          /* fp16 [N][K] row-major (K contiguous) */
+    int32_t M, N, K;
+    int32_t lda;            /* PNC_A_PLAIN: elements between rows of A */
+    int32_t a_mode;
+    /* PNC_A_CONV3X3 */
+    int32_t Cin, Hin, Win, Hout, Wout, stride, upsample;
+    /* PNC_A_CONV1D_T (Cin = channels) */
+    int32_t T, Npix;
+    /* epilogue */
+    const float* bias;      /* [N] or NULL */
+    const float* rowbias;   /* [rb_mod][N] or NULL */
+    int32_t rb_rows, rb_mod;
+    const float* res1; int32_t ldr1;
+    const float* res2; int32_t ldr2;
+    float*  out32;  int32_t ldc32;
+    void*   out16;  int32_t ldc16;
+    void*   out16t; int32_t ldt; int32_t t_rows; int64_t t_gstride;
+    int32_t n_split;        /* multiple of 128 (or >= N when out16t == NULL) */
+    int32_t act;
+    int32_t geglu;
+} PncGemmParams;
+
+int pnc_gemm_f16(const PncGemmParams* p, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * 2. View-sliced flash attention, head dim 64, fp16 in/out, fp32 softmax/acc.
+ *    q rows/kv rows live in token matrices (row m = (group g, y, x)); the query
+ *    grid of one group is H x W split along the width into `views` equal slices.
+ *    For query view v the key set is the concatenation of kv views
+ *    seg[v][0..nseg[v]) of kv group (g / q_per_kv).
+ *    K is row-major [rows][ldk]; V is channel-major ("V^T"):
+ *        vt[kvg*vt_gstride + (head*64+d)*ldvt + token]
+ *    Only the first kv_valid keys of each kv view exist (rest masked).
+ *     -> xformers.ops.memory_efficient_attention (attention.py:469 intra-view,
+ *        :590 inter-view incl. the view-5 quirk, :363) and
+ *        F.scaled_dot_product_attention (attention.py:281) for text keys.
+ * ------------------------------------------------------------------------- */
+typedef struct PncAttnParams {
+    const void* q;  int32_t ldq;    /* fp16, head h at column h*64 */
+    const void* k;  int32_t ldk;
+    const void* vt; int32_t ldvt; int64_t vt_gstride;
+    void* o;        int32_t ldo;
+    int32_t groups;                 /* number of q groups (frames) */
+    int32_t heads;
+    int32_t H, W, views;            /* q grid per group, W % views == 0 */
+    int32_t kvH, kvW, kv_views;     /* kv grid per kv group */
+    int32_t kv_rows_per_group;      /* rows of K per kv group */
+    int32_t q_per_kv;               /* kv group = g / q_per_kv */
+    int32_t kv_valid;               /* valid keys per kv view (<= kvH*kvW/kv_views) */
+    int32_t nseg[8];                /* per q view */
+    int32_t seg[8][2];              /* kv view ids */
+    float scale;                    /* softmax scale (d^-0.5) */
+} PncAttnParams;
+
+int pnc_attn_views_f16(const PncAttnParams* p, void* stream);
+
+/* Temporal self-attention over the T frames of one pixel (head dim 64):
+ *   row m = (b*T+t)*Npix + p; q/k/v fp16 with leading dims; out fp16.
+ *    -> CrossAttention self-attn on "(b h w) t c" (attention.py:229-291, 1106-1134) */
+int pnc_attn_temporal_f16(const void* q, int ldq, const void* k, int ldk,
+                          const void* v, int ldv, void* o, int ldo,
+                          int B, int T, int Npix, int heads, float scale, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * 3. Normalisations (fp32 stream in, fp16 operand out)
+ * ------------------------------------------------------------------------- */
+/* Spatial GroupNorm(32,C) over one frame's (H*W, C/32) slab, two launches.
+ *   stats: partial[(f*nchunk + chunk)*32 + g] = {count, mean, M2}
+ *   apply: y = (x-mean)*rstd*gamma+beta, optional SiLU, -> fp16 [F*Npix][ldy]
+ *    -> nn.GroupNorm (diffusionmodules/util.py:283 eps 1e-5; attention.py:129-132 eps 1e-6) + nn.SiLU */
+int pnc_groupnorm_stats(const float* x, int ldx, int F, int Npix, int C,
+                        int pix_per_chunk, float* partial, void* stream);
+int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int C,
+                        int pix_per_chunk, const float* partial,
+                        const float* gamma, const float* beta, float eps, int silu,
+                        void* y16, int ldy, void* stream);
+/* Temporal GroupNorm(32,C)+SiLU: statistics over the (C/32, T) slab of ONE pixel
+ *    -> nn.GroupNorm applied on "(b h w) c t" (openaimodel.py:409-419,509-515) */
+int pnc_groupnorm_temporal_silu(const float* x, int B, int T, int Npix, int C,
+                                const float* gamma, const float* beta, float eps,
+                                void* y16, void* stream);
+/* LayerNorm over C (eps 1e-5) -> nn.LayerNorm (attention.py:699-701) */
+int pnc_layernorm(const float* x, int ldx, int M, int C,
+                  const float* gamma, const float* beta, float eps,
+                  void* y16, int ldy, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * 4. Small helpers
+ * ------------------------------------------------------------------------- */
+/* out[m][n] = sum_k f(a[m][k]) * W[n][k] + bias[n], f = SiLU if silu_in; a fp32,
+ * W fp16, M <= 16.  -> time_embed / emb_layers Linear (openaimodel.py:936-943,440-447) */
+int pnc_linear_smallm(const float* a, int lda, const void* W, const float* bias,
+                      float* out, int ldo, int M, int N, int K, int silu_in, int silu_out,
+                      void* stream);
+/* sinusoidal timestep embedding out[f] = [cos(t*freqs) | sin(t*freqs)], fp32; freqs[dim/2] is
+ * tabulated by the caller  (diffusionmodules/util.py:224-248) */
+int pnc_timestep_embedding(const int64_t* t, int F, int dim, const float* freqs,
+                           float* out, void* stream);
+/* NCHW (fp32) -> channels-last fp16 with optional second source (channel concat)
+ * and zero padding to Cpad: out[f][p][c] = c<C1 ? a[f][c][p]*sa : c<C1+C2 ? b[f][c-C1][p] : 0
+ *    -> torch.cat in wrappers.py:41 + layout change */
+int pnc_nchw_to_tokens_f16(const float* a, int C1, const float* b, int C2,
+                           int F, int Npix, int Cpad, void* out16, void* stream);
+/* channels-last fp32 [F*Npix][ld] -> NCHW fp32 (first C columns) */
+int pnc_tokens_to_nchw_f32(const float* x, int ld, int F, int Npix, int C,
+                           float* out, void* stream);
+/* out32[m][0:C1] = a[m][:], out32[m][C1:C1+C2] = s[m][:] + c[m][:]; optional fp16 copy
+ *    -> th.cat([h, hs.pop() + control.pop()], dim=1)  (controlmodel.py:193-195) */
+int pnc_concat_add(const float* a, int C1, const float* s, const float* c, int C2,
+                   int64_t M, float* out32, void* out16, void* stream);
+/* y = x + a (fp32, may be in place); optional fp16 copy of y
+ *    -> h += guided_hint / h += control.pop()  (controlmodel.py:127,192) */
+int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16,
+                void* stream);
+/* fp32 -> fp16 */
+int pnc_cast_f16(const float* x, int64_t n, void* y16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANACEA_HIP_H */

@@ -1,0 +1,313 @@
+// attn.hip — attention kernels of the decomposed-4D attention (gfx950).
+//
+// 1. attn_views_kernel: flash-style attention, head dim 64, over width-sliced "views" of a token
+//    grid.  Covers intra-view, cross-view (incl. the view-5 one-neighbour quirk) and text
+//    cross-attention (include/panacea_hip.h §2).  No tensor is ever re-laid out: a view is a
+//    strided window of the (H, W) token grid, addressed directly.
+//
+//    Everything is computed TRANSPOSED so that one lane owns one query:
+//        S^T[key][q] = K Q^T      (A = K tile rows, B = Q fragment kept in registers)
+//        O^T[d][q]   = V^T P^T    (A = V^T tile rows, B = P converted in-register)
+//    With v_mfma_f32_32x32x16_f16 the C/D column is lane&31, so the softmax statistics (m, l),
+//    the probabilities and the output accumulator of query q all live in lane q (and its partner
+//    lane q+32, which holds the other half of the keys): the only cross-lane traffic per KV tile is
+//    one xor-32 exchange of the running max.  K rows are fed to the MFMA in the permuted order
+//    pi(i) = 16*((i>>2)&1) + 4*(i>>3) + (i&3) so that lane group g = lane>>5 ends up holding the 16
+//    CONSECUTIVE keys 16g..16g+15 of each 32-key half; P then feeds the second MFMA directly as the
+//    B operand and the matching V^T fragment is one 16-byte LDS read (keys contiguous because V is
+//    produced channel-major by the projection GEMM's transposed epilogue).
+//
+// 2. attn_temporal_kernel: self-attention over the T <= 8 frames of one pixel.  25 GFLOP per step
+//    in total, so it is a bandwidth-bound VALU kernel: 8 lanes per (token, head), 16-byte loads.
+#include "common.h"
+
+namespace {
+
+constexpr int QT = 128;   // queries per workgroup (4 waves x 32)
+constexpr int KT = 64;    // keys per tile
+
+__device__ __forceinline__ int kperm(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
+
+__global__ __launch_bounds__(256) void attn_views_kernel(const PncAttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];   // [stage][K | Vt][64 rows x 128 B]
+    const half_t* __restrict__ Q = reinterpret_cast<const half_t*>(p.q);
+    const half_t* __restrict__ K = reinterpret_cast<const half_t*>(p.k);
+    const half_t* __restrict__ VT = reinterpret_cast<const half_t*>(p.vt);
+    half_t* __restrict__ O = reinterpret_cast<half_t*>(p.o);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qtile = blockIdx.x, view = blockIdx.y;
+    const int g = blockIdx.z / p.heads, head = blockIdx.z % p.heads;
+    const int Wv = p.W / p.views, Nq = p.H * Wv;
+    const int kvWv = p.kvW / p.kv_views;
+    const int Nkv = p.kvH * kvWv;                    // keys per kv view (multiple of 8)
+    const int kvg = g / p.q_per_kv;
+    const int hc = head * 64;
+
+    // ---- this lane's query (column of S^T / O^T) ----
+    const int ql = qtile * QT + wave * 32 + (lane & 31);   // view-local query index
+    const bool qok = ql < Nq;
+    const int qlc = qok ? ql : (Nq - 1);
+    const int qy = qlc / Wv, qx = view * Wv + (qlc - qy * Wv);
+    const int64_t qrow = ((int64_t)g * p.H + qy) * p.W + qx;
+    const int grp = lane >> 5;
+    half8v qf[4];
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds)
+        qf[ds] = *reinterpret_cast<const half8v*>(Q + qrow * p.ldq + hc + ds * 16 + grp * 8);
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.0f; oacc[1][r] = 0.0f; }
+    float mrun = -1e30f, lrun = 0.0f;
+    const float sc = p.scale * 1.44269504088896340736f;   // exp2 domain
+
+    // ---- staging assignment: 16-B chunk column sc8 of rows sr and sr+32 ----
+    const int sc8 = tid & 7, sr = tid >> 3;
+    const int nseg = p.nseg[view];
+    const int tiles_per_seg = (Nkv + KT - 1) / KT;
+    const int ntiles = nseg * tiles_per_seg;
+
+    half8v rk[2], rv[2];
+    auto load_tile = [&](int t) {
+        const int s = t / tiles_per_seg, tt = t - s * tiles_per_seg;
+        const int kview = p.seg[view][s];
+        const int key0 = tt * KT;
+        half8v z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // K: row = key (sr + 32 i), chunk = 8 channels
+            const int key = key0 + sr + 32 * i;
+            if (key < Nkv) {
+                const int ky = key / kvWv, kx = kview * kvWv + (key - ky * kvWv);
+                const int64_t krow = (int64_t)kvg * p.kv_rows_per_group + (int64_t)ky * p.kvW + kx;
+                rk[i] = *reinterpret_cast<const half8v*>(K + krow * p.ldk + hc + sc8 * 8);
+            } else rk[i] = z;
+            // V^T: row = channel d (sr + 32 i), chunk = 8 consecutive keys
+            const int d = sr + 32 * i;
+            const int kc = key0 + sc8 * 8;
+            if (kc < Nkv) {
+                const int ky = kc / kvWv, kx = kview * kvWv + (kc - ky * kvWv);
+                rv[i] = *reinterpret_cast<const half8v*>(
+                    VT + (int64_t)kvg * p.vt_gstride + (int64_t)(hc + d) * p.ldvt + (int64_t)ky * p.kvW + kx);
+            } else rv[i] = z;
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* sk = smem + stage * (2 * KT * 128);
+        char* sv = sk + KT * 128;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<half8v*>(sk + lds_off128(sr + 32 * i, sc8)) = rk[i];
+            *reinterpret_cast<half8v*>(sv + lds_off128(sr + 32 * i, sc8)) = rv[i];
+        }
+    };
+
+    if (ntiles > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int frow = lane & 31;
+    const int krow_lds = kperm(frow);
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = (t + 1) < ntiles;
+        if (more) load_tile(t + 1);
+        const char* sk = smem + (t & 1) * (2 * KT * 128);
+        const char* sv = sk + KT * 128;
+        const int tt = t % tiles_per_seg;
+        const int key0 = tt * KT;
+
+        // ---- S^T = K Q^T : two 32-key halves ----
+        f32x16 s[2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kh][r] = 0.0f;
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const half8v kf = *reinterpret_cast<const half8v*>(
+                    sk + lds_off128(kh * 32 + krow_lds, ds * 2 + grp));
+                s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ds], s[kh], 0, 0, 0);
+            }
+        }
+        // lane holds keys key0 + kh*32 + grp*16 + r  (r = 0..15)
+        float tmax = -1e30f;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + kh * 32 + grp * 16 + r;
+                const float v = (key < p.kv_valid) ? s[kh][r] * sc : -1e30f;
+                s[kh][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrun, tmax);
+        const float alpha = exp2f(mrun - mnew);
+        mrun = mnew;
+        float psum = 0.0f;
+        half8v pf[2][2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // masked entries: (-1e30 - mnew) -> exp2 -> 0 (mnew is finite once any key is valid)
+                const float pv = exp2f(s[kh][r] - mnew);
+                psum += pv;
+                pf[kh][r >> 3][r & 7] = (half_t)pv;
+            }
+        lrun = lrun * alpha + psum;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dh][r] *= alpha;
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const half8v vf = *reinterpret_cast<const half8v*>(
+                        sv + lds_off128(dh * 32 + frow, kh * 4 + grp * 2 + ss));
+                    oacc[dh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kh][ss], oacc[dh], 0, 0, 0);
+                }
+        if (more) store_tile((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane owns query ql, channels d = 32*dh + mfma32_row(r, lane) ----
+    const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+    const float inv = ltot > 0.0f ? 1.0f / ltot : 0.0f;
+    if (qok) {
+        half_t* orow = O + qrow * p.ldo + hc;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                half4v h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h[q] = (half_t)(oacc[dh][r4 * 4 + q] * inv);
+                *reinterpret_cast<half4v*>(orow + dh * 32 + 8 * r4 + 4 * grp) = h;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// temporal attention: lane = slot*8 + dl ; slot -> (pixel sub-index, frame t) ; dl -> 8 channels
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot8(const half8v a, const half8v b) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s = fmaf((float)a[i], (float)b[i], s);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void attn_temporal_kernel(
+    const half_t* __restrict__ Q, int ldq, const half_t* __restrict__ Kp, int ldk,
+    const half_t* __restrict__ Vp, int ldv, half_t* __restrict__ O, int ldo,
+    int B, int T, int Npix, int heads, float scale, int ppw, int64_t nwork) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // wave work item
+    if (w >= nwork) return;
+    // work item -> (b, pixel group, head); head fastest so neighbouring waves share DRAM pages
+    const int head = (int)(w % heads);
+    const int64_t pg = w / heads;
+    const int groups_per_b = (Npix + ppw - 1) / ppw;
+    const int b = (int)(pg / groups_per_b);
+    const int p0 = (int)(pg % groups_per_b) * ppw;
+    const int slot = lane >> 3, dl = lane & 7;
+    const int ps = slot / T, t = slot - ps * T;
+    const int pix = p0 + ps;
+    const bool ok = (ps < ppw) && (pix < Npix);
+    const int pixc = ok ? pix : p0;
+    const int tc = ok ? t : 0;
+    const int col = head * 64 + dl * 8;
+    const int64_t row_q = ((int64_t)(b * T + tc)) * Npix + pixc;
+    const half8v q = *reinterpret_cast<const half8v*>(Q + row_q * ldq + col);
+    float sc[8];
+    float mx = -1e30f;
+    const float c = scale * 1.44269504088896340736f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s < T) {
+            const int64_t row_k = ((int64_t)(b * T + s)) * Npix + pixc;
+            const half8v k = *reinterpret_cast<const half8v*>(Kp + row_k * ldk + col);
+            float d = dot8(q, k);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            sc[s] = d * c;
+            mx = fmaxf(mx, sc[s]);
+        } else sc[s] = -1e30f;
+    }
+    float l = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { sc[s] = (s < T) ? exp2f(sc[s] - mx) : 0.0f; l += sc[s]; }
+    const float inv = 1.0f / l;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s < T) {
+            const int64_t row_v = ((int64_t)(b * T + s)) * Npix + pixc;
+            const half8v v = *reinterpret_cast<const half8v*>(Vp + row_v * ldv + col);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(sc[s], (float)v[i], acc[i]);
+        }
+    }
+    if (ok) {
+        half8v o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (half_t)(acc[i] * inv);
+        *reinterpret_cast<half8v*>(O + row_q * ldo + col) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
+    if (!pp) return PNC_EINVAL;
+    const PncAttnParams& p = *pp;
+    if (!p.q || !p.k || !p.vt || !p.o) return PNC_EINVAL;
+    if (p.views < 1 || p.views > 8 || p.kv_views < 1 || p.kv_views > 8) return PNC_EINVAL;
+    if (p.W % p.views || p.kvW % p.kv_views) return PNC_EINVAL;
+    const int kvWv = p.kvW / p.kv_views;
+    if (kvWv % 8 || p.kvW % 8) return PNC_EALIGN;                 // 8-key V^T chunks stay inside a row
+    if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.vt_gstride % 8 || p.ldo % 4) return PNC_EALIGN;
+    if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.vt) & 15) return PNC_EALIGN;
+    if ((uintptr_t)p.o & 7) return PNC_EALIGN;
+    if (p.q_per_kv < 1 || p.groups < 1 || p.heads < 1) return PNC_EINVAL;
+    if (p.kv_valid < 1 || p.kv_valid > p.kvH * kvWv) return PNC_EINVAL;
+    for (int v = 0; v < p.views; ++v) {
+        if (p.nseg[v] < 1 || p.nseg[v] > 2) return PNC_EINVAL;
+        for (int s = 0; s < p.nseg[v]; ++s)
+            if (p.seg[v][s] < 0 || p.seg[v][s] >= p.kv_views) return PNC_EINVAL;
+    }
+    const int Nq = p.H * (p.W / p.views);
+    dim3 grid((Nq + QT - 1) / QT, p.views, p.groups * p.heads);
+    hipLaunchKernelGGL(attn_views_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return pnc_launch_status();
+}
+
+extern "C" int pnc_attn_temporal_f16(const void* q, int ldq, const void* k, int ldk,
+                                     const void* v, int ldv, void* o, int ldo,
+                                     int B, int T, int Npix, int heads, float scale, void* stream) {
+    if (!q || !k || !v || !o) return PNC_EINVAL;
+    if (T < 1 || T > 8 || B < 1 || Npix < 1 || heads < 1) return PNC_EINVAL;
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8) return PNC_EALIGN;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return PNC_EALIGN;
+    const int ppw = 8 / T;
+    const int64_t nwork = (int64_t)B * ((Npix + ppw - 1) / ppw) * heads;
+    const int64_t blocks = (nwork + 3) / 4;
+    hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const half_t*>(q), ldq, reinterpret_cast<const half_t*>(k), ldk,
+                       reinterpret_cast<const half_t*>(v), ldv, reinterpret_cast<half_t*>(o), ldo,
+                       B, T, Npix, heads, scale, ppw, nwork);
+    return pnc_launch_status();
+}

@@ -1,0 +1,51 @@
+// common.h — shared device helpers for the gfx950 kernels (wave64, MFMA 32x32x16 f16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "panacea_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define PNC_WAVE 64
+
+// MFMA C/D fragment map of v_mfma_f32_32x32x16_f16 (MI355X_MICROARCH / CDNA4 guide §3):
+//   column = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+__device__ __forceinline__ int mfma32_row(int reg, int lane) {
+    return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+// 128-byte LDS rows (64 fp16) hold eight 16-byte chunks; XOR-swizzle the chunk index with
+// (row>>1)&7 so that the 16-lane groups of ds_read_b128 (rows differ, chunk equal) hit
+// sixteen distinct 16-B slots of the 256-B bank row.
+__device__ __forceinline__ int lds_off128(int row, int chunk) {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu_erf_f(float v) {
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block id -> XCD-contiguous tile id (bijective for any nblk; guide §5 "XCD swizzle must be bijective")
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static inline int pnc_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PNC_OK : (int)e;
+}

@@ -1,0 +1,204 @@
+// misc.hip — small HBM-bound helpers of the denoising path: time-embedding MLP (small-M fp32
+// linear), sinusoidal embedding, NCHW <-> channels-last conversion, skip/control concat-add.
+#include "common.h"
+
+namespace {
+
+constexpr int SM_MAXM = 16;
+
+// one wave per output column n: out[m][n] = sum_k f(a[m][k]) W[n][k] + bias[n]
+__global__ __launch_bounds__(256) void linear_smallm_kernel(const float* __restrict__ a, int lda,
+                                                            const half_t* __restrict__ W,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ out, int ldo, int M, int N,
+                                                            int K, int silu_in, int silu_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[SM_MAXM];
+#pragma unroll
+    for (int m = 0; m < SM_MAXM; ++m) acc[m] = 0.0f;
+    for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
+        const half8v w = *reinterpret_cast<const half8v*>(W + (int64_t)n * K + k0);
+        float wf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wf[e] = (float)w[e];
+#pragma unroll
+        for (int m = 0; m < SM_MAXM; ++m) {
+            if (m < M) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(a + (int64_t)m * lda + k0);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(a + (int64_t)m * lda + k0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u0 = silu_in ? silu_f(x0[e]) : x0[e];
+                    const float u1 = silu_in ? silu_f(x1[e]) : x1[e];
+                    acc[m] = fmaf(u0, wf[e], acc[m]);
+                    acc[m] = fmaf(u1, wf[e + 4], acc[m]);
+                }
+            }
+        }
+    }
+    const float b = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int m = 0; m < SM_MAXM; ++m) {
+        if (m < M) {
+            float v = wave_sum(acc[m]) + b;
+            if (silu_out) v = silu_f(v);
+            if (lane == 0) out[(int64_t)m * ldo + n] = v;
+        }
+    }
+}
+
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int F, int dim,
+                                          const float* __restrict__ freqs, float* __restrict__ out) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F * half) return;
+    const int f = i / half, j = i - f * half;
+    // freqs[j] = exp(-ln(max_period) * j / half) is tabulated by the host exactly as
+    // diffusionmodules/util.py:236-241 does (fp32), so only cos/sin run here.
+    const float arg = (float)t[f] * freqs[j];
+    out[(int64_t)f * dim + j] = cosf(arg);
+    out[(int64_t)f * dim + half + j] = sinf(arg);
+    if ((dim & 1) && j == 0) out[(int64_t)f * dim + dim - 1] = 0.0f;
+}
+
+// thread per (f, pixel): gather channels (stride Npix), write Cpad fp16 contiguous
+__global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __restrict__ a, int C1,
+                                                             const float* __restrict__ b, int C2, int F,
+                                                             int Npix, int Cpad, half_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)F * Npix) return;
+    const int64_t f = i / Npix, pix = i - f * Npix;
+    half_t* o = out + i * Cpad;
+    for (int c0 = 0; c0 < Cpad; c0 += 8) {
+        half8v h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            float v = 0.0f;
+            if (c < C1) v = a[(f * C1 + c) * Npix + pix];
+            else if (c < C1 + C2) v = b[(f * C2 + (c - C1)) * Npix + pix];
+            h[e] = (half_t)v;
+        }
+        *reinterpret_cast<half8v*>(o + c0) = h;
+    }
+}
+
+__global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const float* __restrict__ x, int ld, int F,
+                                                             int Npix, int C, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)F * Npix) return;
+    const int64_t f = i / Npix, pix = i - f * Npix;
+    for (int c = 0; c < C; ++c) out[(f * C + c) * Npix + pix] = x[i * ld + c];
+}
+
+// float4 granularity over the concatenated row
+__global__ __launch_bounds__(256) void concat_add_kernel(const float* __restrict__ a, int C1,
+                                                         const float* __restrict__ s,
+                                                         const float* __restrict__ c, int C2, int64_t M,
+                                                         float* __restrict__ out32, half_t* __restrict__ out16) {
+    const int CT = C1 + C2, V = CT >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * V) return;
+    const int64_t m = i / V;
+    const int ch = (int)(i - m * V) * 4;
+    f32x4 v;
+    if (ch < C1) {
+        v = *reinterpret_cast<const f32x4*>(a + m * C1 + ch);
+    } else {
+        const int c2 = ch - C1;
+        v = *reinterpret_cast<const f32x4*>(s + m * C2 + c2);
+        if (c) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(c + m * C2 + c2);
+            v += w;
+        }
+    }
+    if (out32) *reinterpret_cast<f32x4*>(out32 + m * CT + ch) = v;
+    if (out16) {
+        half4v h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4v*>(out16 + m * CT + ch) = h;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                  int64_t n4, float* __restrict__ y32, half_t* __restrict__ y16) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    if (a) { const f32x4 w = *reinterpret_cast<const f32x4*>(a + i * 4); v += w; }
+    if (y32) *reinterpret_cast<f32x4*>(y32 + i * 4) = v;
+    if (y16) {
+        half4v h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4v*>(y16 + i * 4) = h;
+    }
+}
+
+}  // namespace
+
+extern "C" const char* pnc_version(void) { return "panacea_hip 0.1.0 gfx950"; }
+
+extern "C" int pnc_linear_smallm(const float* a, int lda, const void* W, const float* bias,
+                                 float* out, int ldo, int M, int N, int K, int silu_in, int silu_out,
+                                 void* stream) {
+    if (!a || !W || !out || M < 1 || M > SM_MAXM || N < 1 || K < 8) return PNC_EINVAL;
+    if (K % 8 || lda % 4) return PNC_EINVAL;
+    if (((uintptr_t)a | (uintptr_t)W) & 15) return PNC_EALIGN;
+    hipLaunchKernelGGL(linear_smallm_kernel, dim3((N + 3) / 4), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a, lda, reinterpret_cast<const half_t*>(W), bias,
+                       out, ldo, M, N, K, silu_in, silu_out);
+    return pnc_launch_status();
+}
+
+extern "C" int pnc_timestep_embedding(const int64_t* t, int F, int dim, const float* freqs,
+                                      float* out, void* stream) {
+    if (!t || !out || !freqs || F < 1 || dim < 2) return PNC_EINVAL;
+    const int n = F * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), t, F, dim, freqs, out);
+    return pnc_launch_status();
+}
+
+extern "C" int pnc_nchw_to_tokens_f16(const float* a, int C1, const float* b, int C2,
+                                      int F, int Npix, int Cpad, void* out16, void* stream) {
+    if (!a || !out16 || F < 1 || Npix < 1 || C1 < 1 || C2 < 0 || (C2 > 0 && !b)) return PNC_EINVAL;
+    if (Cpad % 8 || Cpad < C1 + C2) return PNC_EINVAL;
+    if ((uintptr_t)out16 & 15) return PNC_EALIGN;
+    const int64_t n = (int64_t)F * Npix;
+    hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a, C1, b, C2, F, Npix, Cpad,
+                       reinterpret_cast<half_t*>(out16));
+    return pnc_launch_status();
+}
+
+extern "C" int pnc_tokens_to_nchw_f32(const float* x, int ld, int F, int Npix, int C,
+                                      float* out, void* stream) {
+    if (!x || !out || F < 1 || Npix < 1 || C < 1 || ld < C) return PNC_EINVAL;
+    const int64_t n = (int64_t)F * Npix;
+    hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, ld, F, Npix, C, out);
+    return pnc_launch_status();
+}
+
+extern "C" int pnc_concat_add(const float* a, int C1, const float* s, const float* c, int C2,
+                              int64_t M, float* out32, void* out16, void* stream) {
+    if (!a || !s || M < 1 || C1 % 4 || C2 % 4 || C1 < 4 || C2 < 4) return PNC_EINVAL;
+    if (!out32 && !out16) return PNC_EINVAL;
+    const int64_t n = M * ((C1 + C2) / 4);
+    hipLaunchKernelGGL(concat_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a, C1, s, c, C2, M, out32,
+                       reinterpret_cast<half_t*>(out16));
+    return pnc_launch_status();
+}
+
+extern "C" int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16, void* stream) {
+    if (!x || n < 4 || n % 4 || (!y32 && !y16)) return PNC_EINVAL;
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, a, n4, y32, reinterpret_cast<half_t*>(y16));
+    return pnc_launch_status();
+}
+
+extern "C" int pnc_cast_f16(const float* x, int64_t n, void* y16, void* stream) {
+    return pnc_add_f32(x, nullptr, n, nullptr, y16, stream);
+}

@@ -1,0 +1,249 @@
+"""ctypes binding of libpanacea_hip.so (the C-ABI declared in include/panacea_hip.h).
+
+This is the ONLY compute backend of the package: there is no CPU or eager fallback.  Importing the
+module is cheap; the shared object is loaded on first use and a missing / stale library raises
+`HipLibraryError` (run `python -m panacea_amd.build`).  Every wrapper takes torch tensors that already
+live in HBM, enqueues on the CURRENT torch stream and returns immediately (hipGraph-capturable).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "lib" / "libpanacea_hip.so"
+HEADER = PKG.parent / "include" / "panacea_hip.h"
+
+A_PLAIN, A_CONV3X3, A_CONV1D_T = 0, 1, 2
+ACT_NONE, ACT_SILU = 0, 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class PncError(RuntimeError):
+    pass
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("a_mode", C.c_int32),
+        ("Cin", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32),
+        ("Wout", C.c_int32), ("stride", C.c_int32), ("upsample", C.c_int32),
+        ("T", C.c_int32), ("Npix", C.c_int32),
+        ("bias", C.c_void_p), ("rowbias", C.c_void_p),
+        ("rb_rows", C.c_int32), ("rb_mod", C.c_int32),
+        ("res1", C.c_void_p), ("ldr1", C.c_int32),
+        ("res2", C.c_void_p), ("ldr2", C.c_int32),
+        ("out32", C.c_void_p), ("ldc32", C.c_int32),
+        ("out16", C.c_void_p), ("ldc16", C.c_int32),
+        ("out16t", C.c_void_p), ("ldt", C.c_int32), ("t_rows", C.c_int32), ("t_gstride", C.c_int64),
+        ("n_split", C.c_int32), ("act", C.c_int32), ("geglu", C.c_int32),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("ldq", C.c_int32),
+        ("k", C.c_void_p), ("ldk", C.c_int32),
+        ("vt", C.c_void_p), ("ldvt", C.c_int32), ("vt_gstride", C.c_int64),
+        ("o", C.c_void_p), ("ldo", C.c_int32),
+        ("groups", C.c_int32), ("heads", C.c_int32),
+        ("H", C.c_int32), ("W", C.c_int32), ("views", C.c_int32),
+        ("kvH", C.c_int32), ("kvW", C.c_int32), ("kv_views", C.c_int32),
+        ("kv_rows_per_group", C.c_int32), ("q_per_kv", C.c_int32), ("kv_valid", C.c_int32),
+        ("nseg", C.c_int32 * 8), ("seg", (C.c_int32 * 2) * 8),
+        ("scale", C.c_float),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGNATURES = {
+    "pnc_version": (C.c_char_p, []),
+    "pnc_gemm_f16": (_I, [C.POINTER(GemmParams), _P]),
+    "pnc_attn_views_f16": (_I, [C.POINTER(AttnParams), _P]),
+    "pnc_attn_temporal_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "pnc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "pnc_groupnorm_apply": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P]),
+    "pnc_groupnorm_temporal_silu": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P]),
+    "pnc_layernorm": (_I, [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P]),
+    "pnc_linear_smallm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "pnc_timestep_embedding": (_I, [_P, _I, _I, _P, _P, _P]),
+    "pnc_nchw_to_tokens_f16": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "pnc_tokens_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "pnc_concat_add": (_I, [_P, _I, _P, _P, _I, _L, _P, _P, _P]),
+    "pnc_add_f32": (_I, [_P, _P, _L, _P, _P, _P]),
+    "pnc_cast_f16": (_I, [_P, _L, _P, _P]),
+}
+
+_lib = None
+
+
+def header_symbols() -> list[str]:
+    """Every function name declared in include/panacea_hip.h."""
+    txt = HEADER.read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pnc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load():
+    """Load the shared library (once) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: the HIP extension is the only compute path of panacea_amd. "
+            "Build it with `python -m panacea_amd.build` (hipcc --offload-arch=gfx950).")
+    try:
+        lib = C.CDLL(str(LIB_PATH))
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "PNC_EINVAL (unsupported shape/argument)", -2: "PNC_EALIGN (alignment)"}.get(rc, f"hipError {rc}")
+        raise PncError(f"{what} failed: {kind}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PncError("panacea_amd kernels need tensors resident in HBM (got a CPU tensor); "
+                       "there is no CPU fallback")
+    return t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype:
+        raise PncError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise PncError(f"{name}: tensor must be contiguous")
+
+
+# ----------------------------------------------------------------------------------------------
+# wrappers (names mirror the C entry points)
+# ----------------------------------------------------------------------------------------------
+def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: int = 0,
+         a_mode: int = A_PLAIN, conv: Optional[dict] = None, tconv: Optional[dict] = None,
+         bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
+         rb_rows: int = 0, rb_mod: int = 0,
+         res1: Optional[torch.Tensor] = None, ldr1: int = 0,
+         res2: Optional[torch.Tensor] = None, ldr2: int = 0,
+         out32: Optional[torch.Tensor] = None, ldc32: int = 0,
+         out16: Optional[torch.Tensor] = None, ldc16: int = 0,
+         out16t: Optional[torch.Tensor] = None, ldt: int = 0, t_rows: int = 0, t_gstride: int = 0,
+         n_split: int = 0, act: int = ACT_NONE, geglu: bool = False):
+    p = GemmParams()
+    p.A, p.W = _ptr(a16), _ptr(w16)
+    p.M, p.N, p.K, p.lda, p.a_mode = M, N, K, lda, a_mode
+    if conv:
+        p.Cin, p.Hin, p.Win = conv["Cin"], conv["Hin"], conv["Win"]
+        p.Hout, p.Wout = conv["Hout"], conv["Wout"]
+        p.stride, p.upsample = conv.get("stride", 1), int(conv.get("upsample", 0))
+    if tconv:
+        p.Cin, p.T, p.Npix = tconv["C"], tconv["T"], tconv["Npix"]
+    p.bias, p.rowbias, p.rb_rows, p.rb_mod = _ptr(bias), _ptr(rowbias), rb_rows, rb_mod
+    p.res1, p.ldr1, p.res2, p.ldr2 = _ptr(res1), ldr1, _ptr(res2), ldr2
+    p.out32, p.ldc32, p.out16, p.ldc16 = _ptr(out32), ldc32, _ptr(out16), ldc16
+    p.out16t, p.ldt, p.t_rows, p.t_gstride = _ptr(out16t), ldt, t_rows, t_gstride
+    p.n_split = n_split if out16t is not None else N
+    p.act, p.geglu = act, int(geglu)
+    _check(load().pnc_gemm_f16(C.byref(p), _stream()), "pnc_gemm_f16")
+
+
+def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H, W, views,
+               kvH, kvW, kv_views, kv_rows_per_group, q_per_kv, kv_valid, segs, scale):
+    p = AttnParams()
+    p.q, p.ldq, p.k, p.ldk = _ptr(q), ldq, _ptr(k), ldk
+    p.vt, p.ldvt, p.vt_gstride, p.o, p.ldo = _ptr(vt), ldvt, vt_gstride, _ptr(o), ldo
+    p.groups, p.heads, p.H, p.W, p.views = groups, heads, H, W, views
+    p.kvH, p.kvW, p.kv_views = kvH, kvW, kv_views
+    p.kv_rows_per_group, p.q_per_kv, p.kv_valid = kv_rows_per_group, q_per_kv, kv_valid
+    for v, s in enumerate(segs):
+        p.nseg[v] = len(s)
+        for j, u in enumerate(s):
+            p.seg[v][j] = u
+    p.scale = scale
+    _check(load().pnc_attn_views_f16(C.byref(p), _stream()), "pnc_attn_views_f16")
+
+
+def attn_temporal(q, ldq, k, ldk, v, ldv, o, ldo, *, B, T, Npix, heads, scale):
+    _check(load().pnc_attn_temporal_f16(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(o), ldo,
+                                        B, T, Npix, heads, scale, _stream()), "pnc_attn_temporal_f16")
+
+
+def groupnorm_stats(x32, ldx, F, Npix, Cch, ppc, partial):
+    _check(load().pnc_groupnorm_stats(_ptr(x32), ldx, F, Npix, Cch, ppc, _ptr(partial), _stream()),
+           "pnc_groupnorm_stats")
+
+
+def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy):
+    _check(load().pnc_groupnorm_apply(_ptr(x32), ldx, F, Npix, Cch, ppc, _ptr(partial), _ptr(gamma),
+                                      _ptr(beta), eps, int(silu), _ptr(y16), ldy, _stream()),
+           "pnc_groupnorm_apply")
+
+
+def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16):
+    _check(load().pnc_groupnorm_temporal_silu(_ptr(x32), B, T, Npix, Cch, _ptr(gamma), _ptr(beta), eps,
+                                              _ptr(y16), _stream()), "pnc_groupnorm_temporal_silu")
+
+
+def layernorm(x32, ldx, M, Cch, gamma, beta, eps, y16, ldy):
+    _check(load().pnc_layernorm(_ptr(x32), ldx, M, Cch, _ptr(gamma), _ptr(beta), eps, _ptr(y16), ldy,
+                                _stream()), "pnc_layernorm")
+
+
+def linear_smallm(a32, lda, w16, bias, out32, ldo, M, N, K, silu_in=False, silu_out=False):
+    _check(load().pnc_linear_smallm(_ptr(a32), lda, _ptr(w16), _ptr(bias), _ptr(out32), ldo, M, N, K,
+                                    int(silu_in), int(silu_out), _stream()), "pnc_linear_smallm")
+
+
+def timestep_embedding(t_i64, F, dim, freqs, out32):
+    _check(load().pnc_timestep_embedding(_ptr(t_i64), F, dim, _ptr(freqs), _ptr(out32), _stream()),
+           "pnc_timestep_embedding")
+
+
+def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16):
+    _check(load().pnc_nchw_to_tokens_f16(_ptr(a32), C1, _ptr(b32), C2, F, Npix, Cpad, _ptr(out16),
+                                         _stream()), "pnc_nchw_to_tokens_f16")
+
+
+def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):
+    _check(load().pnc_tokens_to_nchw_f32(_ptr(x32), ld, F, Npix, Cch, _ptr(out32), _stream()),
+           "pnc_tokens_to_nchw_f32")
+
+
+def concat_add(a32, C1, s32, c32, C2, M, out32, out16):
+    _check(load().pnc_concat_add(_ptr(a32), C1, _ptr(s32), _ptr(c32), C2, M, _ptr(out32), _ptr(out16),
+                                 _stream()), "pnc_concat_add")
+
+
+def add_f32(x32, a32, n, y32, y16):
+    _check(load().pnc_add_f32(_ptr(x32), _ptr(a32), n, _ptr(y32), _ptr(y16), _stream()), "pnc_add_f32")
+
+
+def cast_f16(x32, n, y16):
+    _check(load().pnc_cast_f16(_ptr(x32), n, _ptr(y16), _stream()), "pnc_cast_f16")

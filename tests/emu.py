@@ -1,0 +1,230 @@
+"""Plain-torch emulation of every entry point of panacea_amd.hip (same names, same arguments,
+results written into the caller's output tensors).
+
+TEST INFRASTRUCTURE ONLY.  Two uses:
+  * `-m gpu` kernel tests: HIP kernel vs this emulation on the same device tensors;
+  * `-m "not gpu"` host-logic tests: the engine (weight packing, layouts, quirks, graph order) runs
+    on CPU against this module injected in place of `panacea_amd.hip`, and is compared with the oracle.
+The product never imports it: `panacea_amd.hip` has no fallback and raises without the HIP library.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as TF
+
+A_PLAIN, A_CONV3X3, A_CONV1D_T = 0, 1, 2
+ACT_NONE, ACT_SILU = 0, 1
+
+
+class PncError(RuntimeError):
+    pass
+
+
+def _mat(t: torch.Tensor, rows: int, cols: int, ld: int) -> torch.Tensor:
+    """[rows, cols] strided view (row stride ld) of the flat storage of t."""
+    return torch.as_strided(t.reshape(-1), (rows, cols), (ld, 1))
+
+
+def load():
+    return None
+
+
+def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bias=None, rowbias=None,
+         rb_rows=0, rb_mod=0, res1=None, ldr1=0, res2=None, ldr2=0, out32=None, ldc32=0, out16=None,
+         ldc16=0, out16t=None, ldt=0, t_rows=0, t_gstride=0, n_split=0, act=ACT_NONE, geglu=False):
+    assert a16.dtype == torch.float16 and w16.dtype == torch.float16
+    assert K % 8 == 0
+    Wm = w16.reshape(-1)[: N * K].view(N, K).float()
+    if a_mode == A_PLAIN:
+        A = _mat(a16, M, K, lda).float()
+        acc = A @ Wm.t()
+    elif a_mode == A_CONV3X3:
+        Cin, Hin, Win, Hout, Wout = conv["Cin"], conv["Hin"], conv["Win"], conv["Hout"], conv["Wout"]
+        stride, up = conv.get("stride", 1), conv.get("upsample", 0)
+        Fr = M // (Hout * Wout)
+        x = a16.reshape(-1)[: Fr * Hin * Win * Cin].view(Fr, Hin, Win, Cin).permute(0, 3, 1, 2).float()
+        if up:
+            x = TF.interpolate(x, scale_factor=2, mode="nearest")
+        w = Wm.view(N, 3, 3, Cin).permute(0, 3, 1, 2)
+        y = TF.conv2d(x, w, stride=stride, padding=1)
+        assert y.shape[2] == Hout and y.shape[3] == Wout, (y.shape, Hout, Wout)
+        acc = y.permute(0, 2, 3, 1).reshape(M, N)
+    else:
+        Cc, T, Npix = tconv["C"], tconv["T"], tconv["Npix"]
+        B = M // (T * Npix)
+        x = a16.reshape(-1)[: M * Cc].view(B, T, Npix, Cc).permute(0, 2, 3, 1).reshape(B * Npix, Cc, T).float()
+        w = Wm.view(N, 3, Cc).permute(0, 2, 1)
+        y = TF.conv1d(x, w, padding=1)                       # [B*Npix, N, T]
+        acc = y.view(B, Npix, N, T).permute(0, 3, 1, 2).reshape(M, N)
+    v = acc
+    if bias is not None:
+        v = v + bias.reshape(-1)[:N].float()
+    if geglu:
+        assert N % 64 == 0
+        vb = v.view(M, N // 64, 2, 32)
+        v = (vb[:, :, 0, :] * TF.gelu(vb[:, :, 1, :])).reshape(M, N // 2)
+        if out32 is not None:
+            _mat(out32, M, N // 2, ldc32).copy_(v)
+        if out16 is not None:
+            _mat(out16, M, N // 2, ldc16).copy_(v.half())
+        return
+    if rowbias is not None:
+        idx = (torch.arange(M, device=v.device) // rb_rows) % rb_mod
+        v = v + rowbias.reshape(-1)[: rb_mod * N].view(rb_mod, N).float()[idx]
+    if act == ACT_SILU:
+        v = TF.silu(v)
+    if res1 is not None:
+        v = v + _mat(res1, M, N, ldr1)
+    if res2 is not None:
+        v = v + _mat(res2, M, N, ldr2)
+    ns = n_split if out16t is not None else N
+    if out32 is not None:
+        _mat(out32, M, ns, ldc32).copy_(v[:, :ns])
+    if out16 is not None:
+        _mat(out16, M, ns, ldc16).copy_(v[:, :ns].half())
+    if out16t is not None:
+        G = M // t_rows
+        assert G * t_rows == M
+        dst = torch.as_strided(out16t.reshape(-1), (G, N - ns, t_rows), (t_gstride, ldt, 1))
+        dst.copy_(v[:, ns:].half().view(G, t_rows, N - ns).permute(0, 2, 1))
+
+
+def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H, W, views, kvH, kvW,
+               kv_views, kv_rows_per_group, q_per_kv, kv_valid, segs, scale):
+    Cc = heads * 64
+    Wv, kvWv = W // views, kvW // kv_views
+    Q = _mat(q, groups * H * W, Cc, ldq).float().view(groups, H, W, heads, 64)
+    n_kvg = (groups + q_per_kv - 1) // q_per_kv
+    Kall = _mat(k, n_kvg * kv_rows_per_group, Cc, ldk).float().view(n_kvg, kv_rows_per_group, heads, 64)
+    Kall = Kall[:, : kvH * kvW].reshape(n_kvg, kvH, kvW, heads, 64)
+    Vall = torch.as_strided(vt.reshape(-1), (n_kvg, Cc, kvH * kvW), (vt_gstride, ldvt, 1)).float()
+    Vall = Vall.view(n_kvg, heads, 64, kvH, kvW)
+    O = _mat(o, groups * H * W, Cc, ldo).view(groups, H, W, Cc)
+    gidx = torch.arange(groups, device=q.device) // q_per_kv
+    for v in range(views):
+        qv = Q[:, :, v * Wv:(v + 1) * Wv].reshape(groups, H * Wv, heads, 64).permute(0, 2, 1, 3)
+        ks, vs = [], []
+        for u in segs[v]:
+            kk = Kall[:, :, u * kvWv:(u + 1) * kvWv].reshape(n_kvg, kvH * kvWv, heads, 64)[:, :kv_valid]
+            vv = Vall[:, :, :, :, u * kvWv:(u + 1) * kvWv].reshape(n_kvg, heads, 64, kvH * kvWv)[..., :kv_valid]
+            ks.append(kk.permute(0, 2, 1, 3))          # [g, heads, keys, 64]
+            vs.append(vv.permute(0, 1, 3, 2))
+        kc = torch.cat(ks, dim=2)[gidx]
+        vc = torch.cat(vs, dim=2)[gidx]
+        s = torch.einsum("ghqd,ghkd->ghqk", qv, kc) * scale
+        pr = torch.softmax(s, dim=-1)
+        ov = torch.einsum("ghqk,ghkd->ghqd", pr, vc)   # [g, heads, q, 64]
+        ov = ov.permute(0, 2, 1, 3).reshape(groups, H, Wv, Cc)
+        O[:, :, v * Wv:(v + 1) * Wv] = ov.half()
+
+
+def attn_temporal(q, ldq, k, ldk, v, ldv, o, ldo, *, B, T, Npix, heads, scale):
+    Cc = heads * 64
+    M = B * T * Npix
+
+    def g(t, ld):
+        return _mat(t, M, Cc, ld).float().view(B, T, Npix, heads, 64).permute(0, 2, 3, 1, 4)  # b p h t d
+    s = torch.einsum("bphtd,bphsd->bphts", g(q, ldq), g(k, ldk)) * scale
+    pr = torch.softmax(s, dim=-1)
+    ov = torch.einsum("bphts,bphsd->bphtd", pr, g(v, ldv))
+    _mat(o, M, Cc, ldo).copy_(ov.permute(0, 3, 1, 2, 4).reshape(M, Cc).half())
+
+
+def groupnorm_stats(x32, ldx, F, Npix, Cch, ppc, partial):
+    nchunk = (Npix + ppc - 1) // ppc
+    X = _mat(x32, F * Npix, Cch, ldx).view(F, Npix, 32, Cch // 32)
+    P = partial.reshape(-1)[: F * nchunk * 32 * 3].view(F, nchunk, 32, 3)
+    for c in range(nchunk):
+        xs = X[:, c * ppc:(c + 1) * ppc].permute(0, 2, 1, 3).reshape(F, 32, -1)
+        n = xs.shape[-1]
+        mean = xs.mean(-1)
+        P[:, c, :, 0] = n
+        P[:, c, :, 1] = mean
+        P[:, c, :, 2] = ((xs - mean[..., None]) ** 2).sum(-1)
+
+
+def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy):
+    nchunk = (Npix + ppc - 1) // ppc
+    P = partial.reshape(-1)[: F * nchunk * 32 * 3].view(F, nchunk, 32, 3).double()
+    n = P[..., 0].sum(1)
+    mean = (P[..., 0] * P[..., 1]).sum(1) / n
+    m2 = (P[..., 2] + P[..., 0] * (P[..., 1] - mean[:, None]) ** 2).sum(1)
+    rstd = 1.0 / torch.sqrt(m2 / n + eps)
+    X = _mat(x32, F * Npix, Cch, ldx).view(F, Npix, 32, Cch // 32)
+    y = (X - mean.float()[:, None, :, None]) * rstd.float()[:, None, :, None]
+    y = y.reshape(F * Npix, Cch) * gamma.reshape(-1)[:Cch] + beta.reshape(-1)[:Cch]
+    if silu:
+        y = TF.silu(y)
+    _mat(y16, F * Npix, Cch, ldy).copy_(y.half())
+
+
+def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16):
+    X = x32.reshape(-1)[: B * T * Npix * Cch].view(B, T, Npix, Cch).permute(0, 2, 3, 1).reshape(B * Npix, Cch, T)
+    y = TF.silu(TF.group_norm(X, 32, gamma.reshape(-1)[:Cch], beta.reshape(-1)[:Cch], eps))
+    y = y.view(B, Npix, Cch, T).permute(0, 3, 1, 2).reshape(-1)
+    y16.reshape(-1)[: y.numel()].copy_(y.half())
+
+
+def layernorm(x32, ldx, M, Cch, gamma, beta, eps, y16, ldy):
+    X = _mat(x32, M, Cch, ldx)
+    y = TF.layer_norm(X, (Cch,), gamma.reshape(-1)[:Cch], beta.reshape(-1)[:Cch], eps)
+    _mat(y16, M, Cch, ldy).copy_(y.half())
+
+
+def linear_smallm(a32, lda, w16, bias, out32, ldo, M, N, K, silu_in=False, silu_out=False):
+    A = _mat(a32, M, K, lda)
+    if silu_in:
+        A = TF.silu(A)
+    y = A @ w16.reshape(-1)[: N * K].view(N, K).float().t()
+    if bias is not None:
+        y = y + bias.reshape(-1)[:N]
+    if silu_out:
+        y = TF.silu(y)
+    _mat(out32, M, N, ldo).copy_(y)
+
+
+def timestep_embedding(t_i64, F, dim, freqs, out32):
+    args = t_i64.reshape(-1)[:F, None].float() * freqs.reshape(-1)[None, : dim // 2]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    out32.reshape(-1)[: F * dim].view(F, dim)[:, : 2 * (dim // 2)].copy_(emb)
+
+
+def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16):
+    o = out16.reshape(-1)[: F * Npix * Cpad].view(F, Npix, Cpad)
+    o.zero_()
+    o[:, :, :C1] = a32.reshape(F, C1, Npix).permute(0, 2, 1).half()
+    if C2:
+        o[:, :, C1:C1 + C2] = b32.reshape(F, C2, Npix).permute(0, 2, 1).half()
+
+
+def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):
+    X = _mat(x32, F * Npix, Cch, ld).view(F, Npix, Cch)
+    out32.reshape(-1)[: F * Cch * Npix].view(F, Cch, Npix).copy_(X.permute(0, 2, 1))
+
+
+def concat_add(a32, C1, s32, c32, C2, M, out32, out16):
+    a = a32.reshape(-1)[: M * C1].view(M, C1)
+    s = s32.reshape(-1)[: M * C2].view(M, C2)
+    if c32 is not None:
+        s = s + c32.reshape(-1)[: M * C2].view(M, C2)
+    y = torch.cat([a, s], dim=1)
+    if out32 is not None:
+        out32.reshape(-1)[: y.numel()].copy_(y.reshape(-1))
+    if out16 is not None:
+        out16.reshape(-1)[: y.numel()].copy_(y.reshape(-1).half())
+
+
+def add_f32(x32, a32, n, y32, y16):
+    y = x32.reshape(-1)[:n]
+    if a32 is not None:
+        y = y + a32.reshape(-1)[:n]
+    if y16 is not None:
+        y16.reshape(-1)[:n].copy_(y.half())
+    if y32 is not None and (a32 is not None or y32.data_ptr() != x32.data_ptr()):
+        y32.reshape(-1)[:n].copy_(y)
+
+
+def cast_f16(x32, n, y16):
+    add_f32(x32, None, n, None, y16)

@@ -1,0 +1,363 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point of libpanacea_hip.so against the plain
+torch emulation (tests/emu.py, fp32 math on the same device tensors).
+
+Inputs are asymmetric random data (a transposed fragment map cannot pass); shapes cover the tile
+guards (ragged M/N/K), every A-gather mode, every epilogue flag, the view quirks and T < 8.
+"""
+import math
+
+import pytest
+import torch
+
+import emu
+from panacea_amd import hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, scale=1.0, dtype=torch.float32, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) & 0xFFFF) + 17)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def check(name, got, ref, atol, rtol=2e-3):
+    got, ref = got.float(), ref.float()
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    worst = (err - tol).max().item()
+    if worst > 0:
+        idx = torch.nonzero(err > tol)
+        first = idx[0].tolist()
+        raise AssertionError(
+            f"{name}: {idx.shape[0]}/{err.numel()} elements off; max|err|={err.max().item():.4e} "
+            f"(ref max {ref.abs().max().item():.3e}); first bad index {first}: got "
+            f"{got[tuple(first)].item():.5f} ref {ref[tuple(first)].item():.5f}")
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def _run_both(fn_name, make_outs, kwargs_fn):
+    outs_h, outs_e = make_outs(), make_outs()
+    getattr(hip, fn_name)(**kwargs_fn(outs_h))
+    getattr(emu, fn_name)(**kwargs_fn(outs_e))
+    torch.cuda.synchronize()
+    return outs_h, outs_e
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (128, 256, 128), (300, 320, 320), (130, 96, 72),
+                                   (1000, 32, 64), (77, 16, 216), (16, 1280, 320), (3072, 640, 1920)])
+def test_gemm_plain_bias_out32_out16(M, N, K):
+    a = rnd(M, K, dtype=torch.float16)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    bias = rnd(N)
+
+    def outs():
+        return dict(o32=torch.zeros(M, N, device=DEV), o16=torch.zeros(M, N, device=DEV, dtype=torch.float16))
+    h, e = _run_both("gemm", outs, lambda o: dict(
+        a16=a, w16=w, M=M, N=N, K=K, lda=K, bias=bias, out32=o["o32"], ldc32=N, out16=o["o16"], ldc16=N))
+    check("out32", h["o32"], e["o32"], 2e-3)
+    check("out16", h["o16"], e["o16"], 4e-3)
+
+
+def test_gemm_identity_asymmetric():
+    # A = I, asymmetric W: catches a transposed C fragment map or swapped operands exactly
+    M = N = K = 128
+    a = torch.eye(M, device=DEV, dtype=torch.float16)
+    w = (torch.arange(N * K, device=DEV).view(N, K) % 251).to(torch.float16) / 16
+    o = torch.zeros(M, N, device=DEV)
+    hip.gemm(a, w, M=M, N=N, K=K, lda=K, out32=o, ldc32=N)
+    torch.cuda.synchronize()
+    assert torch.equal(o, w.float().t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (200, 128, 64)])
+def test_gemm_epilogue_rowbias_residuals_inplace(M, N, K):
+    a = rnd(M, K, dtype=torch.float16)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    bias, rowb = rnd(N), rnd(4, N)
+    res1_init, res2 = rnd(M, N + 8), rnd(M, N)
+
+    def outs():
+        return dict(o32=res1_init.clone(), o16=torch.zeros(M, N, device=DEV, dtype=torch.float16))
+    # res1 aliases out32 (in-place residual stream), leading dimension N+8
+    h, e = _run_both("gemm", outs, lambda o: dict(
+        a16=a, w16=w, M=M, N=N, K=K, lda=K, bias=bias, rowbias=rowb, rb_rows=50, rb_mod=4,
+        res1=o["o32"], ldr1=N + 8, res2=res2, ldr2=N, out32=o["o32"], ldc32=N + 8, out16=o["o16"], ldc16=N))
+    check("out32", h["o32"], e["o32"], 2e-3)
+    check("out16", h["o16"], e["o16"], 6e-3)
+
+
+def test_gemm_act_silu():
+    M, N, K = 256, 96, 216
+    a, w = rnd(M, K, dtype=torch.float16), rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    bias = rnd(N)
+    h, e = _run_both("gemm", lambda: dict(o=torch.zeros(M, N, device=DEV, dtype=torch.float16)), lambda o: dict(
+        a16=a, w16=w, M=M, N=N, K=K, lda=K, bias=bias, act=hip.ACT_SILU, out16=o["o"], ldc16=N))
+    check("silu", h["o"], e["o"], 4e-3)
+
+
+@pytest.mark.parametrize("M,C", [(256, 64), (384, 320)])
+def test_gemm_geglu(M, C):
+    N, K = 8 * C, C
+    a, w = rnd(M, K, dtype=torch.float16), rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    bias = rnd(N)
+    h, e = _run_both("gemm", lambda: dict(o=torch.zeros(M, N // 2, device=DEV, dtype=torch.float16)), lambda o: dict(
+        a16=a, w16=w, M=M, N=N, K=K, lda=K, bias=bias, geglu=True, out16=o["o"], ldc16=N // 2))
+    check("geglu", h["o"], e["o"], 4e-3)
+
+
+@pytest.mark.parametrize("G,t_rows,C", [(2, 128, 64), (3, 96, 128), (2, 80, 64)])
+def test_gemm_split_transposed_output(G, t_rows, C):
+    # q|k row-major for n < 2C, V^T channel-major for n >= 2C  (QKV projection epilogue)
+    M, N, K = G * t_rows, 3 * C, C
+    ldt = t_rows + 8
+    a, w = rnd(M, K, dtype=torch.float16), rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+
+    def outs():
+        return dict(qk=torch.zeros(M, 2 * C, device=DEV, dtype=torch.float16),
+                    vt=torch.zeros(G, C, ldt, device=DEV, dtype=torch.float16))
+    h, e = _run_both("gemm", outs, lambda o: dict(
+        a16=a, w16=w, M=M, N=N, K=K, lda=K, out16=o["qk"], ldc16=2 * C, out16t=o["vt"], ldt=ldt,
+        t_rows=t_rows, t_gstride=C * ldt, n_split=2 * C))
+    check("qk", h["qk"], e["qk"], 4e-3)
+    check("vt", h["vt"], e["vt"], 4e-3)
+
+
+@pytest.mark.parametrize("F,Hin,Win,Cin,N,stride,up", [
+    (2, 8, 24, 8, 64, 1, 0), (2, 8, 24, 64, 64, 2, 0), (1, 4, 12, 128, 128, 1, 1),
+    (2, 16, 48, 24, 16, 1, 0), (1, 16, 48, 16, 32, 2, 0), (2, 9, 11, 32, 320, 1, 0), (1, 8, 8, 320, 8, 1, 0)])
+def test_gemm_conv3x3(F, Hin, Win, Cin, N, stride, up):
+    if up:
+        Hout, Wout = 2 * Hin, 2 * Win
+    else:
+        Hout, Wout = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
+    M, K = F * Hout * Wout, 9 * Cin
+    x = rnd(F, Hin, Win, Cin, dtype=torch.float16)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    bias = rnd(N)
+    conv = dict(Cin=Cin, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride, upsample=up)
+    h, e = _run_both("gemm", lambda: dict(o=torch.zeros(M, N, device=DEV)), lambda o: dict(
+        a16=x, w16=w, M=M, N=N, K=K, a_mode=hip.A_CONV3X3, conv=conv, bias=bias, out32=o["o"], ldc32=N))
+    check("conv3x3", h["o"], e["o"], 2e-3)
+
+
+@pytest.mark.parametrize("B,T,Npix,C", [(2, 8, 48, 64), (1, 2, 100, 128), (2, 1, 64, 64), (1, 8, 32, 320)])
+def test_gemm_conv1d_temporal(B, T, Npix, C):
+    M, N, K = B * T * Npix, C, 3 * C
+    x = rnd(M, C, dtype=torch.float16)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    bias, emb = rnd(N), rnd(B * T, N)
+    res = rnd(M, N)
+
+    def outs():
+        return dict(o=res.clone())
+    h, e = _run_both("gemm", outs, lambda o: dict(
+        a16=x, w16=w, M=M, N=N, K=K, a_mode=hip.A_CONV1D_T, tconv=dict(C=C, T=T, Npix=Npix), bias=bias,
+        rowbias=emb, rb_rows=Npix, rb_mod=B * T, res1=o["o"], ldr1=N, out32=o["o"], ldc32=N))
+    check("conv1d_t", h["o"], e["o"], 2e-3)
+
+
+# -------------------------------------------------------------------------------------- attention
+INTRA = [[0], [1], [2], [3], [4], [5]]
+CROSS = [[5, 1], [0, 2], [1, 3], [2, 4], [3, 5], [4]]      # view 5 sees view 4 only (reference quirk)
+
+
+def _qkv(G, N, C, seed):
+    q = rnd(G * N, C, dtype=torch.float16, seed=seed)
+    k = rnd(G * N, C, dtype=torch.float16, seed=seed + 1)
+    v = rnd(G * N, C, dtype=torch.float16, seed=seed + 2)
+    vt = v.view(G, N, C).permute(0, 2, 1).contiguous()
+    return q, k, v, vt
+
+
+@pytest.mark.parametrize("G,H,W,heads,segs", [
+    (2, 8, 96, 1, INTRA), (2, 8, 96, 2, CROSS), (1, 4, 48, 2, INTRA), (1, 4, 48, 1, CROSS),
+    (1, 32, 384, 1, CROSS), (2, 16, 16, 1, [[0]]), (1, 16, 192, 2, INTRA)])
+def test_attn_views_self(G, H, W, heads, segs):
+    C, N, views = heads * 64, H * W, len(segs)
+    q, k, _, vt = _qkv(G, N, C, 5)
+    kw = dict(groups=G, heads=heads, H=H, W=W, views=views, kvH=H, kvW=W, kv_views=views,
+              kv_rows_per_group=N, q_per_kv=1, kv_valid=H * (W // views), segs=segs, scale=0.125)
+    oh = torch.zeros(G * N, C, device=DEV, dtype=torch.float16)
+    oe = torch.zeros_like(oh)
+    hip.attn_views(q, C, k, C, vt, N, C * N, oh, C, **kw)
+    emu.attn_views(q, C, k, C, vt, N, C * N, oe, C, **kw)
+    torch.cuda.synchronize()
+    check("attn_views", oh, oe, 3e-3)
+
+
+def test_attn_views_sharp_softmax():
+    # large-magnitude scores: exercises the running-max rescale across KV tiles
+    G, H, W, heads = 1, 8, 96, 1
+    C, N = 64, H * W
+    q, k, _, vt = _qkv(G, N, C, 9)
+    q = q * 4
+    kw = dict(groups=G, heads=heads, H=H, W=W, views=6, kvH=H, kvW=W, kv_views=6, kv_rows_per_group=N,
+              q_per_kv=1, kv_valid=H * (W // 6), segs=CROSS, scale=0.125)
+    oh = torch.zeros(G * N, C, device=DEV, dtype=torch.float16)
+    oe = torch.zeros_like(oh)
+    hip.attn_views(q, C, k, C, vt, N, C * N, oh, C, **kw)
+    emu.attn_views(q, C, k, C, vt, N, C * N, oe, C, **kw)
+    torch.cuda.synchronize()
+    check("attn_views_sharp", oh, oe, 5e-3)
+
+
+@pytest.mark.parametrize("B,T,H,W,heads", [(2, 2, 8, 96, 2), (1, 8, 4, 48, 1)])
+def test_attn_views_text(B, T, H, W, heads):
+    # 77 text keys per sample, padded to 80 rows, shared by the T frames of the sample
+    C, N, G = heads * 64, H * W, B * T
+    q = rnd(G * N, C, dtype=torch.float16, seed=3)
+    k = rnd(B * 80, C, dtype=torch.float16, seed=4)
+    v = rnd(B * 80, C, dtype=torch.float16, seed=6)
+    k.view(B, 80, C)[:, 77:] = 0
+    v.view(B, 80, C)[:, 77:] = 0
+    vt = v.view(B, 80, C).permute(0, 2, 1).contiguous()
+    kw = dict(groups=G, heads=heads, H=H, W=W, views=1, kvH=1, kvW=80, kv_views=1, kv_rows_per_group=80,
+              q_per_kv=T, kv_valid=77, segs=[[0]], scale=0.125)
+    oh = torch.zeros(G * N, C, device=DEV, dtype=torch.float16)
+    oe = torch.zeros_like(oh)
+    hip.attn_views(q, C, k, C, vt, 80, C * 80, oh, C, **kw)
+    emu.attn_views(q, C, k, C, vt, 80, C * 80, oe, C, **kw)
+    torch.cuda.synchronize()
+    check("attn_text", oh, oe, 3e-3)
+
+
+def test_attn_views_strided_qkv_buffer():
+    # q and k live in one [M, 2C] projection buffer (ld = 2C), as the engine lays them out
+    G, H, W, heads = 2, 8, 96, 2
+    C, N = heads * 64, H * W
+    qk = rnd(G * N, 2 * C, dtype=torch.float16, seed=11)
+    _, _, _, vt = _qkv(G, N, C, 12)
+    kw = dict(groups=G, heads=heads, H=H, W=W, views=6, kvH=H, kvW=W, kv_views=6, kv_rows_per_group=N,
+              q_per_kv=1, kv_valid=H * (W // 6), segs=INTRA, scale=0.125)
+    oh = torch.zeros(G * N, C, device=DEV, dtype=torch.float16)
+    oe = torch.zeros_like(oh)
+    hip.attn_views(qk, 2 * C, qk[:, C:], 2 * C, vt, N, C * N, oh, C, **kw)
+    emu.attn_views(qk, 2 * C, qk.reshape(-1)[C:], 2 * C, vt, N, C * N, oe, C, **kw)
+    torch.cuda.synchronize()
+    check("attn_views_strided", oh, oe, 3e-3)
+
+
+@pytest.mark.parametrize("B,T,Npix,heads", [(2, 8, 96, 2), (1, 2, 50, 1), (2, 1, 64, 1), (1, 3, 33, 2)])
+def test_attn_temporal(B, T, Npix, heads):
+    C, M = heads * 64, B * T * Npix
+    qkv = rnd(M, 3 * C, dtype=torch.float16, seed=21)
+    oh = torch.zeros(M, C, device=DEV, dtype=torch.float16)
+    oe = torch.zeros_like(oh)
+    flat = qkv.reshape(-1)
+    hip.attn_temporal(qkv, 3 * C, qkv[:, C:], 3 * C, qkv[:, 2 * C:], 3 * C, oh, C,
+                      B=B, T=T, Npix=Npix, heads=heads, scale=0.125)
+    emu.attn_temporal(flat, 3 * C, flat[C:], 3 * C, flat[2 * C:], 3 * C, oe, C,
+                      B=B, T=T, Npix=Npix, heads=heads, scale=0.125)
+    torch.cuda.synchronize()
+    check("attn_temporal", oh, oe, 3e-3)
+
+
+# ------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("F,Npix,C,ppc,silu", [(2, 768, 64, 128, 1), (3, 500, 320, 128, 0),
+                                               (1, 192, 1280, 64, 1), (2, 300, 1920, 128, 1), (1, 64, 2560, 16, 0)])
+def test_groupnorm_spatial(F, Npix, C, ppc, silu):
+    x = rnd(F * Npix, C) * 1.7 + 0.9
+    gamma, beta = rnd(C) * 0.5 + 1, rnd(C) * 0.3
+    nchunk = (Npix + ppc - 1) // ppc
+    ph = torch.zeros(F * nchunk * 32 * 3, device=DEV)
+    yh = torch.zeros(F * Npix, C, device=DEV, dtype=torch.float16)
+    hip.groupnorm_stats(x, C, F, Npix, C, ppc, ph)
+    hip.groupnorm_apply(x, C, F, Npix, C, ppc, ph, gamma, beta, 1e-5, silu, yh, C)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.group_norm(x.view(F, Npix, C).permute(0, 2, 1), 32, gamma, beta, 1e-5)
+    if silu:
+        ref = torch.nn.functional.silu(ref)
+    check("groupnorm", yh.view(F, Npix, C).permute(0, 2, 1), ref, 4e-3)
+
+
+@pytest.mark.parametrize("B,T,Npix,C", [(2, 8, 96, 64), (1, 2, 77, 320), (2, 1, 64, 128), (1, 8, 40, 1280)])
+def test_groupnorm_temporal(B, T, Npix, C):
+    x = rnd(B * T * Npix, C) * 1.3 - 0.4
+    gamma, beta = rnd(C) * 0.5 + 1, rnd(C) * 0.3
+    yh = torch.zeros(B * T * Npix, C, device=DEV, dtype=torch.float16)
+    ye = torch.zeros_like(yh)
+    hip.groupnorm_temporal_silu(x, B, T, Npix, C, gamma, beta, 1e-5, yh)
+    emu.groupnorm_temporal_silu(x, B, T, Npix, C, gamma, beta, 1e-5, ye)
+    torch.cuda.synchronize()
+    check("gn_temporal", yh, ye, 4e-3)
+
+
+@pytest.mark.parametrize("M,C", [(1000, 64), (513, 320), (256, 1280), (7, 640)])
+def test_layernorm(M, C):
+    x = rnd(M, C) * 2.1 + 0.5
+    gamma, beta = rnd(C) * 0.5 + 1, rnd(C) * 0.3
+    yh = torch.zeros(M, C, device=DEV, dtype=torch.float16)
+    hip.layernorm(x, C, M, C, gamma, beta, 1e-5, yh, C)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5)
+    check("layernorm", yh, ref, 4e-3)
+
+
+# ---------------------------------------------------------------------------------------- helpers
+def test_linear_smallm_and_timestep_embedding():
+    F, dim, K, N = 16, 320, 320, 1280
+    t = torch.tensor([999, 959, 0, 1, 500, 17, 333, 666] * 2, device=DEV, dtype=torch.int64)
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half).to(DEV)
+    eh = torch.zeros(F, dim, device=DEV)
+    hip.timestep_embedding(t, F, dim, freqs, eh)
+    args = t[:, None].float().cpu() * freqs.cpu()[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    torch.cuda.synchronize()
+    check("timestep_embedding", eh.cpu(), ref, 2e-5, 0)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    b = rnd(N)
+    for M, si, so in [(16, False, True), (2, True, False), (5, False, False)]:
+        oh, oe = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+        hip.linear_smallm(eh, dim, w, b, oh, N, M, N, K, si, so)
+        emu.linear_smallm(eh, dim, w, b, oe, N, M, N, K, si, so)
+        torch.cuda.synchronize()
+        check("linear_smallm", oh, oe, 1e-4, 1e-4)
+
+
+def test_layout_helpers():
+    F, C1, C2, H, W, Cpad = 2, 4, 4, 8, 12, 8
+    a, b = rnd(F, C1, H, W), rnd(F, C2, H, W)
+    oh = torch.zeros(F * H * W, Cpad, device=DEV, dtype=torch.float16)
+    hip.nchw_to_tokens_f16(a, C1, b, C2, F, H * W, Cpad, oh)
+    ref = torch.cat([a, b], 1).permute(0, 2, 3, 1).reshape(F * H * W, Cpad).half()
+    torch.cuda.synchronize()
+    assert torch.equal(oh, ref)
+    a19 = rnd(F, 19, H, W)
+    o24 = torch.full((F * H * W, 24), 7.0, device=DEV, dtype=torch.float16)
+    hip.nchw_to_tokens_f16(a19, 19, None, 0, F, H * W, 24, o24)
+    torch.cuda.synchronize()
+    assert torch.equal(o24[:, :19], a19.permute(0, 2, 3, 1).reshape(-1, 19).half()) and (o24[:, 19:] == 0).all()
+    x = rnd(F * H * W, 32)
+    back = torch.zeros(F, 4, H, W, device=DEV)
+    hip.tokens_to_nchw_f32(x, 32, F, H * W, 4, back)
+    torch.cuda.synchronize()
+    assert torch.equal(back, x[:, :4].reshape(F, H, W, 4).permute(0, 3, 1, 2))
+    M, Ca, Cb = 300, 128, 64
+    aa, ss, cc = rnd(M, Ca), rnd(M, Cb), rnd(M, Cb)
+    o32 = torch.zeros(M, Ca + Cb, device=DEV)
+    o16 = torch.zeros(M, Ca + Cb, device=DEV, dtype=torch.float16)
+    hip.concat_add(aa, Ca, ss, cc, Cb, M, o32, o16)
+    torch.cuda.synchronize()
+    ref = torch.cat([aa, ss + cc], 1)
+    assert torch.equal(o32, ref) and torch.equal(o16, ref.half())
+    y32, y16 = torch.zeros(M, Ca, device=DEV), torch.zeros(M, Ca, device=DEV, dtype=torch.float16)
+    hip.add_f32(aa, aa * 2, M * Ca, y32, y16)
+    torch.cuda.synchronize()
+    assert torch.equal(y32, aa + aa * 2) and torch.equal(y16, (aa + aa * 2).half())
+    hip.add_f32(aa, ss[:, :1].expand(M, Ca).contiguous(), M * Ca, aa, None)     # in place
+    hip.cast_f16(aa, M * Ca, y16)
+    torch.cuda.synchronize()
+    assert torch.equal(y16, aa.half())
+
+
+def test_rejects_cpu_tensors_and_bad_shapes():
+    with pytest.raises(hip.PncError):
+        hip.layernorm(torch.zeros(4, 64), 64, 4, 64, torch.ones(64), torch.zeros(64), 1e-5,
+                      torch.zeros(4, 64, dtype=torch.float16), 64)
+    a = rnd(64, 60, dtype=torch.float16)
+    with pytest.raises(hip.PncError):     # K not a multiple of 8
+        hip.gemm(a, a, M=64, N=64, K=60, lda=60, out32=torch.zeros(64, 64, device=DEV), ldc32=64)

@@ -1,0 +1,141 @@
+"""Micro-benchmarks of the individual HIP kernels at the shapes of BASELINE config 3
+(F = 16 panoramic frames; L0..L3).  Prints one line per case: time, TFLOP/s or GB/s.
+
+    python tools/kbench.py [filter]
+"""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from panacea_amd import hip  # noqa: E402
+
+DEV = "cuda"
+F = 16
+LEVELS = [(320, 32, 384), (640, 16, 192), (1280, 8, 96), (1280, 4, 48)]
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def h16(*shape):
+    return (torch.randn(*shape, device=DEV) * 0.5).half()
+
+
+def report(name, t, flops=None, bytes_=None):
+    s = f"{name:58s} {t * 1e6:10.1f} us"
+    if flops:
+        s += f"  {flops / t / 1e12:8.1f} TFLOP/s"
+    if bytes_:
+        s += f"  {bytes_ / t / 1e9:8.0f} GB/s"
+    print(s, flush=True)
+
+
+def bench_gemm(flt):
+    for li, (C, H, W) in enumerate(LEVELS):
+        M = F * H * W
+        for name, N, K, kw in [("qkv", 3 * C, C, {}), ("proj", C, C, {"res": True}), ("ff1-geglu", 8 * C, C, {"geglu": True}),
+                               ("ff2", C, 4 * C, {"res": True})]:
+            tag = f"gemm L{li} {name} M={M} N={N} K={K}"
+            if flt and flt not in tag:
+                continue
+            a, w = h16(M, K), h16(N, K)
+            bias = torch.zeros(N, device=DEV)
+            if kw.get("geglu"):
+                o = torch.empty(M, N // 2, device=DEV, dtype=torch.float16)
+                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, geglu=True, out16=o, ldc16=N // 2)
+            elif kw.get("res"):
+                o = torch.zeros(M, N, device=DEV)
+                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, res1=o, ldr1=N, out32=o, ldc32=N)
+            else:
+                o = torch.empty(M, N, device=DEV, dtype=torch.float16)
+                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, out16=o, ldc16=N)
+            report(tag, timeit(fn), flops=2.0 * M * N * K)
+            del a, w, o
+        # conv3x3 C->C and temporal conv1d
+        tag = f"conv3x3 L{li} C={C} {H}x{W}"
+        if not flt or flt in tag:
+            x, w = h16(F, H, W, C), h16(C, 9 * C)
+            o = torch.empty(M, C, device=DEV)
+            conv = dict(Cin=C, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0)
+            report(tag, timeit(lambda: hip.gemm(x, w, M=M, N=C, K=9 * C, a_mode=hip.A_CONV3X3, conv=conv, out32=o, ldc32=C)),
+                   flops=2.0 * M * C * 9 * C)
+        tag = f"conv1d_t L{li} C={C}"
+        if not flt or flt in tag:
+            x, w = h16(M, C), h16(C, 3 * C)
+            o = torch.zeros(M, C, device=DEV)
+            report(tag, timeit(lambda: hip.gemm(x, w, M=M, N=C, K=3 * C, a_mode=hip.A_CONV1D_T,
+                                                tconv=dict(C=C, T=8, Npix=H * W), res1=o, ldr1=C, out32=o, ldc32=C)),
+                   flops=2.0 * M * C * 3 * C)
+
+
+INTRA = [[0], [1], [2], [3], [4], [5]]
+CROSS = [[5, 1], [0, 2], [1, 3], [2, 4], [3, 5], [4]]
+
+
+def bench_attn(flt):
+    for li, (C, H, W) in enumerate(LEVELS):
+        N, heads, M = H * W, C // 64, F * H * W
+        Nv = N // 6
+        qk, vt, o = h16(M, 2 * C), h16(F, C, N), torch.empty(M, C, device=DEV, dtype=torch.float16)
+        for name, segs, nk in [("intra", INTRA, 6 * Nv), ("cross", CROSS, 11 * Nv)]:
+            tag = f"attn L{li} {name} Nv={Nv} heads={heads}"
+            if flt and flt not in tag:
+                continue
+            fn = lambda: hip.attn_views(qk, 2 * C, qk[:, C:], 2 * C, vt, N, C * N, o, C, groups=F, heads=heads, H=H,
+                                        W=W, views=6, kvH=H, kvW=W, kv_views=6, kv_rows_per_group=N, q_per_kv=1,
+                                        kv_valid=Nv, segs=segs, scale=0.125)
+            report(tag, timeit(fn), flops=4.0 * F * heads * Nv * nk * 64)
+        tag = f"attn L{li} text heads={heads}"
+        if not flt or flt in tag:
+            kt, vtt = h16(2 * 80, C), h16(2, C, 80)
+            fn = lambda: hip.attn_views(qk, 2 * C, kt, C, vtt, 80, C * 80, o, C, groups=F, heads=heads, H=H, W=W,
+                                        views=1, kvH=1, kvW=80, kv_views=1, kv_rows_per_group=80, q_per_kv=8,
+                                        kv_valid=77, segs=[[0]], scale=0.125)
+            report(tag, timeit(fn), flops=4.0 * M * heads * 77 * 64)
+        tag = f"attn L{li} temporal"
+        if not flt or flt in tag:
+            qkv = h16(M, 3 * C)
+            fn = lambda: hip.attn_temporal(qkv, 3 * C, qkv[:, C:], 3 * C, qkv[:, 2 * C:], 3 * C, o, C, B=2, T=8,
+                                           Npix=N, heads=heads, scale=0.125)
+            report(tag, timeit(fn), bytes_=M * C * 2 * 4.0)
+
+
+def bench_norm(flt):
+    for li, (C, H, W) in enumerate(LEVELS):
+        N, M = H * W, F * H * W
+        x = torch.randn(M, C, device=DEV)
+        y = torch.empty(M, C, device=DEV, dtype=torch.float16)
+        g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        ppc = 128
+        part = torch.empty(F * ((N + ppc - 1) // ppc) * 32 * 3, device=DEV)
+        tag = f"groupnorm L{li} C={C}"
+        if not flt or flt in tag:
+            report(tag + " stats", timeit(lambda: hip.groupnorm_stats(x, C, F, N, C, ppc, part)), bytes_=M * C * 4.0)
+            report(tag + " apply", timeit(lambda: hip.groupnorm_apply(x, C, F, N, C, ppc, part, g, b, 1e-5, 1, y, C)),
+                   bytes_=M * C * 6.0)
+        tag = f"gn_temporal L{li} C={C}"
+        if not flt or flt in tag:
+            report(tag, timeit(lambda: hip.groupnorm_temporal_silu(x, 2, 8, N, C, g, b, 1e-5, y)), bytes_=M * C * 6.0)
+        tag = f"layernorm L{li} C={C}"
+        if not flt or flt in tag:
+            report(tag, timeit(lambda: hip.layernorm(x, C, M, C, g, b, 1e-5, y, C)), bytes_=M * C * 6.0)
+
+
+if __name__ == "__main__":
+    flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    print(torch.cuda.get_device_name(0))
+    bench_gemm(flt)
+    bench_attn(flt)
+    bench_norm(flt)

@@ -100,7 +100,8 @@ def test_view5_sees_only_view4():
 def test_full_manifest_shape():
     m = json.loads((GOLDEN / "manifest_full.json").read_text())
     assert len(m) == 2478
-    assert sum(int(np.prod(v)) for v in m.values()) == 2237465292 or sum(int(np.prod(v)) for v in m.values()) > 2.2e9
+    assert sum(int(np.prod(v)) for v in m.values()) == 2237455188       # 2 237.5 M
     assert m["input_blocks.4.1.transformer_blocks_crossview.0.attn1.to_k.weight"] == [640, 640]
-    assert m["controlnet.zero_convs.7.0.weight"] == [640, 640, 1, 1]
+    assert m["controlnet.zero_convs.6.0.weight"] == [640, 640, 1, 1]
+    assert m["controlnet.zero_convs.7.0.weight"] == [1280, 1280, 1, 1]
     assert m["controlnet.input_hint_block.14.weight"] == [320, 256, 3, 3]

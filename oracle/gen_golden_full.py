@@ -1,0 +1,52 @@
+"""Full-size pin (build container only; ~15 min, ~30 GB): run the REFERENCE network of BASELINE
+config 3 — Panacea+ stage-2, (B, T) = (2, 8), 32x384 latent, 256x3072 BEV hint — on the deterministic
+synthetic weights/inputs and store a stride-7 sample of eps in tests/golden/full_cfg3.npz.  The CPU
+oracle is run on the same data and must agree (fp32 vs fp32) before the file is written.
+
+    python -m oracle.gen_golden_full
+"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import panacea_oracle as po, ref_import          # noqa: E402
+from oracle.gen_golden import GOLDEN, oracle_cfg              # noqa: E402
+from panacea_amd import configs, synth                        # noqa: E402
+
+if __name__ == "__main__":
+    ns = ref_import.import_reference()
+    kw = configs.get("full")
+    t0 = time.time()
+    net, wrapper = ref_import.build_reference_network(ns, kw)
+    manifest = {k: list(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.synth_state_dict(manifest)
+    net.load_state_dict(sd, strict=True)
+    del sd
+    print(f"built + loaded in {time.time() - t0:.0f}s", flush=True)
+    B, T, h, w = configs.SHAPES["full"]
+    inp = synth.synth_inputs(B, T, h, w, context_dim=kw["context_dim"])
+    c = {k: inp[k].clone() for k in ("concat", "crossattn", "cond_feat")}
+    t0 = time.time()
+    with torch.no_grad():
+        eps = wrapper(inp["x"].clone(), inp["t"].clone(), c)
+    t_ref = time.time() - t0
+    print(f"reference forward {t_ref:.1f}s ({torch.get_num_threads()} threads); eps rms {eps.pow(2).mean().sqrt():.4f} "
+          f"max {eps.abs().max():.4f}", flush=True)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    t0 = time.time()
+    eps_o = po.wrapper_forward(sd, oracle_cfg(kw), inp["x"], inp["t"], {k: inp[k] for k in ("concat", "crossattn", "cond_feat")})
+    t_or = time.time() - t0
+    d = (eps - eps_o).abs().max().item()
+    print(f"oracle forward {t_or:.1f}s; oracle vs reference max-abs {d:.3e}", flush=True)
+    assert d <= 1e-4
+    np.savez_compressed(GOLDEN / "full_cfg3.npz", eps_s7=eps.reshape(-1)[::7].numpy(),
+                        eps_rms=np.float32(eps.pow(2).mean().sqrt().item()),
+                        eps_max=np.float32(eps.abs().max().item()),
+                        ref_seconds=np.float32(t_ref), oracle_seconds=np.float32(t_or),
+                        threads=np.int32(torch.get_num_threads()))
+    print("written", flush=True)

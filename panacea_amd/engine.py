@@ -1,0 +1,249 @@
+"""Execution runtime of the MI355X denoising path: activation handles, weight packing and the
+op helpers the module mirrors in `panacea_amd/nn/` are written against.
+
+Data layout.  Activations never leave ONE resident layout: channels-last token
+matrices, row m = (frame f, y, x), columns = channels.  The six camera views are a stride along x,
+frames a stride along the leading dimension, so intra-view / cross-view / temporal attention, 3x3
+convs and temporal convs all address the same buffer — none of the reference's NCHW <-> (b hw c) <->
+(bhw t c) copies (attention.py:1069-1134, openaimodel.py:505-515) exist here.  The residual stream is
+fp32 (`Act.f32`); every contraction operand is fp16 (`Act.f16`, produced by the norm kernels or by a
+GEMM epilogue).
+
+The compute backend is `panacea_amd.hip` (ctypes -> libpanacea_hip.so).  `use_backend()` exists so
+that the test-suite can run the host logic against a torch emulation of the C-ABI on CPU; product
+code never calls it and there is no automatic fallback.
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import hip as _hip
+
+_BACKEND = _hip
+
+
+def backend():
+    return _BACKEND
+
+
+@contextlib.contextmanager
+def use_backend(be):
+    """TESTS ONLY: run the host logic against another implementation of the C-ABI wrappers."""
+    global _BACKEND
+    old, _BACKEND = _BACKEND, be
+    try:
+        yield
+    finally:
+        _BACKEND = old
+
+
+TEXT_PAD = 80          # 77 text tokens padded to a multiple of 8 rows (zero rows, masked in the kernel)
+
+
+@dataclass
+class Act:
+    """A feature map in the resident layout: [F*H*W, C] tokens, fp32 stream and/or fp16 operand."""
+    F: int
+    H: int
+    W: int
+    C: int
+    f32: Optional[torch.Tensor] = None
+    f16: Optional[torch.Tensor] = None
+
+    @property
+    def N(self) -> int:
+        return self.H * self.W
+
+    @property
+    def M(self) -> int:
+        return self.F * self.H * self.W
+
+    def need_f16(self, rt: "Runtime") -> torch.Tensor:
+        if self.f16 is None:
+            self.f16 = rt.empty((self.M, self.C), torch.float16)
+            rt.be.cast_f16(self.f32, self.M * self.C, self.f16)
+        return self.f16
+
+    def to_nchw(self) -> torch.Tensor:
+        t = self.f32 if self.f32 is not None else self.f16.float()
+        return t.view(self.F, self.H, self.W, self.C).permute(0, 3, 1, 2).contiguous()
+
+
+class Runtime:
+    """Per-forward execution context."""
+
+    def __init__(self, device: torch.device, B: int, T: int):
+        self.be = backend()
+        self.device = device
+        self.B, self.T, self.F = B, T, B * T
+        self.ctx16: Optional[torch.Tensor] = None      # [B*TEXT_PAD, context_dim] fp16, zero padded
+        self.n_text = 77
+        self.trace: Optional[Dict[str, torch.Tensor]] = None
+        self.launches = 0
+
+    def empty(self, shape, dtype) -> torch.Tensor:
+        return torch.empty(shape, device=self.device, dtype=dtype)
+
+    def zeros(self, shape, dtype) -> torch.Tensor:
+        return torch.zeros(shape, device=self.device, dtype=dtype)
+
+    def set_context(self, context: torch.Tensor):
+        """context: (B, n_text, D) — tiled over T inside the reference (controlmodel.py:121-122,183-184);
+        here every frame of sample b simply reads sample b's keys."""
+        B, n, D = context.shape
+        if B != self.B:
+            raise ValueError(f"context batch {B} != latent batch {self.B} (= frames / num_frames)")
+        if n > TEXT_PAD:
+            raise ValueError(f"at most {TEXT_PAD} context tokens are supported, got {n}")
+        if D % 8:
+            raise ValueError("context_dim must be a multiple of 8")
+        self.n_text = n
+        c = torch.zeros((B, TEXT_PAD, D), device=self.device, dtype=torch.float16)
+        c[:, :n] = context.to(device=self.device, dtype=torch.float16)
+        self.ctx16 = c.view(B * TEXT_PAD, D)
+
+
+# ----------------------------------------------------------------------------------------------
+# weight packing (fp32 checkpoint tensors -> fp16 operand layouts of the kernels)
+# ----------------------------------------------------------------------------------------------
+def pk_f16(w: torch.Tensor) -> torch.Tensor:
+    return w.detach().to(torch.float16).contiguous()
+
+
+def pk_f32(w: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if w is None else w.detach().to(torch.float32).contiguous()
+
+
+def pk_linear(w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [N, K] is already the W[N][K] operand."""
+    return pk_f16(w.reshape(w.shape[0], -1))
+
+
+def pk_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> [Cout, 9*Cin_pad] with K ordered (ky, kx, ci)."""
+    co, ci = w.shape[0], w.shape[1]
+    cp = cin_pad or ((ci + 7) // 8 * 8)
+    p = torch.zeros((co, 3, 3, cp), device=w.device, dtype=torch.float16)
+    p[..., :ci] = w.detach().permute(0, 2, 3, 1).to(torch.float16)
+    return p.reshape(co, 9 * cp).contiguous()
+
+
+def pk_conv1d(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3] -> [Cout, 3*Cin] with K ordered (dt, ci)."""
+    return pk_f16(w.detach().permute(0, 2, 1).reshape(w.shape[0], -1))
+
+
+def pk_geglu(w: torch.Tensor, b: torch.Tensor):
+    """GEGLU projection [8C, C]: rows [0,4C) are values, [4C,8C) gates (attention.py:97).  Interleave
+    32-row blocks (value block j, gate block j) so that the two MFMA column blocks of one wave hold a
+    value and its gate at the same accumulator position."""
+    n2 = w.shape[0] // 2
+    if n2 % 32:
+        raise ValueError("GEGLU inner dim must be a multiple of 32")
+    wv, wg = w[:n2].view(n2 // 32, 32, -1), w[n2:].view(n2 // 32, 32, -1)
+    wi = torch.stack([wv, wg], dim=1).reshape(2 * n2, -1)
+    bi = torch.stack([b[:n2].view(-1, 32), b[n2:].view(-1, 32)], dim=1).reshape(-1)
+    return pk_f16(wi), pk_f32(bi)
+
+
+class Packable:
+    """Mixin for modules that keep kernel-layout copies of their parameters in `self._pk`."""
+    _pk: Optional[dict] = None
+
+    def _init_packable(self):
+        self._pk = None
+        self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate_packed())
+
+    def invalidate_packed(self):
+        self._pk = None
+
+    def _apply(self, fn, *a, **k):          # .to() / .cuda() / .half() move the parameters
+        self._pk = None
+        return super()._apply(fn, *a, **k)
+
+    def packed(self) -> dict:
+        if self._pk is None:
+            with torch.no_grad():
+                self._pk = self._pack()
+        return self._pk
+
+    def _pack(self) -> dict:                # pragma: no cover
+        raise NotImplementedError
+
+
+def invalidate_all(module: torch.nn.Module):
+    """Drop every packed copy below `module` (call after modifying parameters in place)."""
+    for m in module.modules():
+        if isinstance(m, Packable):
+            m.invalidate_packed()
+
+
+# ----------------------------------------------------------------------------------------------
+# op helpers: allocate the output, call the backend
+# ----------------------------------------------------------------------------------------------
+def _ppc(npix: int) -> int:
+    return max(16, min(128, npix // 48))
+
+
+def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, beta, eps: float, silu: bool) -> torch.Tensor:
+    if C % 64:
+        raise ValueError(f"GroupNorm(32) kernels need C % 64 == 0, got {C}")
+    ppc = _ppc(N)
+    nchunk = (N + ppc - 1) // ppc
+    part = rt.empty((F * nchunk * 32 * 3,), torch.float32)
+    y = rt.empty((F * N, C), torch.float16)
+    rt.be.groupnorm_stats(x32, C, F, N, C, ppc, part)
+    rt.be.groupnorm_apply(x32, C, F, N, C, ppc, part, gamma, beta, eps, silu, y, C)
+    return y
+
+
+def gn_temporal(rt: Runtime, x32: torch.Tensor, N: int, C: int, gamma, beta, eps: float) -> torch.Tensor:
+    y = rt.empty((rt.F * N, C), torch.float16)
+    rt.be.groupnorm_temporal_silu(x32, rt.B, rt.T, N, C, gamma, beta, eps, y)
+    return y
+
+
+def layer_norm(rt: Runtime, x32: torch.Tensor, M: int, C: int, gamma, beta) -> torch.Tensor:
+    y = rt.empty((M, C), torch.float16)
+    rt.be.layernorm(x32, C, M, C, gamma, beta, 1e-5, y, C)
+    return y
+
+
+def small_linear(rt: Runtime, a32: torch.Tensor, w16: torch.Tensor, bias, M: int, N: int, K: int,
+                 silu_in=False, silu_out=False) -> torch.Tensor:
+    """fp32-activation linear for the (frames x 1280) time-embedding path; rows in chunks of 16."""
+    out = rt.empty((M, N), torch.float32)
+    for m0 in range(0, M, 16):
+        mm = min(16, M - m0)
+        rt.be.linear_smallm(a32[m0:], K, w16, bias, out[m0:], N, mm, N, K, silu_in, silu_out)
+    return out
+
+
+_FREQS: Dict[tuple, torch.Tensor] = {}
+
+
+def timestep_freqs(dim: int, device) -> torch.Tensor:
+    """exp(-ln(10000) * i / half), tabulated in fp32 on the host exactly like util.py:236-241."""
+    key = (dim, str(device))
+    if key not in _FREQS:
+        half = dim // 2
+        f = torch.exp(-math.log(10000.0) * torch.arange(0, half, dtype=torch.float32) / half)
+        _FREQS[key] = f.to(device)
+    return _FREQS[key]
+
+
+def temporal_pos_table(T: int, C: int) -> torch.Tensor:
+    """The reference's temporal position table as it actually evaluates (attention.py:1140-1159): the
+    frequency vector is truncated to int64, leaving col 0 = sin(p), col 1 = cos(p), other even columns
+    0 and odd columns 1.  Built once per (T, C) instead of on every forward."""
+    p = torch.arange(T, dtype=torch.float32)
+    tab = torch.zeros(T, C, dtype=torch.float32)
+    tab[:, 1::2] = 1.0
+    tab[:, 0] = torch.sin(p)
+    tab[:, 1] = torch.cos(p)
+    return tab

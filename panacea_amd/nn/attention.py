@@ -1,0 +1,373 @@
+"""Decomposed-4D attention on MI355X — host-side mirror of `sgm/modules/attention.py`.
+
+Same class names, constructor arguments and parameter names as the reference (so its checkpoints
+and YAML `target:` strings work unchanged); the forwards are new: they enqueue the hand-written
+gfx950 kernels of libpanacea_hip.so on channels-last token matrices (`panacea_amd.engine`).
+
+  reference class (attention.py)                 -> what runs here
+  SpatialTemporalTransformer :898-1134           -> three residual branches, no layout copies
+  BasicTransformerBlock :613-747                 -> LN -> fused QKV GEMM -> attention kernel -> GEMM(+res) ...
+  MemoryEfficientIntraViewAttention :382-489     -> pnc_attn_views_f16, views are width strides
+  MemoryEfficientInterViewAttentionTwo :493-610  -> same kernel, two KV segments (view 5: one, quirk Q1)
+  CrossAttention / MemoryEfficientCrossAttention -> text keys: pnc_attn_views_f16 with 77 masked keys,
+      :203-291 / :294-379                           K/V projected once per sample (not per pixel);
+                                                    temporal self-attention: pnc_attn_temporal_f16
+  FeedForward / GEGLU :91-117                    -> GEMM with fused GEGLU epilogue, GEMM(+res)
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import engine as E
+from ..engine import Act, Packable, Runtime
+
+HEAD_DIM = 64
+INTRA_SEGS = [[0], [1], [2], [3], [4], [5]]
+# MemoryEfficientInterViewAttentionTwo: K/V = [left, right]; view 0 = [5, 1]; for view 5 the reference's
+# right-hand slice is empty (attention.py:549-551), so it attends to view 4 only.
+INTER_SEGS = [[5, 1], [0, 2], [1, 3], [2, 4], [3, 5], [4]]
+
+
+def exists(v):
+    return v is not None
+
+
+def default(v, d):
+    return v if v is not None else (d() if callable(d) else d)
+
+
+def Normalize(in_channels):
+    """attention.py:129-132"""
+    return nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+def panorama_grid(n_tokens: int):
+    """attention.py:428 — H = int(sqrt(N / 12)): six views of aspect 1:2 along the width."""
+    H = int(math.sqrt(n_tokens // 12))
+    if H == 0 or n_tokens % H or (n_tokens // H) % 6:
+        raise ValueError(f"{n_tokens} tokens are not a 6-view panorama of aspect 1:2 per view")
+    return H, n_tokens // H
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module, Packable):
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.0):
+        super().__init__()
+        if not glu:
+            raise NotImplementedError("only the gated (GEGLU) feed-forward is on the Panacea path")
+        inner_dim = int(dim * mult)
+        dim_out = default(dim_out, dim)
+        self.dim, self.inner_dim, self.dim_out = dim, inner_dim, dim_out
+        self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), nn.Linear(inner_dim, dim_out))
+        self._init_packable()
+
+    def _pack(self):
+        w1, b1 = E.pk_geglu(self.net[0].proj.weight, self.net[0].proj.bias)
+        return dict(w1=w1, b1=b1, w2=E.pk_linear(self.net[2].weight), b2=E.pk_f32(self.net[2].bias))
+
+    def _run(self, rt: Runtime, x16, M, res32, out32=None, out16=None):
+        """out = FF(x16) + res32 -> out32 (may alias res32) and/or out16."""
+        pk = self.packed()
+        hid = rt.empty((M, self.inner_dim), torch.float16)
+        rt.be.gemm(x16, pk["w1"], M=M, N=2 * self.inner_dim, K=self.dim, lda=self.dim, bias=pk["b1"],
+                   geglu=True, out16=hid, ldc16=self.inner_dim)
+        rt.be.gemm(hid, pk["w2"], M=M, N=self.dim_out, K=self.inner_dim, lda=self.inner_dim, bias=pk["b2"],
+                   res1=res32, ldr1=self.dim_out, out32=out32, ldc32=self.dim_out, out16=out16,
+                   ldc16=self.dim_out)
+
+
+class _AttentionBase(nn.Module, Packable):
+    """Parameters of every attention flavour: to_q / to_k / to_v (no bias) and to_out.0 (bias)."""
+    kind = "plain"
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0, backend=None, **kwargs):
+        super().__init__()
+        if dim_head != HEAD_DIM:
+            raise NotImplementedError(f"the gfx950 attention kernels are built for head dim {HEAD_DIM}, got {dim_head}")
+        inner_dim = dim_head * heads
+        self.is_self = context_dim is None
+        context_dim = default(context_dim, query_dim)
+        self.query_dim, self.context_dim, self.inner_dim = query_dim, context_dim, inner_dim
+        self.scale = dim_head ** -0.5
+        self.heads, self.dim_head = heads, dim_head
+        self.to_q = nn.Linear(query_dim, inner_dim, bias=False)
+        self.to_k = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
+        self.backend = backend
+        self._init_packable()
+
+    def _pack(self):
+        pk = dict(wo=E.pk_linear(self.to_out[0].weight), bo=E.pk_f32(self.to_out[0].bias))
+        if self.is_self:
+            pk["wqkv"] = E.pk_f16(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], dim=0))
+        else:
+            pk["wq"], pk["wk"], pk["wv"] = (E.pk_linear(self.to_q.weight), E.pk_linear(self.to_k.weight),
+                                            E.pk_linear(self.to_v.weight))
+        return pk
+
+    # ---- text cross-attention: x16 [M, C] queries of F frames vs the 77 context tokens of each sample
+    def _run_text(self, rt: Runtime, x16, F, H, W, res32, out32):
+        pk = self.packed()
+        C, M = self.inner_dim, F * H * W
+        D = rt.ctx16.shape[1]
+        rows = rt.B * E.TEXT_PAD
+        q = rt.empty((M, C), torch.float16)
+        rt.be.gemm(x16, pk["wq"], M=M, N=C, K=self.query_dim, lda=self.query_dim, out16=q, ldc16=C)
+        k = rt.empty((rows, C), torch.float16)
+        vt = rt.empty((rt.B, C, E.TEXT_PAD), torch.float16)
+        rt.be.gemm(rt.ctx16, pk["wk"], M=rows, N=C, K=D, lda=D, out16=k, ldc16=C)
+        rt.be.gemm(rt.ctx16, pk["wv"], M=rows, N=C, K=D, lda=D, out16t=vt, ldt=E.TEXT_PAD, t_rows=E.TEXT_PAD,
+                   t_gstride=C * E.TEXT_PAD, n_split=0)
+        o = rt.empty((M, C), torch.float16)
+        rt.be.attn_views(q, C, k, C, vt, E.TEXT_PAD, C * E.TEXT_PAD, o, C, groups=F, heads=self.heads, H=H, W=W,
+                         views=1, kvH=1, kvW=E.TEXT_PAD, kv_views=1, kv_rows_per_group=E.TEXT_PAD,
+                         q_per_kv=rt.T, kv_valid=rt.n_text, segs=[[0]], scale=self.scale)
+        rt.be.gemm(o, pk["wo"], M=M, N=self.query_dim, K=C, lda=C, bias=pk["bo"], res1=res32,
+                   ldr1=self.query_dim, out32=out32, ldc32=self.query_dim)
+
+    # ---- spatial self-attention over width-sliced views (views = 1: plain attention)
+    def _run_views(self, rt: Runtime, x16, F, H, W, segs, res32, out32):
+        pk = self.packed()
+        C, N = self.inner_dim, H * W
+        M = F * N
+        views = len(segs)
+        if W % views or (W // views) % 8:
+            raise ValueError(f"view width {W}/{views} must be a multiple of 8 latent columns")
+        qk = rt.empty((M, 2 * C), torch.float16)
+        vt = rt.empty((F, C, N), torch.float16)
+        rt.be.gemm(x16, pk["wqkv"], M=M, N=3 * C, K=self.query_dim, lda=self.query_dim, out16=qk, ldc16=2 * C,
+                   out16t=vt, ldt=N, t_rows=N, t_gstride=C * N, n_split=2 * C)
+        o = rt.empty((M, C), torch.float16)
+        rt.be.attn_views(qk, 2 * C, qk.view(-1)[C:], 2 * C, vt, N, C * N, o, C, groups=F, heads=self.heads,
+                         H=H, W=W, views=views, kvH=H, kvW=W, kv_views=views, kv_rows_per_group=N, q_per_kv=1,
+                         kv_valid=H * (W // views), segs=segs, scale=self.scale)
+        rt.be.gemm(o, pk["wo"], M=M, N=self.query_dim, K=C, lda=C, bias=pk["bo"], res1=res32,
+                   ldr1=self.query_dim, out32=out32, ldc32=self.query_dim)
+
+    # ---- temporal self-attention over the T frames of each pixel
+    def _run_temporal(self, rt: Runtime, x16, N, res32, out32):
+        pk = self.packed()
+        C = self.inner_dim
+        M = rt.F * N
+        qkv = rt.empty((M, 3 * C), torch.float16)
+        rt.be.gemm(x16, pk["wqkv"], M=M, N=3 * C, K=self.query_dim, lda=self.query_dim, out16=qkv, ldc16=3 * C)
+        o = rt.empty((M, C), torch.float16)
+        flat = qkv.view(-1)
+        rt.be.attn_temporal(flat, 3 * C, flat[C:], 3 * C, flat[2 * C:], 3 * C, o, C, B=rt.B, T=rt.T, Npix=N,
+                            heads=self.heads, scale=self.scale)
+        rt.be.gemm(o, pk["wo"], M=M, N=self.query_dim, K=C, lda=C, bias=pk["bo"], res1=res32,
+                   ldr1=self.query_dim, out32=out32, ldc32=self.query_dim)
+
+
+class CrossAttention(_AttentionBase):
+    """attention.py:203-291"""
+    kind = "plain"
+
+
+class MemoryEfficientCrossAttention(_AttentionBase):
+    """attention.py:294-379 (same parameters as CrossAttention; what the reference's torch 1.13 env runs)"""
+    kind = "plain"
+
+
+class MemoryEfficientIntraViewAttention(_AttentionBase):
+    """attention.py:382-489"""
+    kind = "intra-view"
+
+
+class MemoryEfficientInterViewAttentionTwo(_AttentionBase):
+    """attention.py:493-610"""
+    kind = "inter-view"
+
+
+class BasicTransformerBlock(nn.Module, Packable):
+    """attention.py:613-747: x = attn1(LN1 x) + x ; x = attn2(LN2 x, text) + x ; x = ff(LN3 x) + x"""
+    ATTENTION_MODES = {"softmax": CrossAttention, "softmax-xformers": MemoryEfficientCrossAttention}
+
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None, gated_ff=True, checkpoint=True,
+                 disable_self_attn=False, attn_mode="softmax", sdp_backend=None,
+                 temporal_transformer_attn_type=None, spatial_only_attn_type=None):
+        super().__init__()
+        if attn_mode not in self.ATTENTION_MODES:
+            raise ValueError(f"unknown attn_mode {attn_mode}")
+        if disable_self_attn:
+            raise NotImplementedError("disable_self_attn is not used on the Panacea path")
+        attn_cls = self.ATTENTION_MODES[attn_mode]
+        self.disable_self_attn = disable_self_attn
+        self.temporal_transformer_attn_type = temporal_transformer_attn_type
+        self.spatial_only_attn_type = spatial_only_attn_type
+        if spatial_only_attn_type == "intra-view":
+            a1 = MemoryEfficientIntraViewAttention
+        elif spatial_only_attn_type == "inter-view":
+            a1 = MemoryEfficientInterViewAttentionTwo
+        else:
+            a1 = attn_cls
+        self.attn1 = a1(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout, context_dim=None,
+                        backend=sdp_backend)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = attn_cls(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head,
+                              dropout=dropout, backend=sdp_backend)
+        if self.attn2.is_self:
+            raise NotImplementedError("attn2 without a text context is not on the Panacea path")
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.checkpoint = checkpoint
+        self.dim = dim
+        self._init_packable()
+
+    def _pack(self):
+        return {f"{n}{s}": E.pk_f32(getattr(getattr(self, n), "weight" if s == "w" else "bias"))
+                for n in ("norm1", "norm2", "norm3") for s in ("w", "b")}
+
+    def _run(self, rt: Runtime, t32, F, H, W, branch: str, last: bool):
+        """t32 [M, dim] fp32 stream, updated in place; returns the fp16 copy of the final x when `last`."""
+        pk = self.packed()
+        C, N = self.dim, H * W
+        M = F * N
+        x16 = E.layer_norm(rt, t32, M, C, pk["norm1w"], pk["norm1b"])
+        if branch == "temporal":
+            self.attn1._run_temporal(rt, x16, N, t32, t32)
+        elif self.attn1.kind == "intra-view":
+            ph, pw = panorama_grid(N)
+            self.attn1._run_views(rt, x16, F, ph, pw, INTRA_SEGS, t32, t32)
+        elif self.attn1.kind == "inter-view":
+            ph, pw = panorama_grid(N)
+            self.attn1._run_views(rt, x16, F, ph, pw, INTER_SEGS, t32, t32)
+        else:
+            self.attn1._run_views(rt, x16, F, H, W, [[0]], t32, t32)
+        x16 = E.layer_norm(rt, t32, M, C, pk["norm2w"], pk["norm2b"])
+        self.attn2._run_text(rt, x16, F, H, W, t32, t32)
+        x16 = E.layer_norm(rt, t32, M, C, pk["norm3w"], pk["norm3b"])
+        if last:
+            out16 = rt.empty((M, C), torch.float16)
+            self.ff._run(rt, x16, M, t32, out32=None, out16=out16)
+            return out16
+        self.ff._run(rt, x16, M, t32, out32=t32)
+        return None
+
+
+class SpatialTemporalTransformer(nn.Module, Packable):
+    """attention.py:898-1134 — intra-view spatial -> cross-view -> cross-frame temporal branches."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None,
+                 disable_self_attn=False, use_linear=False, attn_type="softmax", use_checkpoint=True,
+                 sdp_backend=None, alpha=1, num_frames=4, temporal_transformer_attn_type=None,
+                 spatial_only_attn_type=None, insert_crossview=False):
+        super().__init__()
+        if not use_linear:
+            raise NotImplementedError("use_linear_in_transformer=False (1x1-conv projections) is not on the Panacea path")
+        self.insert_crossview = insert_crossview
+        self.num_frames = num_frames
+        self.alpha = 1 if alpha == 1 else nn.Parameter(torch.rand(1, requires_grad=True))
+        if exists(context_dim) and not isinstance(context_dim, (list, tuple)) and not _is_listconfig(context_dim):
+            context_dim = [context_dim]
+        if exists(context_dim):
+            context_dim = list(context_dim)
+            if depth != len(context_dim):
+                assert all(c == context_dim[0] for c in context_dim), "need homogenous context_dim"
+                context_dim = depth * [context_dim[0]]
+        else:
+            context_dim = [None] * depth
+        self.in_channels = in_channels
+        inner_dim = n_heads * d_head
+        if inner_dim != in_channels:
+            raise NotImplementedError("inner_dim != in_channels is not on the Panacea path")
+        self.inner_dim = inner_dim
+        self.norm = Normalize(in_channels)
+        self.proj_in = nn.Linear(in_channels, inner_dim)
+        self.norm_temporal = Normalize(in_channels)
+        self.proj_in_temporal = nn.Linear(in_channels, inner_dim)
+        if insert_crossview:
+            self.norm_crossview = Normalize(in_channels)
+            self.proj_in_crossview = nn.Linear(in_channels, inner_dim)
+
+        def blocks(**kw):
+            return nn.ModuleList([
+                BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim[d],
+                                      disable_self_attn=disable_self_attn, attn_mode=attn_type,
+                                      checkpoint=use_checkpoint, sdp_backend=sdp_backend, **kw)
+                for d in range(depth)])
+        self.transformer_blocks = blocks(spatial_only_attn_type=spatial_only_attn_type)
+        self.transformer_blocks_temporal = blocks(temporal_transformer_attn_type=temporal_transformer_attn_type)
+        if insert_crossview:
+            assert spatial_only_attn_type == "intra-view"
+            self.transformer_blocks_crossview = blocks(spatial_only_attn_type="inter-view")
+        self.proj_out = zero_module(nn.Linear(inner_dim, in_channels))
+        self.proj_out_temporal = zero_module(nn.Linear(inner_dim, in_channels))
+        if insert_crossview:
+            self.proj_out_crossview = zero_module(nn.Linear(inner_dim, in_channels))
+        self.use_linear = use_linear
+        self.identity_layer = nn.Identity()
+        self._init_packable()
+
+    def _pack(self):
+        pk = {}
+        sfx = ["", "_temporal"] + (["_crossview"] if self.insert_crossview else [])
+        for s in sfx:
+            n, pi, po = getattr(self, "norm" + s), getattr(self, "proj_in" + s), getattr(self, "proj_out" + s)
+            pk["g" + s], pk["b" + s] = E.pk_f32(n.weight), E.pk_f32(n.bias)
+            pk["wi" + s], pk["bi" + s] = E.pk_linear(pi.weight), E.pk_f32(pi.bias)
+            pk["wo" + s], pk["bo" + s] = E.pk_linear(po.weight), E.pk_f32(po.bias)
+        pk["pos"] = E.temporal_pos_table(self.num_frames, self.inner_dim).to(self.proj_in.weight.device)
+        return pk
+
+    def _branch(self, rt: Runtime, x: Act, sfx: str, blocks, branch: str, out16=None):
+        pk = self.packed()
+        C, M = x.C, x.M
+        n16 = E.gn_spatial(rt, x.f32, x.F, x.N, C, pk["g" + sfx], pk["b" + sfx], 1e-6, False)
+        t32 = rt.empty((M, C), torch.float32)
+        if branch == "temporal":
+            # + position table indexed by t = frame % T (attention.py:1117-1118)
+            rt.be.gemm(n16, pk["wi" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bi" + sfx], rowbias=pk["pos"],
+                       rb_rows=x.N, rb_mod=rt.T, out32=t32, ldc32=C)
+        else:
+            rt.be.gemm(n16, pk["wi" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bi" + sfx], out32=t32, ldc32=C)
+        p16 = None
+        for i, blk in enumerate(blocks):
+            p16 = blk._run(rt, t32, x.F, x.H, x.W, branch, last=(i == len(blocks) - 1))
+        # x = proj_out(t) + x_in, in place on the stream
+        rt.be.gemm(p16, pk["wo" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bo" + sfx], res1=x.f32, ldr1=C,
+                   out32=x.f32, ldc32=C, out16=out16, ldc16=C)
+
+    def _run(self, rt: Runtime, x: Act, want_f16: bool = False) -> Act:
+        if rt.T != self.num_frames:
+            raise ValueError(f"runtime has {rt.T} frames per sample, module was built for {self.num_frames}")
+        self._branch(rt, x, "", self.transformer_blocks, "spatial")
+        if self.insert_crossview:
+            self._branch(rt, x, "_crossview", self.transformer_blocks_crossview, "crossview")
+        out16 = rt.empty((x.M, x.C), torch.float16) if want_f16 else None
+        self._branch(rt, x, "_temporal", self.transformer_blocks_temporal, "temporal", out16=out16)
+        return Act(x.F, x.H, x.W, x.C, f32=x.f32, f16=out16)
+
+    def forward(self, x, context=None):
+        """Reference-compatible entry: x (B*T, C, h, w) NCHW, context (B*T, n, D) already tiled over T."""
+        from .util import act_from_nchw, runtime_for
+        ctx = context[0] if isinstance(context, list) else context
+        rt = runtime_for(x, self.num_frames)
+        rt.set_context(ctx.view(rt.B, rt.T, *ctx.shape[1:])[:, 0])
+        a = act_from_nchw(rt, x)
+        return self._run(rt, a).to_nchw().to(x.dtype)
+
+
+def _is_listconfig(v) -> bool:
+    return type(v).__name__ == "ListConfig"
+
+
+def create_1d_absolute_sin_cos_embedding(pos_len, dim):
+    """attention.py:1140-1159 as it evaluates (degenerate table)."""
+    assert dim % 2 == 0, "wrong dimension!"
+    return E.temporal_pos_table(pos_len, dim)

@@ -1,0 +1,176 @@
+"""ControlNet3D (BEV-layout branch) and ControlledUNetModel3D on MI355X — host-side mirror of
+`sgm/modules/diffusionmodules/controlmodel.py`.
+
+  ControlNet3D.forward :86-142            hint stem (8 convs, SiLU fused into the conv epilogue, fp16
+                                          between layers) -> encoder + middle on tokens -> 13 zero 1x1
+                                          convs (GEMM, control_scales folded into the packed weights)
+  ControlledUNetModel3D.forward :160-202  `h += control.pop()` and `cat([h, hs.pop() + control.pop()])`
+                                          are one fused pass each (pnc_add_f32 / pnc_concat_add)
+"""
+from __future__ import annotations
+
+import importlib
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from ..engine import Act, Runtime
+from .openaimodel import TimestepEmbedSequential, UNetModel3D, conv_params, run_conv3x3
+from .util import conv_nd, runtime_for, zero_module
+
+HINT_STRIDES = (1, 1, 2, 1, 2, 1, 2, 1)
+
+
+def instantiate_from_config(config):
+    """sgm/util.py:168-185 — {"target": dotted.path, "params": {...}}.  `sgm.modules...` targets resolve to the
+    mirror classes of this package (the `sgm` shim re-exports them under the reference's import paths)."""
+    if "target" not in config:
+        raise KeyError("Expected key `target` to instantiate.")
+    module, cls = config["target"].rsplit(".", 1)
+    return getattr(importlib.import_module(module), cls)(**dict(config.get("params", dict())))
+
+
+class ControlNet3D(UNetModel3D):
+    """controlmodel.py:19-142"""
+
+    def __init__(self, hint_channels, control_scales, dims=2, disable_temporal=False, *args, **kwargs):
+        kwargs["out_channels"] = kwargs["in_channels"]
+        if disable_temporal:
+            raise NotImplementedError("disable_temporal is not used by the Panacea inference configuration")
+        if hint_channels > 19:
+            raise NotImplementedError("hint_channels > 19 (controlmodel.py:108-117) is a dead path at 19 channels")
+        self.control_scales, self.hint_channels, self.disable_temporal = control_scales, hint_channels, disable_temporal
+        super().__init__(*args, **kwargs)
+        model_channels, channel_mult = kwargs["model_channels"], kwargs["channel_mult"]
+        del self.output_blocks
+        del self.out
+        chans = [hint_channels, 16, 16, 32, 32, 96, 96, 256, model_channels]
+        layers = []
+        for i, s in enumerate(HINT_STRIDES):
+            conv = conv_nd(dims, chans[i], chans[i + 1], 3, padding=1, stride=s)
+            layers.append(conv if i < 7 else zero_module(conv))
+            if i < 7:
+                layers.append(nn.SiLU())
+        self.input_hint_block = TimestepEmbedSequential(*layers)
+        self.zero_convs = nn.ModuleList([self.make_zero_conv(model_channels, dims=2)])
+        ch = model_channels
+        for level, mult in enumerate(channel_mult):
+            for _ in range(self.num_res_blocks[level]):
+                ch = mult * model_channels
+                self.zero_convs.append(self.make_zero_conv(ch, dims=2))
+            if level != len(channel_mult) - 1:
+                self.zero_convs.append(self.make_zero_conv(ch, dims=2))
+        self.middle_block_out = self.make_zero_conv(ch, dims=2)
+
+    def make_zero_conv(self, channels, dims=2):
+        return TimestepEmbedSequential(zero_module(conv_nd(dims, channels, channels, 1, padding=0)))
+
+    def _pack(self):
+        pk = super()._pack()
+        pk["hint"] = [conv_params(m) for m in self.input_hint_block if isinstance(m, nn.Conv2d)]
+        s = float(self.control_scales)
+        zc = []
+        for z in list(self.zero_convs) + [self.middle_block_out]:
+            w, b = conv_params(z[0])
+            zc.append(((w.float() * s).half().contiguous(), b * s) if s != 1.0 else (w, b))
+        pk["zero"] = zc
+        return pk
+
+    def _hint_stem(self, rt: Runtime, hint: torch.Tensor) -> Act:
+        """input_hint_block (controlmodel.py:43-59) on the image-resolution BEV layout."""
+        pk = self.packed()
+        F, C, H, W = hint.shape
+        cp = (C + 7) // 8 * 8
+        t16 = rt.empty((F * H * W, cp), torch.float16)
+        rt.be.nchw_to_tokens_f16(hint.detach().to(torch.float32).contiguous(), C, None, 0, F, H * W, cp, t16)
+        a = Act(F, H, W, cp, f16=t16)
+        for i, ((w, b), s) in enumerate(zip(pk["hint"], HINT_STRIDES)):
+            last = i == len(HINT_STRIDES) - 1
+            a = run_conv3x3(rt, a.f16, a.F, a.H, a.W, a.C, w, b, w.shape[0], stride=s, act_silu=not last,
+                            out32=last, out16=not last)
+        return a
+
+    def _run_control(self, rt: Runtime, x16: Act, hint: torch.Tensor, emb32: torch.Tensor) -> List[Act]:
+        pk = self.packed()
+        guided = self._hint_stem(rt, hint)
+        outs, h = [], x16
+        for i, (module, (zw, zb)) in enumerate(zip(self.input_blocks, pk["zero"])):
+            h = module._run(rt, h, emb32, want_f16=(i != 0))
+            if rt.trace is not None:
+                rt.trace[f"controlnet.input_blocks.{i}"] = h.to_nchw()
+            if i == 0:
+                if (guided.H, guided.W, guided.C) != (h.H, h.W, h.C):
+                    raise ValueError(f"hint stem output {guided.H}x{guided.W}x{guided.C} does not match the latent "
+                                     f"{h.H}x{h.W}x{h.C} (the hint must be 8x the latent resolution)")
+                h.f16 = rt.empty((h.M, h.C), torch.float16)
+                rt.be.add_f32(h.f32, guided.f32, h.M * h.C, h.f32, h.f16)             # h += guided_hint
+            outs.append(self._zero_conv(rt, h, zw, zb))
+        h = self.middle_block._run(rt, h, emb32, want_f16=True)
+        if rt.trace is not None:
+            rt.trace["controlnet.middle_block"] = h.to_nchw()
+        zw, zb = pk["zero"][-1]
+        outs.append(self._zero_conv(rt, h, zw, zb))
+        return outs
+
+    @staticmethod
+    def _zero_conv(rt: Runtime, h: Act, w16, b) -> Act:
+        o = rt.empty((h.M, h.C), torch.float32)
+        rt.be.gemm(h.need_f16(rt), w16, M=h.M, N=h.C, K=h.C, lda=h.C, bias=b, out32=o, ldc32=h.C)
+        return Act(h.F, h.H, h.W, h.C, f32=o)
+
+    def forward(self, x, hint, timesteps=None, context=None, y=None, **kwargs):
+        """controlmodel.py:86-142 — returns the 13 residuals (encoder order, middle last) as NCHW tensors."""
+        assert (y is not None) == (self.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"
+        with torch.no_grad():
+            rt = runtime_for(x, self.num_frames)
+            rt.set_context(context)
+            emb = self._time_embedding(rt, timesteps)
+            outs = self._run_control(rt, self._stem_tokens(rt, x), hint, emb)
+        return [o.to_nchw().to(x.dtype) for o in outs]
+
+
+class ControlledUNetModel3D(UNetModel3D):
+    """controlmodel.py:146-202"""
+
+    def __init__(self, controlnet_config=None, only_add_on_center_frame=False, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if controlnet_config is not None:
+            self.controlnet = instantiate_from_config(controlnet_config)
+
+    def _to_control_acts(self, rt: Runtime, control) -> list:
+        from .util import act_from_nchw
+        return [c if isinstance(c, Act) else act_from_nchw(rt, c) for c in control]
+
+    def forward(self, x, timesteps=None, context=None, y=None, control=None, **kwargs):
+        """controlmodel.py:160-202.  `control` is consumed from the end, like the reference's pop()s."""
+        assert (y is not None) == (self.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"
+        with torch.no_grad():
+            rt = runtime_for(x, self.num_frames)
+            rt.set_context(context)
+            emb = self._time_embedding(rt, timesteps)
+            acts = None
+            if control is not None:
+                acts = self._to_control_acts(rt, control)
+                del control[:]
+            out = self._run_unet(rt, self._stem_tokens(rt, x), emb, acts)
+        return out.to(x.dtype)
+
+    def denoise(self, x, timesteps, context, hint, trace=None) -> torch.Tensor:
+        """ControlNet + UNet in one runtime (what OpenAIWrapperControlLDM3D.forward calls): the stem tokens and
+        the text context are prepared once and the 13 residuals stay in the resident layout."""
+        with torch.no_grad():
+            rt = runtime_for(x, self.num_frames)
+            rt.trace = trace
+            rt.set_context(context)
+            x16 = self._stem_tokens(rt, x)
+            cn = self.controlnet
+            control = cn._run_control(rt, x16, hint, cn._time_embedding(rt, timesteps))
+            if trace is not None:
+                for j, c in enumerate(control):
+                    trace[f"control.{j}"] = c.to_nchw()
+            out = self._run_unet(rt, x16, self._time_embedding(rt, timesteps), control)
+        return out.to(x.dtype)

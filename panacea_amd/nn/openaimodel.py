@@ -1,0 +1,401 @@
+"""UNetModel3D and its blocks on MI355X — host-side mirror of
+`sgm/modules/diffusionmodules/openaimodel.py` (hot part: :79-201 blocks, :356-542 ResBlock3D,
+:774-1319 UNetModel3D).
+
+The module tree (and therefore every state-dict key and shape) is the reference's; the forwards run
+the gfx950 kernels on channels-last tokens:
+
+  ResBlock3D._forward :499-542   GN+SiLU kernel -> implicit-GEMM conv3x3 -> per-pixel temporal GN+SiLU
+                                 -> temporal conv1d GEMM whose epilogue adds the identity, the timestep
+                                 embedding row and (second half) the skip path; 4 layout copies of the
+                                 reference ("(b t) c h w" <-> "(b h w) c t") do not exist here.
+  Downsample :161-201            conv3x3 stride 2 (implicit GEMM, gather does the striding)
+  Upsample :106-142              nearest x2 folded into the conv gather (no upsampled tensor is written)
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from ..engine import Act, Packable, Runtime
+from .attention import SpatialTemporalTransformer
+from .util import conv_nd, linear, normalization, timestep_embedding, zero_module
+
+
+def _as_list(v):
+    if isinstance(v, (int, float)) or v is None:
+        return v
+    return list(v)
+
+
+class TimestepBlock(nn.Module):
+    """openaimodel.py:66-76 — marker for children that take the timestep embedding."""
+
+
+def conv_params(conv: nn.Conv2d):
+    k = conv.kernel_size[0]
+    if k == 3:
+        return E.pk_conv3x3(conv.weight), E.pk_f32(conv.bias)
+    if k == 1:
+        return E.pk_linear(conv.weight), E.pk_f32(conv.bias)
+    raise NotImplementedError(f"conv kernel size {k}")
+
+
+def run_conv3x3(rt: Runtime, x16: torch.Tensor, F: int, Hin: int, Win: int, Cin_pad: int, w16, bias, Cout: int,
+                stride: int = 1, upsample: bool = False, act_silu: bool = False, out32: bool = True,
+                out16: bool = False):
+    """3x3 conv (pad 1) as implicit GEMM over the channels-last fp16 image x16 [F*Hin*Win, Cin_pad]."""
+    if upsample:
+        Hout, Wout = 2 * Hin, 2 * Win
+    else:
+        Hout, Wout = (Hin - 1) // stride + 1, (Win - 1) // stride + 1
+    M = F * Hout * Wout
+    o32 = rt.empty((M, Cout), torch.float32) if out32 else None
+    o16 = rt.empty((M, Cout), torch.float16) if out16 else None
+    rt.be.gemm(x16, w16, M=M, N=Cout, K=9 * Cin_pad, a_mode=E._hip.A_CONV3X3,
+               conv=dict(Cin=Cin_pad, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride, upsample=int(upsample)),
+               bias=bias, act=E._hip.ACT_SILU if act_silu else E._hip.ACT_NONE,
+               out32=o32, ldc32=Cout, out16=o16, ldc16=Cout)
+    return Act(F, Hout, Wout, Cout, f32=o32, f16=o16)
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock, Packable):
+    """openaimodel.py:79-103 — children get (x, emb), (x, context) or (x) according to their type."""
+
+    def __init__(self, *args):
+        super().__init__(*args)
+        self._init_packable()
+
+    def _pack(self):
+        return {i: conv_params(m) for i, m in enumerate(self) if isinstance(m, nn.Conv2d)}
+
+    def _run(self, rt: Runtime, x: Act, emb32, want_f16: bool = False) -> Act:
+        layers = list(self)
+        for i, layer in enumerate(layers):
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            wf = want_f16 if nxt is None else isinstance(nxt, (Upsample, Downsample, nn.Conv2d))
+            if isinstance(layer, ResBlock3D):
+                x = layer._run(rt, x, emb32, want_f16=wf)
+            elif isinstance(layer, SpatialTemporalTransformer):
+                x = layer._run(rt, x, want_f16=wf)
+            elif isinstance(layer, (Upsample, Downsample)):
+                x = layer._run(rt, x, want_f16=wf)
+            elif isinstance(layer, nn.Conv2d):
+                w16, b = self.packed()[i]
+                if layer.kernel_size[0] == 3:
+                    x = run_conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, w16, b, layer.out_channels,
+                                    stride=layer.stride[0], out16=wf)
+                else:
+                    o32 = rt.empty((x.M, layer.out_channels), torch.float32)
+                    o16 = rt.empty((x.M, layer.out_channels), torch.float16) if wf else None
+                    rt.be.gemm(x.need_f16(rt), w16, M=x.M, N=layer.out_channels, K=x.C, lda=x.C, bias=b,
+                               out32=o32, ldc32=layer.out_channels, out16=o16, ldc16=layer.out_channels)
+                    x = Act(x.F, x.H, x.W, layer.out_channels, f32=o32, f16=o16)
+            else:
+                raise NotImplementedError(f"{type(layer).__name__} inside TimestepEmbedSequential")
+        return x
+
+
+class Upsample(nn.Module, Packable):
+    """openaimodel.py:106-142"""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1, third_up=False):
+        super().__init__()
+        if dims != 2 or not use_conv or padding != 1:
+            raise NotImplementedError("Upsample: only dims=2 with a 3x3 conv is on the Panacea path")
+        self.channels, self.out_channels, self.use_conv, self.dims = channels, out_channels or channels, use_conv, dims
+        self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
+        self._init_packable()
+
+    def _pack(self):
+        w, b = conv_params(self.conv)
+        return dict(w=w, b=b)
+
+    def _run(self, rt: Runtime, x: Act, want_f16=False) -> Act:
+        pk = self.packed()
+        return run_conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, pk["w"], pk["b"], self.out_channels,
+                           upsample=True, out16=want_f16)
+
+
+class Downsample(nn.Module, Packable):
+    """openaimodel.py:161-201"""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1, third_down=False):
+        super().__init__()
+        if dims != 2 or not use_conv or padding != 1:
+            raise NotImplementedError("Downsample: only dims=2 with a strided 3x3 conv is on the Panacea path")
+        self.channels, self.out_channels, self.use_conv, self.dims = channels, out_channels or channels, use_conv, dims
+        self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
+        self._init_packable()
+
+    def _pack(self):
+        w, b = conv_params(self.op)
+        return dict(w=w, b=b)
+
+    def _run(self, rt: Runtime, x: Act, want_f16=False) -> Act:
+        pk = self.packed()
+        return run_conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, pk["w"], pk["b"], self.out_channels,
+                           stride=2, out16=want_f16)
+
+
+class ResBlock3D(TimestepBlock, Packable):
+    """openaimodel.py:356-542"""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
+                 use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False, kernel_size=3,
+                 exchange_temb_dims=False, skip_t_emb=False, temporal_kernel_size=3, alpha=1, num_frames=4):
+        super().__init__()
+        if up or down or use_scale_shift_norm or exchange_temb_dims or skip_t_emb or use_conv:
+            raise NotImplementedError("ResBlock3D: up/down/scale-shift/exchange_temb/skip_t_emb/use_conv are dead "
+                                      "paths of the Panacea configuration and are not built")
+        if dims != 2 or kernel_size != 3 or temporal_kernel_size != 3:
+            raise NotImplementedError("ResBlock3D: dims=2, 3x3 spatial and k=3 temporal kernels only")
+        self.num_frames = num_frames
+        self.channels, self.emb_channels, self.dropout = channels, emb_channels, dropout
+        self.out_channels = out_channels or channels
+        self.use_conv, self.use_checkpoint, self.use_scale_shift_norm = use_conv, use_checkpoint, use_scale_shift_norm
+        self.exchange_temb_dims = exchange_temb_dims
+        self.alpha = 1 if alpha == 1 else nn.Parameter(torch.rand(1, requires_grad=True))
+        self.temporal_kernel_size = temporal_kernel_size
+        self.identity_layer = nn.Identity()
+        oc = self.out_channels
+        self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(), conv_nd(dims, channels, oc, 3, padding=1))
+        self.in_layers_temporal = nn.Sequential(normalization(oc), nn.SiLU(),
+                                                zero_module(conv_nd(1, oc, oc, 3, padding=1)))
+        self.updown = False
+        self.h_upd = self.x_upd = nn.Identity()
+        self.skip_t_emb = skip_t_emb
+        self.emb_out_channels = oc
+        self.emb_layers = nn.Sequential(nn.SiLU(), linear(emb_channels, oc))
+        self.out_layers = nn.Sequential(normalization(oc), nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(conv_nd(dims, oc, oc, 3, padding=1)))
+        self.out_layers_temporal = nn.Sequential(normalization(oc), nn.SiLU(), nn.Dropout(p=dropout),
+                                                 zero_module(conv_nd(1, oc, oc, 3, padding=1)))
+        self.skip_connection = nn.Identity() if oc == channels else conv_nd(dims, channels, oc, 1)
+        self._init_packable()
+
+    def _pack(self):
+        f32, il, it, ol, ot = E.pk_f32, self.in_layers, self.in_layers_temporal, self.out_layers, self.out_layers_temporal
+        pk = dict(
+            g1=f32(il[0].weight), b1=f32(il[0].bias), w1=E.pk_conv3x3(il[2].weight), c1=f32(il[2].bias),
+            gt1=f32(it[0].weight), bt1=f32(it[0].bias), wt1=E.pk_conv1d(it[2].weight), ct1=f32(it[2].bias),
+            we=E.pk_linear(self.emb_layers[1].weight), be=f32(self.emb_layers[1].bias),
+            g2=f32(ol[0].weight), b2=f32(ol[0].bias), w2=E.pk_conv3x3(ol[3].weight), c2=f32(ol[3].bias),
+            gt2=f32(ot[0].weight), bt2=f32(ot[0].bias), wt2=E.pk_conv1d(ot[3].weight), ct2=f32(ot[3].bias))
+        if isinstance(self.skip_connection, nn.Conv2d):
+            pk["ws"], pk["bs"] = E.pk_linear(self.skip_connection.weight), f32(self.skip_connection.bias)
+        return pk
+
+    def _run(self, rt: Runtime, x: Act, emb32: torch.Tensor, want_f16: bool = False) -> Act:
+        if rt.T != self.num_frames:
+            raise ValueError(f"runtime has {rt.T} frames per sample, block was built for {self.num_frames}")
+        pk = self.packed()
+        F, H, W, N, M = x.F, x.H, x.W, x.N, x.M
+        Cin, Co = self.channels, self.out_channels
+        hip = E._hip
+        tconv = dict(C=Co, T=rt.T, Npix=N)
+        # in_layers: GN + SiLU + conv3x3
+        a16 = E.gn_spatial(rt, x.f32, F, N, Cin, pk["g1"], pk["b1"], 1e-5, True)
+        h = run_conv3x3(rt, a16, F, H, W, Cin, pk["w1"], pk["c1"], Co).f32
+        # h = h + conv1d_t(SiLU(GN_t(h))) + emb_layers(emb)[frame]      (:505-531)
+        t16 = E.gn_temporal(rt, h, N, Co, pk["gt1"], pk["bt1"], 1e-5)
+        emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels, silu_in=True)
+        rt.be.gemm(t16, pk["wt1"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct1"],
+                   rowbias=emb_out, rb_rows=N, rb_mod=F, res1=h, ldr1=Co, out32=h, ldc32=Co)
+        # out_layers: GN + SiLU + conv3x3
+        a16 = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True)
+        g = run_conv3x3(rt, a16, F, H, W, Co, pk["w2"], pk["c2"], Co).f32
+        t16 = E.gn_temporal(rt, g, N, Co, pk["gt2"], pk["bt2"], 1e-5)
+        # skip path
+        if "ws" in pk:
+            s = rt.empty((M, Co), torch.float32)
+            rt.be.gemm(x.need_f16(rt), pk["ws"], M=M, N=Co, K=Cin, lda=Cin, bias=pk["bs"], out32=s, ldc32=Co)
+        else:
+            s = x.f32
+        # return skip(x) + (g + conv1d_t(SiLU(GN_t(g))))                 (:533-542)
+        o16 = rt.empty((M, Co), torch.float16) if want_f16 else None
+        rt.be.gemm(t16, pk["wt2"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct2"],
+                   res1=g, ldr1=Co, res2=s, ldr2=Co, out32=g, ldc32=Co, out16=o16, ldc16=Co)
+        return Act(F, H, W, Co, f32=g, f16=o16)
+
+    def forward(self, x, emb):
+        from .util import act_from_nchw, runtime_for
+        rt = runtime_for(x, self.num_frames)
+        return self._run(rt, act_from_nchw(rt, x), emb.to(torch.float32).contiguous()).to_nchw().to(x.dtype)
+
+
+class UNetModel3D(nn.Module, Packable):
+    """openaimodel.py:774-1319 — same constructor, same module tree, same state dict."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
+                 use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1,
+                 use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False,
+                 use_spatial_transformer=False, transformer_depth=1, context_dim=None, n_embed=None, legacy=True,
+                 disable_self_attentions=None, num_attention_blocks=None, disable_middle_self_attn=False,
+                 use_linear_in_transformer=False, spatial_transformer_attn_type="softmax", adm_in_channels=None,
+                 use_fairscale_checkpoint=False, offload_to_cpu=False, transformer_depth_middle=None, num_frames=4,
+                 alpha=1, temporal_transformer_attn_type=None, spatial_only_attn_type=None, insert_crossview=False):
+        super().__init__()
+        unsupported = dict(num_classes=num_classes, n_embed=n_embed, resblock_updown=resblock_updown,
+                           use_scale_shift_norm=use_scale_shift_norm, disable_self_attentions=disable_self_attentions,
+                           num_attention_blocks=num_attention_blocks, disable_middle_self_attn=disable_middle_self_attn,
+                           use_fairscale_checkpoint=use_fairscale_checkpoint)
+        bad = {k: v for k, v in unsupported.items() if v}
+        if bad or dims != 2 or not conv_resample or not use_spatial_transformer or context_dim is None:
+            raise NotImplementedError(f"UNetModel3D options outside the Panacea inference configuration: {bad or 'dims/conv_resample/use_spatial_transformer/context_dim'}")
+        if num_head_channels == -1:
+            raise NotImplementedError("num_head_channels must be set (the attention kernels use head dim 64)")
+        self.num_frames = num_frames
+        context_dim = _as_list(context_dim)
+        attention_resolutions = _as_list(attention_resolutions)
+        channel_mult = _as_list(channel_mult)
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        if isinstance(transformer_depth, int):
+            transformer_depth = len(channel_mult) * [transformer_depth]
+        else:
+            transformer_depth = list(transformer_depth)
+        transformer_depth_middle = transformer_depth[-1] if transformer_depth_middle is None else transformer_depth_middle
+        if isinstance(num_res_blocks, int):
+            self.num_res_blocks = len(channel_mult) * [num_res_blocks]
+        else:
+            if len(num_res_blocks) != len(channel_mult):
+                raise ValueError("provide num_res_blocks either as an int or as a per-level list")
+            self.num_res_blocks = list(num_res_blocks)
+        self.attention_resolutions, self.dropout, self.channel_mult = attention_resolutions, dropout, channel_mult
+        self.conv_resample, self.num_classes, self.use_checkpoint = conv_resample, num_classes, use_checkpoint
+        self.num_heads, self.num_head_channels, self.num_heads_upsample = num_heads, num_head_channels, num_heads_upsample
+        self.predict_codebook_ids = False
+        self.alpha = alpha
+
+        time_embed_dim = model_channels * 4
+        self.time_embed_dim = time_embed_dim
+        self.time_embed = nn.Sequential(linear(model_channels, time_embed_dim), nn.SiLU(),
+                                        linear(time_embed_dim, time_embed_dim))
+
+        def res(cin, cout):
+            return ResBlock3D(cin, time_embed_dim, dropout, out_channels=cout, dims=dims,
+                              use_checkpoint=use_checkpoint, num_frames=num_frames, alpha=alpha)
+
+        def stt(ch, depth):
+            return SpatialTemporalTransformer(
+                ch, ch // num_head_channels, num_head_channels, depth=depth, context_dim=context_dim,
+                use_linear=use_linear_in_transformer, attn_type=spatial_transformer_attn_type,
+                use_checkpoint=use_checkpoint, num_frames=num_frames, alpha=alpha,
+                temporal_transformer_attn_type=temporal_transformer_attn_type,
+                spatial_only_attn_type=spatial_only_attn_type, insert_crossview=insert_crossview)
+
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_nd(dims, in_channels, model_channels, 3, padding=1))])
+        input_block_chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(self.num_res_blocks[level]):
+                layers = [res(ch, mult * model_channels)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(stt(ch, transformer_depth[level]))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                input_block_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims, out_channels=ch)))
+                input_block_chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbedSequential(res(ch, ch), stt(ch, transformer_depth_middle), res(ch, ch))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(self.num_res_blocks[level] + 1):
+                ich = input_block_chans.pop()
+                layers = [res(ch + ich, model_channels * mult)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(stt(ch, transformer_depth[level]))
+                if level and i == self.num_res_blocks[level]:
+                    layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(normalization(ch), nn.SiLU(),
+                                 zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
+        self._init_packable()
+
+    # ---- packed parameters owned by the network itself (time embedding MLP, output head)
+    def _pack(self):
+        te = self.time_embed
+        pk = dict(tw0=E.pk_linear(te[0].weight), tb0=E.pk_f32(te[0].bias),
+                  tw2=E.pk_linear(te[2].weight), tb2=E.pk_f32(te[2].bias))
+        if hasattr(self, "out"):
+            pk["og"], pk["ob"] = E.pk_f32(self.out[0].weight), E.pk_f32(self.out[0].bias)
+            pk["ow"], pk["oc"] = E.pk_conv3x3(self.out[2].weight), E.pk_f32(self.out[2].bias)
+        return pk
+
+    def _time_embedding(self, rt: Runtime, timesteps: torch.Tensor) -> torch.Tensor:
+        """timestep_embedding -> Linear -> SiLU -> Linear, all fp32 activations (util.py:224-248, :936-943)."""
+        pk = self.packed()
+        mc, td = self.model_channels, self.time_embed_dim
+        if mc % 8:
+            raise NotImplementedError("model_channels must be a multiple of 8")
+        t_emb = timestep_embedding(timesteps.to(rt.device), mc)
+        h = E.small_linear(rt, t_emb, pk["tw0"], pk["tb0"], rt.F, td, mc, silu_out=True)
+        return E.small_linear(rt, h, pk["tw2"], pk["tb2"], rt.F, td, td)
+
+    def _head(self, rt: Runtime, h: Act) -> torch.Tensor:
+        """self.out: GN + SiLU + conv3x3 -> NCHW fp32 (:1245-1253, controlmodel.py:197-202)."""
+        pk = self.packed()
+        a16 = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, pk["og"], pk["ob"], 1e-5, True)
+        o = run_conv3x3(rt, a16, h.F, h.H, h.W, h.C, pk["ow"], pk["oc"], self.out_channels)
+        out = rt.empty((h.F, self.out_channels, h.H, h.W), torch.float32)
+        rt.be.tokens_to_nchw_f32(o.f32, self.out_channels, h.F, h.N, self.out_channels, out)
+        return out
+
+    def _stem_tokens(self, rt: Runtime, x: torch.Tensor) -> Act:
+        """NCHW network input -> channels-last fp16 tokens (channel count padded to 8)."""
+        F, C, H, W = x.shape
+        cp = (C + 7) // 8 * 8
+        x32 = x.detach().to(torch.float32).contiguous()
+        t16 = rt.empty((F * H * W, cp), torch.float16)
+        rt.be.nchw_to_tokens_f16(x32, C, None, 0, F, H * W, cp, t16)
+        return Act(F, H, W, cp, f16=t16)
+
+    def _run_unet(self, rt: Runtime, x16: Act, emb32: torch.Tensor, control: Optional[list]) -> torch.Tensor:
+        """controlmodel.py:186-202 / openaimodel.py:1305-1319 on tokens."""
+        hs, h = [], x16
+        nb = len(self.input_blocks)
+        for i, module in enumerate(self.input_blocks):
+            nxt = self.input_blocks[i + 1] if i + 1 < nb else None
+            wf = nxt is not None and isinstance(nxt[0], Downsample)
+            h = module._run(rt, h, emb32, want_f16=wf)
+            hs.append(h)
+            if rt.trace is not None:
+                rt.trace[f"input_blocks.{i}"] = h.to_nchw()
+        h = self.middle_block._run(rt, h, emb32)
+        if rt.trace is not None:
+            rt.trace["middle_block"] = h.to_nchw()
+        if control is not None:
+            c = control.pop()
+            rt.be.add_f32(h.f32, c.f32, h.M * h.C, h.f32, None)                       # h += control.pop()
+        for i, module in enumerate(self.output_blocks):
+            s = hs.pop()
+            c = control.pop() if control is not None else None
+            ct = h.C + s.C
+            cat32 = rt.empty((h.M, ct), torch.float32)
+            cat16 = rt.empty((h.M, ct), torch.float16)
+            # th.cat([h, hs.pop() + control.pop()], dim=1): one pass, fp32 stream + fp16 operand
+            rt.be.concat_add(h.f32, h.C, s.f32, None if c is None else c.f32, s.C, h.M, cat32, cat16)
+            h = module._run(rt, Act(h.F, h.H, h.W, ct, f32=cat32, f16=cat16), emb32)
+            if rt.trace is not None:
+                rt.trace[f"output_blocks.{i}"] = h.to_nchw()
+        return self._head(rt, h)
+
+    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+        """openaimodel.py:1279-1319 — x (B*T, C, h, w), timesteps (B*T,), context (B, 77, D)."""
+        assert (y is not None) == (self.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"
+        from .util import runtime_for
+        with torch.no_grad():
+            rt = runtime_for(x, self.num_frames)
+            rt.set_context(context)
+            emb = self._time_embedding(rt, timesteps)
+            out = self._run_unet(rt, self._stem_tokens(rt, x), emb, None)
+        return out.to(x.dtype)

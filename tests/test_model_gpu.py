@@ -1,0 +1,119 @@
+"""End-to-end parity of the HIP path on the MI355X, through the drop-in boundary
+(`OpenAIWrapperControlLDM3D.forward` -> C-ABI kernels):
+
+  * tiny / plain1 networks vs the reference's golden eps (tests/golden) and block outputs;
+  * the FULL Panacea+ network (2 478 tensors, C = 320..1280, 5..20 heads) on a small panorama vs the CPU
+    oracle on the same synthetic weights and inputs;
+  * size-independent properties at BASELINE config 3 size (16 panoramic frames of 32x384): the two CFG
+    halves are independent, a frame permutation inside a sample permutes the output (temporal
+    attention/conv are the only frame couplings and the text context is per sample), determinism.
+
+Tolerances are the fp16-operand tolerances of the design (fp32 residual stream, fp16 MFMA operands,
+fp32 accumulation) against the fp32 oracle on identical fp16-representable weights: see DESIGN.md §6.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, cond, err_stats, golden, manifest, oracle_cfg, product_network, step_inputs
+from oracle import panacea_oracle as po
+from panacea_amd import configs, hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = {"tiny": (4e-3, 8e-4), "plain1": (1.2e-2, 2e-3)}
+
+
+def test_library_is_loaded_and_native():
+    lib = hip.load()
+    assert b"gfx950" in lib.pnc_version()
+    maps = open("/proc/self/maps").read()
+    assert "libpanacea_hip.so" in maps
+
+
+@pytest.mark.parametrize("name", ["tiny", "plain1"])
+def test_hip_path_matches_reference_golden(name):
+    w, _, kw = product_network(name, DEV)
+    inp = step_inputs(name, kw, DEV)
+    gold = golden(name)
+    trace = {}
+    eps = w(inp["x"], inp["t"], cond(inp), trace=trace)
+    torch.cuda.synchronize()
+    st = err_stats(eps, gold["eps"])
+    print(name, st)
+    assert eps.is_cuda and eps.dtype == torch.float32
+    assert st["max_abs"] <= TOL[name][0] and st["mean_abs"] <= TOL[name][1], st
+    for k in gold.files:
+        key = k[6:] if k.startswith("block.") else k
+        if key in trace and k != "eps":
+            ref = gold[k]
+            got = trace[key].reshape(-1)[::7].cpu().numpy()
+            lim = (2e-3 if name == "tiny" else 6e-3) * max(1.0, np.abs(ref).max())
+            assert np.abs(got - ref).max() <= lim, (k, np.abs(got - ref).max())
+
+
+def test_hip_path_other_timesteps_and_frames_vs_oracle():
+    """tiny network, T = 4 frames, t = 333: outside the golden vectors, against the oracle directly."""
+    kw = configs.with_frames(configs.get("tiny"), 4)
+    w, sd, _ = product_network("tiny", DEV, kw=kw)
+    inp = step_inputs("tiny", kw, "cpu", t_index=333, shape=(2, 4, 8, 96))
+    ref = po.wrapper_forward(sd, oracle_cfg(kw), inp["x"], inp["t"], cond(inp))
+    g = {k: v.to(DEV) for k, v in inp.items()}
+    eps = w(g["x"], g["t"], cond(g))
+    st = err_stats(eps, ref)
+    print(st)
+    assert st["max_abs"] <= 4e-3 and st["mean_abs"] <= 8e-4, st
+
+
+def test_full_network_small_panorama_vs_oracle():
+    """Every tensor of the Panacea+ stage-2 network at its real width; latent 8x96, B=1, T=2."""
+    kw = configs.with_frames(configs.get("full"), 2)
+    w, sd, _ = product_network("full", "cpu", kw=kw)
+    inp = step_inputs("full", kw, "cpu", shape=(1, 2, 8, 96))
+    ref = po.wrapper_forward(sd, oracle_cfg(kw), inp["x"], inp["t"], cond(inp))
+    w = w.to(DEV)
+    g = {k: v.to(DEV) for k, v in inp.items()}
+    eps = w(g["x"], g["t"], cond(g))
+    st = err_stats(eps, ref)
+    print("full network, 8x96:", st)
+    assert st["ref_max"] > 1.0
+    assert st["max_abs"] <= 6e-3 and st["mean_abs"] <= 1e-3, st
+
+
+@pytest.fixture(scope="module")
+def full_net():
+    w, _, kw = product_network("full", "cpu")
+    return w.to(DEV), kw
+
+
+def test_full_size_properties_and_golden(full_net):
+    """BASELINE config 3 size: (B, T) = (2, 8), 32x384 latent, 256x3072 BEV hint."""
+    w, kw = full_net
+    inp = step_inputs("full", kw, DEV)
+    eps = w(inp["x"], inp["t"], cond(inp))
+    torch.cuda.synchronize()
+    assert eps.shape == (16, 4, 32, 384) and torch.isfinite(eps).all()
+    # run-to-run: identical up to the order of the LDS float atomics in the GroupNorm statistics
+    eps_b = w(inp["x"], inp["t"], cond(inp))
+    assert (eps - eps_b).abs().max().item() <= 2e-5
+    # the CFG halves never interact inside the network (guiders.py:31-40): the cond half alone gives the same eps
+    half = {k: (v[8:] if v.shape[0] == 16 else v[1:]).contiguous() for k, v in inp.items()}
+    eps_h = w(half["x"], half["t"], cond(half))
+    assert (eps_h - eps[8:]).abs().max().item() <= 2e-5
+    # samples are isolated: perturbing sample 0 (latent, hint, text) leaves sample 1's eps unchanged
+    pert = {k: v.clone() for k, v in inp.items()}
+    pert["x"][:8] += 0.5
+    pert["cond_feat"][:8] = 1.0 - pert["cond_feat"][:8]
+    pert["crossattn"][0] *= -1.0
+    eps_p = w(pert["x"], pert["t"], cond(pert))
+    assert (eps_p[8:] - eps[8:]).abs().max().item() <= 2e-5
+    assert (eps_p[:8] - eps[:8]).abs().max().item() > 1e-2
+    # full-size golden: the REFERENCE itself on the same synthetic weights/inputs (oracle/gen_golden_full.py)
+    path = GOLDEN / "full_cfg3.npz"
+    if path.exists():
+        g = np.load(path)
+        st = err_stats(eps.reshape(-1)[::7], g["eps_s7"])
+        print("config 3 vs reference:", st)
+        assert st["max_abs"] <= 8e-3 and st["mean_abs"] <= 1e-3, st
+    else:
+        pytest.skip("tests/golden/full_cfg3.npz not generated yet (property checks passed)")

@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py — denoising steps/s of the Panacea hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE config 3): the full Panacea+ stage-2 network (ControlledUNetModel3D + ControlNet3D,
+2 478 tensors, 2.24 B parameters, synthetic fp16-representable weights), 6 views x 8 frames at 256x512
+per view (latent (8, 4, 32, 384), BEV hint (8, 19, 256, 3072)), classifier-free guidance scale 5 => one
+"step" = `EulerEDMSampler.sampler_step` = VanillaCFG.prepare_inputs -> DiscreteDenoiser -> eps_theta on
+2 x 8 = 16 panoramic frames -> CFG combine -> Euler update, walking the 50-step LegacyDDPM schedule.
+Inputs are resident in HBM before the timed region; nothing is cached across steps (hint stem and text K/V
+are recomputed every step, like the reference).
+
+N > 1: one process per GPU, one independent sample per rank (the reference's own multi-GPU strategy,
+inference.py:248-280 — replicas, no collective on the data path), hence "scaling": "weak".
+
+Rank 0 prints ONE JSON line.  `roofline` prices the whole step against the dense fp16 MFMA peak using the
+ALGORITHMIC 96.59 TFLOP/step of SURVEY.md §8(d); `roofline.kernels` is a per-kernel-family breakdown from a
+HIP-event-instrumented extra step (same process, not part of the timed region); `cpu_baseline` is the CPU
+oracle (a port of the reference's op graph, faithful mode) on a bounded sample on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+ALGO_TFLOP_PER_STEP = 96.59        # SURVEY.md §8(d), (B, T) = (2, 8), 6 views, 256x512
+MFMA_PEAK_TFLOPS = 2500.0          # dense fp16, MI355X_MICROARCH.md
+GOLDEN_FULL = ROOT / "tests" / "golden" / "full_cfg3.npz"
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(kw, sd, threads_note=True):
+    """The reference's CPU path, restated (oracle, faithful op graph incl. the per-pixel text K/V projection),
+    timed on a bounded sample: ONE CFG half (B=1) x 8 frames on a 16x192 latent (1/4 of the pixels).
+    steps/s is extrapolated linearly in frames x pixels (x2 halves x4 pixels), which flatters the CPU: the
+    intra-/cross-view attention it under-counts is quadratic in view size."""
+    from oracle import panacea_oracle as po
+    from panacea_amd import synth
+    cfg = po.OracleConfig(num_frames=kw["num_frames"], model_channels=kw["model_channels"],
+                          num_head_channels=kw["num_head_channels"], spatial_only_attn_type=kw["spatial_only_attn_type"],
+                          insert_crossview=kw["insert_crossview"], faithful_temporal_context=True)
+    inp = synth.synth_inputs(1, kw["num_frames"], 16, 192, context_dim=kw["context_dim"])
+    c = {k: inp[k] for k in ("concat", "crossattn", "cond_feat")}
+    t0 = time.time()
+    po.wrapper_forward(sd, cfg, inp["x"], inp["t"], c)
+    dt = time.time() - t0
+    scale = 2 * 4
+    return {"value": 1.0 / (dt * scale), "unit": "denoising steps/s", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"oracle (fp32 torch, faithful op graph) on 1 CFG half x 8 frames x 16x192 latent: {dt:.1f} s; "
+                      f"x{scale} linear extrapolation to 2 halves x 32x384",
+            "sample_seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="full", choices=["full", "tiny"])
+    ap.add_argument("--num-sampling-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-breakdown", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from panacea_amd import build_network, configs, hip, sampling, synth
+    hip.load()
+    kw = configs.get(args.config)
+    B, T, h, w = configs.SHAPES[args.config]
+    man = json.loads((ROOT / "tests" / "golden" / f"manifest_{args.config}.json").read_text())
+    t0 = time.time()
+    sd = synth.synth_state_dict(man)
+    net = build_network(kw)
+    net.diffusion_model.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    log(f"[rank {rank}] network built in {time.time() - t0:.0f}s")
+
+    # one sample per rank: c / uc conditioning of ONE 6-view x T-frame clip (seed offset by rank, inference.py:250)
+    inp = synth.synth_inputs(2, T, h, w, context_dim=kw["context_dim"], salt=rank)
+    g = {k: v.to(dev) for k, v in inp.items()}
+    cond = {"crossattn": g["crossattn"][1:2], "concat": g["concat"][T:], "cond_feat": g["cond_feat"][T:]}
+    uc = {"crossattn": g["crossattn"][0:1], "concat": g["concat"][:T], "cond_feat": g["cond_feat"][:T]}
+    den = sampling.DiscreteDenoiser().to(dev)
+    smp = sampling.EulerEDMSampler(args.num_sampling_steps, guider=sampling.VanillaCFG(5.0), device=dev)
+    sig = smp.sigmas()
+    nsig = len(sig) - 1
+    x = g["x"][T:] * torch.sqrt(1.0 + sig[0] ** 2.0)
+    s_in = x.new_ones([T])
+    denoiser = lambda xi, sigma, cc: den(net, xi, sigma, cc)   # noqa: E731
+
+    def step(i, xx):
+        j = i % nsig
+        return smp.sampler_step(s_in * sig[j], s_in * sig[j + 1], denoiser, xx, cond, uc)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    with torch.no_grad():
+        # parity guard inside the bench run: eps of the very first network call vs the reference's own output
+        parity = None
+        if args.config == "full" and rank == 0 and GOLDEN_FULL.exists():
+            import numpy as np
+            gold = np.load(GOLDEN_FULL)
+            eps = net(g["x"], g["t"], {k: g[k] for k in ("concat", "crossattn", "cond_feat")})
+            d = (eps.reshape(-1)[::7].float().cpu() - torch.from_numpy(gold["eps_s7"])).abs()
+            parity = {"eps_max_abs_err": d.max().item(), "eps_mean_abs_err": d.mean().item(),
+                      "eps_ref_rms": float(gold["eps_rms"]), "against": "reference fp32 CPU forward (tests/golden/full_cfg3.npz)"}
+            log(f"parity vs reference: {parity}")
+        xx = x
+        for i in range(args.warmup):
+            xx = step(i, xx)
+        torch.cuda.synchronize()
+        if args.graph:
+            from panacea_amd.graph import GraphedStep
+            gs = GraphedStep(step_fn=lambda xi, j: smp.sampler_step(s_in * sig[j], s_in * sig[j + 1], denoiser, xi, cond, uc),
+                             example=x, nsig=nsig)
+            run = gs
+        else:
+            run = None
+        barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for i in range(args.steps):
+            xx = step(args.warmup + i, xx) if run is None else run(xx, (args.warmup + i) % nsig)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(xx).all()
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed           # every rank advances its own sample by `steps`
+    out = {
+        "metric": "denoising steps/s (6-view x 8-frame 256x512)", "value": value, "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "BASELINE config 3: Panacea+ stage-2 UNet+ControlNet, CFG 2 x 8 frames, 6 views, latent 32x384, "
+                               "hint 256x3072, Euler/LegacyDDPM 50-step schedule" if args.config == "full" else "tiny",
+                   "frames_per_step": 2 * T, "parallelism": f"replica x{world}" if world > 1 else "single",
+                   "graph": bool(args.graph)},
+    }
+    if args.config == "full":
+        ach = ALGO_TFLOP_PER_STEP * (value / world)
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                           "basis": "96.59 algorithmic TFLOP per step (SURVEY.md §8d) / measured step time, per GPU"}
+    if parity:
+        out["parity"] = parity
+
+    if rank == 0 and not args.no_kernel_breakdown:
+        prof = hip.Profiler()
+        hip.set_profiler(prof)
+        with torch.no_grad():
+            step(0, x)
+        hip.set_profiler(None)
+        summ = prof.summary()
+        tot = sum(v["ms"] for v in summ.values())
+        kern = {}
+        for fam, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+            e = {"launches": v["launches"], "ms": round(v["ms"], 3), "share": round(v["ms"] / tot, 4)}
+            if v["flops"]:
+                e["TFLOP/s"] = round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)
+            elif v["bytes"]:
+                e["GB/s"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0)
+            kern[fam] = e
+        out.setdefault("roofline", {})["kernels"] = kern
+        out["roofline"]["kernel_ms_sum"] = round(tot, 2)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "full":
+        del net
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(kw, sd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,10 +116,53 @@ def small_vectors(ns):
     print("[tables] written")
 
 
+def fake_network(x, t, c):
+    """closed-form stand-in for eps_theta so that the sampler / denoiser / guider arithmetic can be pinned"""
+    return torch.tanh(0.3 * x) * 0.5 + 1e-4 * t.float()[:, None, None, None] + 0.01 * c["crossattn"].mean() \
+        + 0.05 * c["concat"]
+
+
+def sampler_vectors(ns):
+    """3- and 25-step EulerEDMSampler + VanillaCFG(5) + DiscreteDenoiser(EpsScaling) trajectory of the REFERENCE
+    classes (sampling.py, guiders.py, denoiser.py, discretizer.py) around `fake_network`."""
+    import importlib
+    P = "sgm.modules.diffusionmodules."
+    for m in ("guiders", "discretizer", "denoiser_scaling", "denoiser_weighting", "sampling_utils"):
+        importlib.import_module(P + m)
+    disc = {"target": P + "discretizer.LegacyDDPMDiscretization"}
+    den = ns.dn.DiscreteDenoiser(weighting_config={"target": P + "denoiser_weighting.EpsWeighting"},
+                                 scaling_config={"target": P + "denoiser_scaling.EpsScaling"}, num_idx=1000,
+                                 discretization_config=disc)
+    out = {"denoiser.sigmas": den.sigmas.numpy()}
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(2, 4, 4, 12, generator=g)
+    c = {"crossattn": torch.randn(1, 77, 8, generator=g), "concat": torch.randn(2, 4, 4, 12, generator=g),
+         "cond_feat": torch.rand(2, 19, 8, 8, generator=g)}
+    uc = {"crossattn": torch.randn(1, 77, 8, generator=g), "concat": c["concat"].clone(), "cond_feat": c["cond_feat"].clone()}
+    for n in (3, 25):
+        smp = ns.sp.EulerEDMSampler(num_steps=n, discretization_config=disc, device="cpu",
+                                    guider_config={"target": P + "guiders.VanillaCFG", "params": {"scale": 5.0}})
+        seen = []
+
+        def net(x, t, cc):
+            seen.append(t.clone())
+            return fake_network(x, t, cc)
+        xs = smp(lambda inp, sigma, cc: den(net, inp, sigma, cc), x0.clone(), c, uc)
+        out[f"sampler.{n}.sigmas"] = smp.discretization(n, device="cpu").numpy()
+        out[f"sampler.{n}.timesteps"] = torch.stack(seen)[:, 0].numpy()
+        out[f"sampler.{n}.x_final"] = xs.numpy()
+    np.savez_compressed(GOLDEN / "sampler.npz", **out)
+    print("[sampler] timesteps(3) =", out["sampler.3.timesteps"], " sigma0 =", out["sampler.25.sigmas"][0])
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     ns = ref_import.import_reference()
+    if "--sampler-only" in sys.argv:
+        sampler_vectors(ns)
+        sys.exit(0)
     small_vectors(ns)
+    sampler_vectors(ns)
     for name in ("tiny", "plain1"):
         run_config(ns, name)
     full_manifest(ns)

@@ -23,15 +23,18 @@ __device__ __forceinline__ ChanMap chan_map(int C, int tid) {
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int ldx, int Npix, int C,
                                                        int ppc, float* __restrict__ partial) {
-    __shared__ float s_sum[GROUPS], s_sq[GROUPS];
+    // Deterministic: per-thread channel sums go to LDS [pixel lane][channel] and ONE thread per group adds
+    // them in a fixed order (no float atomics: a 1e-7 run-to-run wobble here would decorrelate the fp16
+    // rounding of everything downstream).
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // [PL][C] sums, then [PL][C] squares
     const int f = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int tid = threadIdx.x;
-    if (tid < GROUPS) { s_sum[tid] = 0.0f; s_sq[tid] = 0.0f; }
-    __syncthreads();
     const ChanMap cm = chan_map(C, tid);
     const int cpg = C / GROUPS;
     const int p0 = chunk * ppc;
     const int p1 = min(Npix, p0 + ppc);
+    float* s_sum = sm;
+    float* s_sq = sm + cm.PL * C;
     float sum[MAXV][4], sq[MAXV][4];
 #pragma unroll
     for (int j = 0; j < MAXV; ++j)
@@ -54,20 +57,24 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         for (int j = 0; j < MAXV; ++j) {
             const int cv = cm.cv0 + j * cm.CVT;
             if (cv < cm.CV) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int gidx = (cv * 4 + e) / cpg;
-                    atomicAdd(&s_sum[gidx], sum[j][e]);
-                    atomicAdd(&s_sq[gidx], sq[j][e]);
-                }
+                f32x4 a = {sum[j][0], sum[j][1], sum[j][2], sum[j][3]};
+                f32x4 b = {sq[j][0], sq[j][1], sq[j][2], sq[j][3]};
+                *reinterpret_cast<f32x4*>(s_sum + cm.pl * C + cv * 4) = a;
+                *reinterpret_cast<f32x4*>(s_sq + cm.pl * C + cv * 4) = b;
             }
         }
     }
     __syncthreads();
     if (tid < GROUPS) {
+        float ts = 0.0f, tq = 0.0f;
+        for (int pl = 0; pl < cm.PL; ++pl)
+            for (int c = 0; c < cpg; ++c) {
+                ts += s_sum[pl * C + tid * cpg + c];
+                tq += s_sq[pl * C + tid * cpg + c];
+            }
         const float n = (float)(p1 - p0) * (float)cpg;
-        const float mean = n > 0 ? s_sum[tid] / n : 0.0f;
-        const float m2 = n > 0 ? fmaxf(s_sq[tid] - s_sum[tid] * mean, 0.0f) : 0.0f;
+        const float mean = n > 0 ? ts / n : 0.0f;
+        const float m2 = n > 0 ? fmaxf(tq - ts * mean, 0.0f) : 0.0f;
         float* o = partial + ((int64_t)(f * nchunk + chunk) * GROUPS + tid) * 3;
         o[0] = n; o[1] = mean; o[2] = m2;
     }
@@ -256,7 +263,9 @@ extern "C" int pnc_groupnorm_stats(const float* x, int ldx, int F, int Npix, int
     if (C % 64 || C > 4 * 256 * MAXV || ldx % 4) return PNC_EINVAL;
     if ((uintptr_t)x & 15) return PNC_EALIGN;
     const int nchunk = (Npix + pix_per_chunk - 1) / pix_per_chunk;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, F), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    const int CV = C / 4, CVT = CV < 256 ? CV : 256, PL = 256 / CVT;
+    const size_t lds = (size_t)2 * PL * C * sizeof(float);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, F), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
                        x, ldx, Npix, C, pix_per_chunk, partial);
     return pnc_launch_status();
 }

@@ -117,6 +117,44 @@ def load():
     return lib
 
 
+class Profiler:
+    """Per-launch HIP-event timing by kernel family (bench.py's instrumented pass; off by default).
+    Events are recorded on the current torch stream, which is the stream every kernel is launched on."""
+
+    def __init__(self):
+        self.records = []          # (family, ev0, ev1, flops, bytes)
+
+    def summary(self) -> dict:
+        torch.cuda.synchronize()
+        out = {}
+        for fam, e0, e1, fl, by in self.records:
+            d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+_PROF: Optional[Profiler] = None
+
+
+def set_profiler(p: Optional[Profiler]):
+    global _PROF
+    _PROF = p
+
+
+def _timed(family: str, flops: float, nbytes: float, fn, *args):
+    if _PROF is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    _PROF.records.append((family, e0, e1, flops, nbytes))
+    return rc
+
+
 def _check(rc: int, what: str):
     if rc != 0:
         kind = {-1: "PNC_EINVAL (unsupported shape/argument)", -2: "PNC_EALIGN (alignment)"}.get(rc, f"hipError {rc}")
@@ -171,7 +209,8 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
     p.out16t, p.ldt, p.t_rows, p.t_gstride = _ptr(out16t), ldt, t_rows, t_gstride
     p.n_split = n_split if out16t is not None else N
     p.act, p.geglu = act, int(geglu)
-    _check(load().pnc_gemm_f16(C.byref(p), _stream()), "pnc_gemm_f16")
+    fam = ("gemm_plain", "gemm_conv3x3", "gemm_conv1d_t")[a_mode]
+    _check(_timed(fam, 2.0 * M * N * K, 0.0, load().pnc_gemm_f16, C.byref(p), _stream()), "pnc_gemm_f16")
 
 
 def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H, W, views,
@@ -187,38 +226,43 @@ def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H
         for j, u in enumerate(s):
             p.seg[v][j] = u
     p.scale = scale
-    _check(load().pnc_attn_views_f16(C.byref(p), _stream()), "pnc_attn_views_f16")
+    nq = H * (W // views)
+    nkeys = sum(len(sv) for sv in segs) * kv_valid
+    _check(_timed("attn_views", 4.0 * groups * heads * nq * nkeys * 64, 0.0, load().pnc_attn_views_f16,
+                  C.byref(p), _stream()), "pnc_attn_views_f16")
 
 
 def attn_temporal(q, ldq, k, ldk, v, ldv, o, ldo, *, B, T, Npix, heads, scale):
-    _check(load().pnc_attn_temporal_f16(_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(o), ldo,
-                                        B, T, Npix, heads, scale, _stream()), "pnc_attn_temporal_f16")
+    nb = 8.0 * B * T * Npix * heads * 64
+    _check(_timed("attn_temporal", 0.0, nb, load().pnc_attn_temporal_f16, _ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv,
+                  _ptr(o), ldo, B, T, Npix, heads, scale, _stream()), "pnc_attn_temporal_f16")
 
 
 def groupnorm_stats(x32, ldx, F, Npix, Cch, ppc, partial):
-    _check(load().pnc_groupnorm_stats(_ptr(x32), ldx, F, Npix, Cch, ppc, _ptr(partial), _stream()),
-           "pnc_groupnorm_stats")
+    _check(_timed("groupnorm", 0.0, 4.0 * F * Npix * Cch, load().pnc_groupnorm_stats, _ptr(x32), ldx, F, Npix, Cch,
+                  ppc, _ptr(partial), _stream()), "pnc_groupnorm_stats")
 
 
 def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy):
-    _check(load().pnc_groupnorm_apply(_ptr(x32), ldx, F, Npix, Cch, ppc, _ptr(partial), _ptr(gamma),
-                                      _ptr(beta), eps, int(silu), _ptr(y16), ldy, _stream()),
+    _check(_timed("groupnorm", 0.0, 6.0 * F * Npix * Cch, load().pnc_groupnorm_apply, _ptr(x32), ldx, F, Npix, Cch,
+                  ppc, _ptr(partial), _ptr(gamma), _ptr(beta), eps, int(silu), _ptr(y16), ldy, _stream()),
            "pnc_groupnorm_apply")
 
 
 def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16):
-    _check(load().pnc_groupnorm_temporal_silu(_ptr(x32), B, T, Npix, Cch, _ptr(gamma), _ptr(beta), eps,
-                                              _ptr(y16), _stream()), "pnc_groupnorm_temporal_silu")
+    _check(_timed("groupnorm_temporal", 0.0, 6.0 * B * T * Npix * Cch, load().pnc_groupnorm_temporal_silu,
+                  _ptr(x32), B, T, Npix, Cch, _ptr(gamma), _ptr(beta), eps, _ptr(y16), _stream()),
+           "pnc_groupnorm_temporal_silu")
 
 
 def layernorm(x32, ldx, M, Cch, gamma, beta, eps, y16, ldy):
-    _check(load().pnc_layernorm(_ptr(x32), ldx, M, Cch, _ptr(gamma), _ptr(beta), eps, _ptr(y16), ldy,
-                                _stream()), "pnc_layernorm")
+    _check(_timed("layernorm", 0.0, 6.0 * M * Cch, load().pnc_layernorm, _ptr(x32), ldx, M, Cch, _ptr(gamma),
+                  _ptr(beta), eps, _ptr(y16), ldy, _stream()), "pnc_layernorm")
 
 
 def linear_smallm(a32, lda, w16, bias, out32, ldo, M, N, K, silu_in=False, silu_out=False):
-    _check(load().pnc_linear_smallm(_ptr(a32), lda, _ptr(w16), _ptr(bias), _ptr(out32), ldo, M, N, K,
-                                    int(silu_in), int(silu_out), _stream()), "pnc_linear_smallm")
+    _check(_timed("linear_smallm", 2.0 * M * N * K, 2.0 * N * K, load().pnc_linear_smallm, _ptr(a32), lda, _ptr(w16),
+                  _ptr(bias), _ptr(out32), ldo, M, N, K, int(silu_in), int(silu_out), _stream()), "pnc_linear_smallm")
 
 
 def timestep_embedding(t_i64, F, dim, freqs, out32):
@@ -227,8 +271,8 @@ def timestep_embedding(t_i64, F, dim, freqs, out32):
 
 
 def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16):
-    _check(load().pnc_nchw_to_tokens_f16(_ptr(a32), C1, _ptr(b32), C2, F, Npix, Cpad, _ptr(out16),
-                                         _stream()), "pnc_nchw_to_tokens_f16")
+    _check(_timed("layout", 0.0, F * Npix * (4.0 * (C1 + C2) + 2.0 * Cpad), load().pnc_nchw_to_tokens_f16, _ptr(a32),
+                  C1, _ptr(b32), C2, F, Npix, Cpad, _ptr(out16), _stream()), "pnc_nchw_to_tokens_f16")
 
 
 def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):
@@ -237,12 +281,14 @@ def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):
 
 
 def concat_add(a32, C1, s32, c32, C2, M, out32, out16):
-    _check(load().pnc_concat_add(_ptr(a32), C1, _ptr(s32), _ptr(c32), C2, M, _ptr(out32), _ptr(out16),
-                                 _stream()), "pnc_concat_add")
+    nb = M * (4.0 * C1 + (8.0 if c32 is not None else 4.0) * C2 + 6.0 * (C1 + C2))
+    _check(_timed("elementwise", 0.0, nb, load().pnc_concat_add, _ptr(a32), C1, _ptr(s32), _ptr(c32), C2, M,
+                  _ptr(out32), _ptr(out16), _stream()), "pnc_concat_add")
 
 
 def add_f32(x32, a32, n, y32, y16):
-    _check(load().pnc_add_f32(_ptr(x32), _ptr(a32), n, _ptr(y32), _ptr(y16), _stream()), "pnc_add_f32")
+    _check(_timed("elementwise", 0.0, 12.0 * n, load().pnc_add_f32, _ptr(x32), _ptr(a32), n, _ptr(y32), _ptr(y16),
+                  _stream()), "pnc_add_f32")
 
 
 def cast_f16(x32, n, y16):

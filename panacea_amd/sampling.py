@@ -1,0 +1,146 @@
+"""The callers either side of the hot path: discretisation, discrete denoiser with
+eps-scaling, classifier-free guidance and the Euler sampler of `configs/inference_nuscenes.yaml`.
+
+Host-side mirrors with the reference's names and call signatures
+  LegacyDDPMDiscretization   sgm/modules/diffusionmodules/discretizer.py:42-69
+  EpsScaling                 .../denoiser_scaling.py:16-22
+  DiscreteDenoiser           .../denoiser.py:31-63
+  VanillaCFG                 .../guiders.py:8-40 (+ sampling_utils.py:7-9)
+  EulerEDMSampler            .../sampling.py:27-133,214-218
+written for a device-resident loop: the sigma schedule is a Python list of floats plus one device tensor
+(no `.item()` sync per step — the reference compares Python floats with a device element at
+sampling.py:118-122), and every per-step quantity (c_in, c_out, timestep index) is a host scalar.
+These are a handful of elementwise torch ops per step; the arithmetic that matters is in the network.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def append_dims(x: torch.Tensor, target_dims: int) -> torch.Tensor:
+    return x[(...,) + (None,) * (target_dims - x.ndim)]
+
+
+class LegacyDDPMDiscretization:
+    """discretizer.py:42-69 — sigma_i = sqrt((1 - abar_i) / abar_i) of the 1000-step linear-beta DDPM schedule."""
+
+    def __init__(self, linear_start=0.00085, linear_end=0.0120, num_timesteps=1000):
+        self.num_timesteps = num_timesteps
+        betas = np.linspace(linear_start ** 0.5, linear_end ** 0.5, num_timesteps, dtype=np.float64) ** 2
+        self.alphas_cumprod = np.cumprod(1.0 - betas, axis=0)
+
+    def get_sigmas(self, n, device="cpu"):
+        if n < self.num_timesteps:
+            ts = np.linspace(self.num_timesteps - 1, 0, n, endpoint=False).astype(int)[::-1]
+            ac = self.alphas_cumprod[ts]
+        elif n == self.num_timesteps:
+            ac = self.alphas_cumprod
+        else:
+            raise ValueError("more sampling steps than training timesteps")
+        sig = torch.tensor((1 - ac) / ac, dtype=torch.float32, device=device) ** 0.5
+        return torch.flip(sig, (0,))
+
+    def __call__(self, n, do_append_zero=True, device="cpu", flip=False):
+        s = self.get_sigmas(n, device=device)
+        if do_append_zero:
+            s = torch.cat([s, s.new_zeros([1])])
+        return s if not flip else torch.flip(s, (0,))
+
+
+class EpsScaling:
+    """denoiser_scaling.py:16-22"""
+
+    def __call__(self, sigma):
+        return torch.ones_like(sigma), -sigma, 1 / (sigma ** 2 + 1.0) ** 0.5, sigma.clone()
+
+
+class DiscreteDenoiser(nn.Module):
+    """denoiser.py:31-63 with EpsScaling: snaps sigma to the 1000-entry table and hands the network its INDEX."""
+
+    def __init__(self, num_idx=1000, discretization=None, do_append_zero=False, quantize_c_noise=True, flip=True):
+        super().__init__()
+        disc = discretization or LegacyDDPMDiscretization()
+        self.register_buffer("sigmas", disc(num_idx, do_append_zero=do_append_zero, flip=flip))
+        self.scaling = EpsScaling()
+        self.quantize_c_noise = quantize_c_noise
+
+    def sigma_to_idx(self, sigma):
+        return (sigma - self.sigmas[:, None]).abs().argmin(dim=0).view(sigma.shape)
+
+    def idx_to_sigma(self, idx):
+        return self.sigmas[idx]
+
+    def __call__(self, network: Callable, input: torch.Tensor, sigma: torch.Tensor, cond: Dict) -> torch.Tensor:
+        sigma = self.idx_to_sigma(self.sigma_to_idx(sigma))
+        shape = sigma.shape
+        sigma = append_dims(sigma, input.ndim)
+        c_skip, c_out, c_in, c_noise = self.scaling(sigma)
+        c_noise = c_noise.reshape(shape)
+        if self.quantize_c_noise:
+            c_noise = self.sigma_to_idx(c_noise)
+        return network(input * c_in, c_noise, cond) * c_out + input * c_skip
+
+
+class VanillaCFG:
+    """guiders.py:8-40: batch-doubling (uncond half first) and x_u + s (x_c - x_u)."""
+    KEYS = ("vector", "crossattn", "concat", "cond_feat", "cond_bev_feat")
+
+    def __init__(self, scale, dyn_thresh_config=None):
+        self.scale = scale
+
+    def __call__(self, x, sigma):
+        x_u, x_c = x.chunk(2)
+        return x_u + self.scale * (x_c - x_u)
+
+    def prepare_inputs(self, x, s, c, uc):
+        c_out = {}
+        for k in c:
+            if k in self.KEYS:
+                c_out[k] = torch.cat((uc[k], c[k]), 0)
+            else:
+                assert c[k] == uc[k]
+                c_out[k] = c[k]
+        return torch.cat([x] * 2), torch.cat([s] * 2), c_out
+
+
+class EulerEDMSampler:
+    """sampling.py:27-133,214-218 with s_churn = 0 (deterministic; == DDIM for eps-prediction)."""
+
+    def __init__(self, num_steps: int, guider: Optional[VanillaCFG] = None, discretization=None, device="cuda"):
+        self.num_steps = num_steps
+        self.discretization = discretization or LegacyDDPMDiscretization()
+        self.guider = guider
+        self.device = device
+
+    def sigmas(self, num_steps=None) -> torch.Tensor:
+        return self.discretization(self.num_steps if num_steps is None else num_steps, device=self.device)
+
+    def denoise(self, x, denoiser, sigma, cond, uc):
+        if self.guider is None:
+            return denoiser(x, sigma, cond)
+        return self.guider(denoiser(*self.guider.prepare_inputs(x, sigma, cond, uc)), sigma)
+
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc=None):
+        denoised = self.denoise(x, denoiser, sigma, cond, uc)
+        d = (x - denoised) / append_dims(sigma, x.ndim)
+        return x + append_dims(next_sigma - sigma, x.ndim) * d
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
+        sig = self.sigmas(num_steps)
+        uc = cond if uc is None else uc
+        x = x * torch.sqrt(1.0 + sig[0] ** 2.0)
+        s_in = x.new_ones([x.shape[0]])
+        for i in range(len(sig) - 1):
+            x = self.sampler_step(s_in * sig[i], s_in * sig[i + 1], denoiser, x, cond, uc)
+        return x
+
+
+def timestep_indices(num_steps: int) -> List[int]:
+    """The int64 timestep indices the network sees over a `num_steps` schedule (999, 959, ... for 25)."""
+    den = DiscreteDenoiser()
+    sig = LegacyDDPMDiscretization()(num_steps)[:-1]
+    return den.sigma_to_idx(sig).tolist()

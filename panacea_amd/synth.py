@@ -48,8 +48,16 @@ def synth_tensor(name: str, shape: Tuple[int, ...], salt: int = 0) -> torch.Tens
     return torch.from_numpy(_fp16_round(a))
 
 
-def synth_state_dict(manifest: Dict[str, Iterable[int]], salt: int = 0) -> Dict[str, torch.Tensor]:
-    return {k: synth_tensor(k, tuple(v), salt) for k, v in manifest.items()}
+def synth_state_dict(manifest: Dict[str, Iterable[int]], salt: int = 0, threads: int = 8) -> Dict[str, torch.Tensor]:
+    """Every tensor is generated from its own (name, shape) stream, so the result does not depend on the
+    thread count; numpy's Generator releases the GIL while sampling."""
+    items = list(manifest.items())
+    if threads <= 1 or len(items) < 64:
+        return {k: synth_tensor(k, tuple(v), salt) for k, v in items}
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(threads) as ex:
+        vals = list(ex.map(lambda kv: synth_tensor(kv[0], tuple(kv[1]), salt), items))
+    return {k: v for (k, _), v in zip(items, vals)}
 
 
 def synth_inputs(B: int, T: int, h: int, w: int, context_dim: int = 1024, hint_channels: int = 19,

@@ -118,9 +118,14 @@ def main():
     s_in = x.new_ones([T])
     denoiser = lambda xi, sigma, cc: den(net, xi, sigma, cc)   # noqa: E731
 
+    sig_rows = [s_in * sig[j] for j in range(nsig + 1)]          # per-step sigma vectors, resident
+
+    def step_fn(xi, sigma, next_sigma):
+        return smp.sampler_step(sigma, next_sigma, denoiser, xi, cond, uc)
+
     def step(i, xx):
         j = i % nsig
-        return smp.sampler_step(s_in * sig[j], s_in * sig[j + 1], denoiser, xx, cond, uc)
+        return step_fn(xx, sig_rows[j], sig_rows[j + 1])
 
     def barrier():
         if world > 1:
@@ -141,18 +146,19 @@ def main():
         for i in range(args.warmup):
             xx = step(i, xx)
         torch.cuda.synchronize()
+        run = None
         if args.graph:
             from panacea_amd.graph import GraphedStep
-            gs = GraphedStep(step_fn=lambda xi, j: smp.sampler_step(s_in * sig[j], s_in * sig[j + 1], denoiser, xi, cond, uc),
-                             example=x, nsig=nsig)
-            run = gs
-        else:
-            run = None
+            run = GraphedStep(step_fn, x, sig_rows[0], sig_rows[1])
+            for i in range(args.warmup):
+                xx = run(xx, sig_rows[i % nsig], sig_rows[i % nsig + 1])
+            torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
         for i in range(args.steps):
-            xx = step(args.warmup + i, xx) if run is None else run(xx, (args.warmup + i) % nsig)
+            j = (args.warmup + i) % nsig
+            xx = step(args.warmup + i, xx) if run is None else run(xx, sig_rows[j], sig_rows[j + 1])
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t_start

@@ -1,0 +1,11 @@
+"""Put this directory first on PYTHONPATH to run the reference's inference.py unchanged on the MI355X path:
+
+    PYTHONPATH=<repo>/dropin_site:<repo>:<reference> python -m torch.distributed.launch ... inference.py ...
+
+(see panacea_amd/dropin.py and INTEGRATION.md)."""
+try:
+    import panacea_amd.dropin as _d
+    _d.install(lazy=True)
+except Exception as _e:  # pragma: no cover - never break interpreter start-up
+    import sys
+    print(f"[panacea_amd] drop-in not armed: {_e}", file=sys.stderr)

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void attn_views_kernel(const PncAttnParams p) 
     const int g = blockIdx.z / p.heads, head = blockIdx.z % p.heads;
     const int Wv = p.W / p.views, Nq = p.H * Wv;
     const int kvWv = p.kvW / p.kv_views;
-    const int Nkv = p.kvH * kvWv;                    // keys per kv view (multiple of 8)
+    const int Nkv = p.kvH * kvWv;                    // keys per kv view
+    const bool vec_v = ((kvWv & 7) == 0) && ((p.kvW & 7) == 0) && ((p.ldvt & 7) == 0) && ((p.vt_gstride & 7) == 0);
     const int kvg = g / p.q_per_kv;
     const int hc = head * 64;
 
@@ -87,9 +88,22 @@ __global__ __launch_bounds__(256) void attn_views_kernel(const PncAttnParams p) 
             const int d = sr + 32 * i;
             const int kc = key0 + sc8 * 8;
             if (kc < Nkv) {
-                const int ky = kc / kvWv, kx = kview * kvWv + (kc - ky * kvWv);
-                rv[i] = *reinterpret_cast<const half8v*>(
-                    VT + (int64_t)kvg * p.vt_gstride + (int64_t)(hc + d) * p.ldvt + (int64_t)ky * p.kvW + kx);
+                const half_t* vrow = VT + (int64_t)kvg * p.vt_gstride + (int64_t)(hc + d) * p.ldvt;
+                if (vec_v) {          // 8 consecutive keys of one grid row: one aligned 16-byte load
+                    const int ky = kc / kvWv, kx = kview * kvWv + (kc - ky * kvWv);
+                    rv[i] = *reinterpret_cast<const half8v*>(vrow + (int64_t)ky * p.kvW + kx);
+                } else {              // narrow views (< 8 columns or unaligned): gather key by key
+                    half8v g = z;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int key = kc + e;
+                        if (key < Nkv) {
+                            const int ky = key / kvWv, kx = kview * kvWv + (key - ky * kvWv);
+                            g[e] = vrow[(int64_t)ky * p.kvW + kx];
+                        }
+                    }
+                    rv[i] = g;
+                }
             } else rv[i] = z;
         }
     };
@@ -277,9 +291,10 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     if (p.views < 1 || p.views > 8 || p.kv_views < 1 || p.kv_views > 8) return PNC_EINVAL;
     if (p.W % p.views || p.kvW % p.kv_views) return PNC_EINVAL;
     const int kvWv = p.kvW / p.kv_views;
-    if (kvWv % 8 || p.kvW % 8) return PNC_EALIGN;                 // 8-key V^T chunks stay inside a row
-    if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.vt_gstride % 8 || p.ldo % 4) return PNC_EALIGN;
-    if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.vt) & 15) return PNC_EALIGN;
+    (void)kvWv;   // any view width: V^T chunks fall back to a per-key gather when a view row is not 8-aligned
+    if (p.ldq % 8 || p.ldk % 8 || p.ldo % 4) return PNC_EALIGN;
+    if (((uintptr_t)p.q | (uintptr_t)p.k) & 15) return PNC_EALIGN;
+    if ((uintptr_t)p.vt & 15) return PNC_EALIGN;
     if ((uintptr_t)p.o & 7) return PNC_EALIGN;
     if (p.q_per_kv < 1 || p.groups < 1 || p.heads < 1) return PNC_EINVAL;
     if (p.kv_valid < 1 || p.kv_valid > p.kvH * kvWv) return PNC_EINVAL;

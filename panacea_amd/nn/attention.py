@@ -147,8 +147,8 @@ class _AttentionBase(nn.Module, Packable):
         C, N = self.inner_dim, H * W
         M = F * N
         views = len(segs)
-        if W % views or (W // views) % 8:
-            raise ValueError(f"view width {W}/{views} must be a multiple of 8 latent columns")
+        if W % views:
+            raise ValueError(f"grid width {W} is not divisible into {views} views")
         qk = rt.empty((M, 2 * C), torch.float16)
         vt = rt.empty((F, C, N), torch.float16)
         rt.be.gemm(x16, pk["wqkv"], M=M, N=3 * C, K=self.query_dim, lda=self.query_dim, out16=qk, ldc16=2 * C,

@@ -1,0 +1,68 @@
+"""The drop-in boundary: (1) the C-ABI library loads on a CPU-only box and exports every symbol declared in
+include/panacea_hip.h; (2) with `panacea_amd.dropin.install()` the REFERENCE's own `instantiate_from_config`
+builds the mirror classes from the reference's YAML target strings (needs /root/reference: build container)."""
+import ctypes
+import sys
+
+import pytest
+import torch
+
+from panacea_amd import configs, hip
+
+
+def test_cabi_library_loads_and_exports_header_symbols():
+    lib = hip.load()
+    syms = hip.header_symbols()
+    assert len(syms) >= 15 and set(syms) == set(hip._SIGNATURES)
+    for s in syms:
+        assert getattr(lib, s) is not None
+    assert lib.pnc_version().decode().startswith("panacea_hip")
+    # struct layouts of the two parameter blocks (must match include/panacea_hip.h)
+    assert ctypes.sizeof(hip.GemmParams) == 200 and hip.GemmParams.t_gstride.offset == 176
+    assert ctypes.sizeof(hip.AttnParams) == 216 and hip.AttnParams.scale.offset == 208
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate before launching: bad arguments return PNC_E* codes even with no device."""
+    lib = hip.load()
+    p = hip.GemmParams()
+    assert lib.pnc_gemm_f16(ctypes.byref(p), None) == -1                  # PNC_EINVAL: null operands
+    assert lib.pnc_attn_temporal_f16(None, 0, None, 0, None, 0, None, 0, 1, 9, 1, 1, 0.125, None) == -1
+    assert lib.pnc_layernorm(None, 0, 0, 0, None, None, 1e-5, None, 0, None) == -1
+
+
+def test_product_refuses_to_run_without_gpu_tensors():
+    with pytest.raises(hip.PncError):
+        hip.cast_f16(torch.zeros(8), 8, torch.zeros(8, dtype=torch.float16))
+
+
+@pytest.mark.skipif(not __import__("pathlib").Path("/root/reference/sgm").exists(), reason="reference tree not present")
+def test_dropin_rebinds_reference_targets():
+    sys.path.insert(0, "/root/repo")
+    from oracle import ref_import
+    from panacea_amd import dropin, nn as mirror
+    for m in list(sys.modules):
+        if m.startswith("sgm"):
+            del sys.modules[m]
+    dropin._installed = False
+    dropin.install(lazy=True)                                   # arm first, import the reference afterwards
+    ns = ref_import.import_reference()
+    assert ns.cm.ControlledUNetModel3D is mirror.ControlledUNetModel3D
+    assert ns.cm.ControlNet3D is mirror.ControlNet3D
+    assert ns.wr.OpenAIWrapperControlLDM3D is mirror.OpenAIWrapperControlLDM3D
+    assert ns.cm._reference_ControlNet3D is not None            # the original stays reachable
+    kw = configs.get("tiny")
+    cfg = {"target": "sgm.modules.diffusionmodules.controlmodel.ControlledUNetModel3D",
+           "params": dict(kw, out_channels=4, controlnet_config={
+               "target": "sgm.modules.diffusionmodules.controlmodel.ControlNet3D",
+               "params": dict(kw, hint_channels=19, control_scales=1.0)})}
+    net = ns.util.instantiate_from_config(cfg)                  # the reference's own factory (sgm/util.py:168-185)
+    assert isinstance(net, mirror.ControlledUNetModel3D) and isinstance(net.controlnet, mirror.ControlNet3D)
+    wrapper = ns.util.get_obj_from_str(ns.wr.OPENAIUNETWRAPPERCONTROLLDM3D)(net, compile_model=False)
+    assert isinstance(wrapper, mirror.OpenAIWrapperControlLDM3D)
+    assert wrapper.diffusion_model.controlnet.input_hint_block[0].weight.dtype == torch.float32
+    for m in list(sys.modules):
+        if m.startswith("sgm") or m in ("omegaconf", "omegaconf.listconfig", "xformers", "xformers.ops"):
+            del sys.modules[m]
+    sys.meta_path[:] = [f for f in sys.meta_path if not isinstance(f, dropin._Finder)]
+    dropin._installed = False

@@ -174,7 +174,8 @@ def _qkv(G, N, C, seed):
 
 @pytest.mark.parametrize("G,H,W,heads,segs", [
     (2, 8, 96, 1, INTRA), (2, 8, 96, 2, CROSS), (1, 4, 48, 2, INTRA), (1, 4, 48, 1, CROSS),
-    (1, 32, 384, 1, CROSS), (2, 16, 16, 1, [[0]]), (1, 16, 192, 2, INTRA)])
+    (1, 32, 384, 1, CROSS), (2, 16, 16, 1, [[0]]), (1, 16, 192, 2, INTRA),
+    (2, 2, 24, 1, CROSS), (1, 1, 12, 2, INTRA), (2, 3, 36, 1, CROSS), (1, 5, 10, 1, [[0]])])
 def test_attn_views_self(G, H, W, heads, segs):
     C, N, views = heads * 64, H * W, len(segs)
     q, k, _, vt = _qkv(G, N, C, 5)

@@ -66,8 +66,8 @@ def test_hip_path_other_timesteps_and_frames_vs_oracle():
 
 
 def test_full_network_small_panorama_vs_oracle():
-    """Every tensor of the Panacea+ stage-2 network at its real width; latent 16x192 (the smallest panorama
-    whose L2 views are still 8 latent columns wide), B=1, T=2."""
+    """Every tensor of the Panacea+ stage-2 network at its real width; latent 16x192 (L2 views 4x8, L3 views
+    2x4 tokens: exercises the narrow-view gather of the attention kernel), B=1, T=2."""
     kw = configs.with_frames(configs.get("full"), 2)
     w, sd, _ = product_network("full", "cpu", kw=kw)
     inp = step_inputs("full", kw, "cpu", shape=(1, 2, 16, 192))

@@ -9,15 +9,19 @@
 //   PNC_A_CONV1D_T  temporal k=3 conv over the frames of one pixel
 //
 // Tile: BM x BN block, BK = 64, 256 threads = 4 waves, each wave owns MI x NI blocks of 32x32.
-// Operands are staged global -> registers -> LDS (16-B chunks, XOR-swizzled 128-B rows, two LDS
-// stages, one barrier per K tile: the loads of tile t+1 are in flight while tile t feeds the MFMAs).
-// Workgroup ids are remapped so that each XCD walks a contiguous range of tiles (W stays in its L2).
+// Operands go HBM -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass), 16-B
+// chunks in XOR-swizzled 128-B rows; the LDS image of the DMA is lane-linear, so the swizzle is applied to
+// the per-lane SOURCE address and again on the ds_read side (CDNA4 guide, rule 21).  Two LDS stages, one
+// barrier per K tile: the DMA of tile t+1 is in flight while tile t feeds the MFMAs.  Out-of-range chunks
+// (conv padding, K/M/N tails) are sourced from a 16-byte zero block.  The epilogue goes through LDS so that
+// every global access (bias, fp32 residual stream, fp32/fp16 stores) is a 16-byte (8-byte for fp16) vector
+// on 4 consecutive columns.  Workgroup ids are remapped so that each XCD walks a contiguous tile range.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BK = 64;          // fp16 elements per K tile = 128 B per LDS row
-constexpr int NTHREADS = 256;
 
 struct RowState {               // per staged A row, fixed over the K loop
     int64_t base;               // element offset of the row origin
@@ -45,14 +49,15 @@ __device__ __forceinline__ RowState make_row(const PncGemmParams& p, int m) {
     return s;
 }
 
-// 16-byte chunk of 8 consecutive k starting at kc (kc % 8 == 0) for row state s; zeros outside.
+__device__ __attribute__((aligned(16))) half_t g_zero_chunk[8];   // zero-initialised: source of padded chunks
+
+// global source of the 16-byte chunk (row state s, k index kc) or the zero block
 template <int AMODE>
-__device__ __forceinline__ half8v load_a_chunk(const PncGemmParams& p, const half_t* __restrict__ A,
-                                               const RowState& s, int kc) {
-    half8v z = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (!s.valid || kc >= p.K) return z;
+__device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, const half_t* __restrict__ A,
+                                                     const RowState& s, int kc) {
+    if (!s.valid || kc >= p.K) return g_zero_chunk;
     if (AMODE == PNC_A_PLAIN) {
-        return *reinterpret_cast<const half8v*>(A + s.base + kc);
+        return A + s.base + kc;
     } else if (AMODE == PNC_A_CONV3X3) {
         const int tap = kc / p.Cin, ci = kc - tap * p.Cin;
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -65,23 +70,29 @@ __device__ __forceinline__ half8v load_a_chunk(const PncGemmParams& p, const hal
             iy = s.y * p.stride + ky - 1; ix = s.x * p.stride + kx - 1;
             ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
         }
-        if (!ok) return z;
-        return *reinterpret_cast<const half8v*>(A + s.base + ((int64_t)iy * p.Win + ix) * p.Cin + ci);
+        return ok ? A + s.base + ((int64_t)iy * p.Win + ix) * p.Cin + ci : g_zero_chunk;
     } else {
         const int tap = kc / p.Cin, ci = kc - tap * p.Cin;
         const int tt = s.y + tap - 1;
-        if (tt < 0 || tt >= p.T) return z;
-        return *reinterpret_cast<const half8v*>(A + s.base + (int64_t)(tap - 1) * p.Npix * p.Cin + ci);
+        return (tt < 0 || tt >= p.T) ? g_zero_chunk : A + s.base + (int64_t)(tap - 1) * p.Npix * p.Cin + ci;
     }
 }
 
-template <int AMODE, int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const PncGemmParams p) {
-    constexpr int MI = BM / WGM / 32;       // 32-row blocks per wave
-    constexpr int NI = BN / WGN / 32;
-    constexpr int A_IT = BM * 8 / NTHREADS; // 16-B chunks per thread per tile
-    constexpr int B_IT = (BN * 8 + NTHREADS - 1) / NTHREADS;
+__device__ __forceinline__ void glds16(const half_t* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams p) {
+    constexpr int NW = WGM * WGN;                          // waves per workgroup
+    constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
+    constexpr int RPI = NW * 8;                            // rows staged per DMA iteration (8 rows per wave)
+    constexpr int A_IT = BM / RPI, B_IT = BN / RPI;
+    constexpr int LOADS = A_IT + B_IT;                     // DMA instructions per thread per K tile
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must be a multiple of the DMA row group");
+    constexpr int EPITCH = NI * 32 + 4;                    // floats per staged epilogue row
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const half_t* __restrict__ A = reinterpret_cast<const half_t*>(p.A);
@@ -96,37 +107,28 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const PncGemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
-    // staging assignment: chunk column c (0..7) and rows r0 + 32*i
-    const int sc = tid & 7, sr = tid >> 3;
+    // DMA assignment: lane l of wave w fills slot (l&7) of row i*32 + w*8 + (l>>3); the slot holds the
+    // chunk slot ^ ((row>>1)&7), and (row>>1)&7 does not depend on i
+    const int srow = wave * 8 + (lane >> 3);
+    const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
     RowState rows[A_IT];
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) rows[i] = make_row<AMODE>(p, m0 + sr + 32 * i);
-
-    half8v ra[A_IT], rb[B_IT];
-    auto load_tile = [&](int kt) {
-        const int kc = kt * BK + sc * 8;
+    for (int i = 0; i < A_IT; ++i) rows[i] = make_row<AMODE>(p, m0 + i * RPI + srow);
+    const half_t* wrow[B_IT];
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) ra[i] = load_a_chunk<AMODE>(p, A, rows[i], kc);
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int rr = sr + 32 * i;
-            const int n = n0 + rr;
-            half8v z = {0, 0, 0, 0, 0, 0, 0, 0};
-            rb[i] = (rr < BN && n < p.N && kc < p.K)
-                        ? *reinterpret_cast<const half8v*>(Wt + (int64_t)n * p.K + kc) : z;
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* sa = smem + stage * STAGE;
+    for (int i = 0; i < B_IT; ++i) {
+        const int n = n0 + i * RPI + srow;
+        wrow[i] = (n < p.N) ? Wt + (int64_t)n * p.K : nullptr;
+    }
+    auto issue_tile = [&](int kt, int stage) {
+        const int kc = kt * BK + schunk * 8;
+        char* sa = smem + stage * STAGE + wave * 1024;
         char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i)
-            *reinterpret_cast<half8v*>(sa + lds_off128(sr + 32 * i, sc)) = ra[i];
+        for (int i = 0; i < A_IT; ++i) glds16(a_chunk_ptr<AMODE>(p, A, rows[i], kc), sa + i * (RPI * 128));
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int rr = sr + 32 * i;
-            if (rr < BN) *reinterpret_cast<half8v*>(sb + lds_off128(rr, sc)) = rb[i];
-        }
+        for (int i = 0; i < B_IT; ++i)
+            glds16((wrow[i] && kc < p.K) ? wrow[i] + kc : g_zero_chunk, sb + i * (RPI * 128));
     };
 
     f32x16 acc[MI][NI];
@@ -138,95 +140,89 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const PncGemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int ntiles = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int frow = lane & 31, fk = lane >> 5;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const bool more = (kt + 1) < ntiles;
-        if (more) load_tile(kt + 1);
-        const char* sa = smem + (kt & 1) * STAGE;
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            half8v af[MI], bf[NI];
+        // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (register double buffer)
+        half8v af[2][MI], bf[2][NI];
+        auto frags = [&](int ks, int b) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                af[i] = *reinterpret_cast<const half8v*>(
+                af[b][i] = *reinterpret_cast<const half8v*>(
                     sa + lds_off128(wm * (MI * 32) + i * 32 + frow, ks * 2 + fk));
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                bf[j] = *reinterpret_cast<const half8v*>(
+                bf[b][j] = *reinterpret_cast<const half8v*>(
                     sb + lds_off128(wn * (NI * 32) + j * 32 + frow, ks * 2 + fk));
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            if (ks + 1 < BK / 16) frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile((kt + 1) & 1);
+    };
+
+    if (STAGES == 2) {
+        // one tile in flight: the plain barrier carries the vmcnt(0) that lands the DMA
+        issue_tile(0, 0);
         __syncthreads();
+        for (int kt = 0; kt < ntiles; ++kt) {
+            if (kt + 1 < ntiles) issue_tile(kt + 1, (kt + 1) & 1);
+            compute(kt & 1);
+            __syncthreads();
+        }
+    } else {
+        // ring of three stages, TWO tiles in flight.  Counted waits: after issuing tile kt+2 only its LOADS
+        // DMA instructions may stay outstanding, i.e. tile kt+1 has landed; the raw s_barrier (no compiler
+        // vmcnt(0)) then publishes every wave's part of it and retires all reads of the stage being recycled.
+        issue_tile(0, 0);
+        if (ntiles > 1) {
+            issue_tile(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        int st = 0;
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const bool ahead = (kt + 2) < ntiles;
+            if (ahead) issue_tile(kt + 2, st == 0 ? 2 : st - 1);      // (kt + 2) % 3
+            compute(st);
+            if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            st = (st == 2) ? 0 : st + 1;
+        }
     }
 
     // ------------------------------ epilogue ------------------------------
     const int mw = m0 + wm * (MI * 32), nw = n0 + wn * (NI * 32);
-    const int col = lane & 31;
     half_t* out16 = reinterpret_cast<half_t*>(p.out16);
     half_t* out16t = reinterpret_cast<half_t*>(p.out16t);
-    const bool transposed = (out16t != nullptr) && (n0 >= p.n_split);
 
-    if (p.geglu) {
-        if (NI >= 2) {
-            const int Nout = p.N >> 1;
+    if ((out16t != nullptr) && (n0 >= p.n_split)) {
+        // channel-major ("V^T") output: a lane already holds 4 consecutive rows of one column
+        const int col = lane & 31;
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int jp = 0; jp < NI / 2; ++jp) {
-                    const int nv = nw + (2 * jp) * 32 + col, ng = nv + 32;
-                    if (ng >= p.N) continue;
-                    const float bv = p.bias ? p.bias[nv] : 0.0f, bg = p.bias ? p.bias[ng] : 0.0f;
-                    const int on = (nw >> 1) + jp * 32 + col;
+            for (int j = 0; j < NI; ++j) {
+                const int n = nw + j * 32 + col;
+                if (n >= p.N) continue;
+                const float bn = p.bias ? p.bias[n] : 0.0f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = mw + i * 32 + mfma32_row(r, lane);
-                        if (m >= p.M) continue;
-                        const float v = (acc[i][2 * jp][r] + bv) * gelu_erf_f(acc[i][2 * jp + 1][r] + bg);
-                        if (out16) out16[(int64_t)m * p.ldc16 + on] = (half_t)v;
-                        if (p.out32) p.out32[(int64_t)m * p.ldc32 + on] = v;
-                    }
-                }
-            }
-            (void)Nout;
-        }
-        return;
-    }
-
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int mb = mw + i * 32 + 8 * r4 + 4 * (lane >> 5);
+                    float v[4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = nw + j * 32 + col;
-            const bool nok = n < p.N;
-            const float bn = (p.bias && nok) ? p.bias[n] : 0.0f;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                float v[4];
-                const int mb = mw + i * 32 + 8 * r4 + 4 * (lane >> 5);   // rows mb..mb+3
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = mb + q;
-                    float x = acc[i][j][r4 * 4 + q] + bn;
-                    if (nok && m < p.M) {
-                        if (p.rowbias) x += p.rowbias[(int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + n];
-                        if (p.act == PNC_ACT_SILU) x = silu_f(x);
-                        if (p.res1) x += p.res1[(int64_t)m * p.ldr1 + n];
-                        if (p.res2) x += p.res2[(int64_t)m * p.ldr2 + n];
-                    }
-                    v[q] = x;
-                }
-                if (!nok) continue;
-                if (transposed) {
+                    for (int q = 0; q < 4; ++q) v[q] = acc[i][j][r4 * 4 + q] + bn;
                     const int g = mb / p.t_rows, tr = mb - g * p.t_rows;
                     half_t* dst = out16t + (int64_t)g * p.t_gstride + (int64_t)(n - p.n_split) * p.ldt + tr;
                     const bool vec = (mb + 3 < p.M) && (tr + 3 < p.t_rows) && ((p.ldt & 3) == 0) &&
@@ -244,39 +240,136 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const PncGemmParams p) {
                             }
                         }
                     }
+                }
+            }
+        return;
+    }
+
+    // row-major outputs: stage each 32-row slab of the wave tile through LDS (wave-private region)
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EPITCH);
+    const bool geglu = p.geglu != 0;
+    constexpr int CPL_FULL = NI * 8;                        // lanes per row at 4 columns per lane
+    const int cpl = (geglu && NI >= 2) ? CPL_FULL / 2 : CPL_FULL;   // GEGLU: a lane pairs value and gate columns
+    const int cl = lane % cpl, rl = lane / cpl;
+    const int rpp = 64 / cpl;                               // rows per pass
+    const int Nout = geglu ? (p.N >> 1) : p.N;
+    const int ncol = geglu ? ((nw >> 1) + cl * 4) : (nw + cl * 4);     // first of this lane's 4 output columns
+    const bool lane_on = true;
+    const bool vec32 = ((p.ldc32 & 3) == 0) && (((uintptr_t)p.out32 & 15) == 0);
+    const bool vec16 = ((p.ldc16 & 3) == 0) && (((uintptr_t)p.out16 & 7) == 0);
+    const bool vecr1 = ((p.ldr1 & 3) == 0) && (((uintptr_t)p.res1 & 15) == 0);
+    const bool vecr2 = ((p.ldr2 & 3) == 0) && (((uintptr_t)p.res2 & 15) == 0);
+    const bool full4 = (ncol + 3) < Nout;
+    float bcol[4], bgate[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int nin = geglu ? (nw + cl * 4 + e) : (ncol + e);          // column in the N space of W / bias
+        bcol[e] = (p.bias && lane_on && nin < p.N) ? p.bias[nin] : 0.0f;
+        bgate[e] = (p.bias && geglu && lane_on && (nin + 32) < p.N) ? p.bias[nin + 32] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        __syncthreads();                    // previous slab fully consumed (and main-loop LDS reads done)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 32 / rpp; ++ps) {
+            const int row = ps * rpp + rl;
+            const int m = mw + i * 32 + row;
+            if (!lane_on || m >= p.M || ncol >= Nout) continue;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ep + row * EPITCH + cl * 4);
+            float v[4];
+            if (geglu) {
+                const f32x4 gt = *reinterpret_cast<const f32x4*>(ep + row * EPITCH + 32 + cl * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (a[e] + bcol[e]) * gelu_erf_f(gt[e] + bgate[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = a[e] + bcol[e];
+                if (p.rowbias) {
+                    const float* rb = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rb[e];
+                }
+                if (p.act == PNC_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                }
+                if (p.res1) {
+                    const float* rp = p.res1 + (int64_t)m * p.ldr1 + ncol;
+                    if (full4 && vecr1) { const f32x4 r = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rp[e];
+                    }
+                }
+                if (p.res2) {
+                    const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
+                    if (full4 && vecr2) { const f32x4 r = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rp[e];
+                    }
+                }
+            }
+            if (p.out32) {
+                float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
+                if (full4 && vec32) { f32x4 o = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(op) = o; }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (ncol + e < Nout) op[e] = v[e];
+                }
+            }
+            if (out16 && (geglu || ncol < p.n_split || out16t == nullptr)) {
+                half_t* op = out16 + (int64_t)m * p.ldc16 + ncol;
+                if (full4 && vec16) {
+                    half4v o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *reinterpret_cast<half4v*>(op) = o;
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int m = mb + q;
-                        if (m >= p.M) continue;
-                        if (p.out32) p.out32[(int64_t)m * p.ldc32 + n] = v[q];
-                        if (out16) out16[(int64_t)m * p.ldc16 + n] = (half_t)v[q];
-                    }
+                    for (int e = 0; e < 4; ++e) if (ncol + e < Nout) op[e] = (half_t)v[e];
                 }
             }
         }
     }
 }
 
-template <int AMODE, int BM, int BN, int WGM, int WGN>
+template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES>
 int launch(const PncGemmParams& p, hipStream_t st) {
-    constexpr int lds = 2 * (BM + BN) * 128;
+    constexpr int lds = STAGES * (BM + BN) * 128;
+    constexpr int threads = 64 * WGM * WGN;
+    static_assert(lds >= WGM * WGN * 32 * ((BN / WGN) + 4) * 4, "epilogue staging must fit the operand ring");
     static bool attr_done = false;   // per-instantiation; idempotent
-    auto kern = gemm_kernel<AMODE, BM, BN, WGM, WGN>;
+    auto kern = gemm_glds_kernel<AMODE, BM, BN, WGM, WGN, STAGES>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds, st, p);
     return pnc_launch_status();
 }
 
+// Tile choice: 256x128 / 8 waves / 3-stage ring (two K tiles = 96 KB in flight per CU, 25 % fewer operand
+// bytes per flop) whenever it still yields >= 2 workgroups per CU; 128x128 / 4 waves / 2 stages for small
+// grids; 128x32 for the few narrow-N convs (hint stem, output head).
 template <int AMODE>
 int dispatch(const PncGemmParams& p, hipStream_t st) {
-    if (p.N <= 32 && !p.geglu) return launch<AMODE, 128, 32, 4, 1>(p, st);
-    return launch<AMODE, 128, 128, 2, 2>(p, st);
+    static const int force = getenv("PNC_GEMM_TILE") ? atoi(getenv("PNC_GEMM_TILE")) : 0;   // A/B runs: 1 = 128x128, 2 = 256x128
+    if (p.N <= 32 && !p.geglu) return launch<AMODE, 128, 32, 4, 1, 2>(p, st);
+    const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+    const bool big = force ? (force == 2) : (big_tiles >= 512);
+    if (big) return launch<AMODE, 256, 128, 4, 2, 3>(p, st);
+    return launch<AMODE, 128, 128, 2, 2, 2>(p, st);
 }
 
 }  // namespace

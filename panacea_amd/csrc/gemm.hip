@@ -83,7 +83,7 @@ __device__ __forceinline__ void glds16(const half_t* src, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES>
+template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams p) {
     constexpr int NW = WGM * WGN;                          // waves per workgroup
     constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     constexpr int LOADS = A_IT + B_IT;                     // DMA instructions per thread per K tile
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must be a multiple of the DMA row group");
-    constexpr int EPITCH = NI * 32 + 4;                    // floats per staged epilogue row
+    constexpr int ENI = NI < 2 ? NI : 2;                   // column blocks staged per epilogue pass
+    constexpr int EPITCH = ENI * 32 + 4;                   // floats per staged epilogue row
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const half_t* __restrict__ A = reinterpret_cast<const half_t*>(p.A);
@@ -144,27 +145,47 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     auto compute = [&](int stage) {
         const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
-        // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (register double buffer)
-        half8v af[2][MI], bf[2][NI];
-        auto frags = [&](int ks, int b) {
+        if (PIPE) {
+            // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (register double buffer)
+            half8v af[2][MI], bf[2][NI];
+            auto frags = [&](int ks, int b) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                af[b][i] = *reinterpret_cast<const half8v*>(
-                    sa + lds_off128(wm * (MI * 32) + i * 32 + frow, ks * 2 + fk));
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                bf[b][j] = *reinterpret_cast<const half8v*>(
-                    sb + lds_off128(wn * (NI * 32) + j * 32 + frow, ks * 2 + fk));
-        };
-        frags(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            if (ks + 1 < BK / 16) frags(ks + 1, (ks + 1) & 1);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
+                    af[b][i] = *reinterpret_cast<const half8v*>(
+                        sa + lds_off128(wm * (MI * 32) + i * 32 + frow, ks * 2 + fk));
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+                    bf[b][j] = *reinterpret_cast<const half8v*>(
+                        sb + lds_off128(wn * (NI * 32) + j * 32 + frow, ks * 2 + fk));
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                if (ks + 1 < BK / 16) frags(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                half8v af[MI], bf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[i] = *reinterpret_cast<const half8v*>(
+                        sa + lds_off128(wm * (MI * 32) + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    bf[j] = *reinterpret_cast<const half8v*>(
+                        sb + lds_off128(wn * (NI * 32) + j * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -245,110 +266,119 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         return;
     }
 
-    // row-major outputs: stage each 32-row slab of the wave tile through LDS (wave-private region)
+    // row-major outputs: each 32-row x (ENI*32)-column slab of the wave tile goes through a wave-private LDS
+    // region (LDS operations of one wave execute in order, so only lgkmcnt waits separate the phases)
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EPITCH);
     const bool geglu = p.geglu != 0;
-    constexpr int CPL_FULL = NI * 8;                        // lanes per row at 4 columns per lane
-    const int cpl = (geglu && NI >= 2) ? CPL_FULL / 2 : CPL_FULL;   // GEGLU: a lane pairs value and gate columns
+    constexpr int CPL_FULL = ENI * 8;                       // lanes per staged row at 4 columns per lane
+    const int cpl = (geglu && ENI >= 2) ? CPL_FULL / 2 : CPL_FULL;   // GEGLU: a lane pairs value and gate columns
     const int cl = lane % cpl, rl = lane / cpl;
     const int rpp = 64 / cpl;                               // rows per pass
     const int Nout = geglu ? (p.N >> 1) : p.N;
-    const int ncol = geglu ? ((nw >> 1) + cl * 4) : (nw + cl * 4);     // first of this lane's 4 output columns
-    const bool lane_on = true;
     const bool vec32 = ((p.ldc32 & 3) == 0) && (((uintptr_t)p.out32 & 15) == 0);
     const bool vec16 = ((p.ldc16 & 3) == 0) && (((uintptr_t)p.out16 & 7) == 0);
     const bool vecr1 = ((p.ldr1 & 3) == 0) && (((uintptr_t)p.res1 & 15) == 0);
     const bool vecr2 = ((p.ldr2 & 3) == 0) && (((uintptr_t)p.res2 & 15) == 0);
-    const bool full4 = (ncol + 3) < Nout;
-    float bcol[4], bgate[4];
+    __syncthreads();                        // every wave is done reading operand tiles from LDS
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int nin = geglu ? (nw + cl * 4 + e) : (ncol + e);          // column in the N space of W / bias
-        bcol[e] = (p.bias && lane_on && nin < p.N) ? p.bias[nin] : 0.0f;
-        bgate[e] = (p.bias && geglu && lane_on && (nin + 32) < p.N) ? p.bias[nin + 32] : 0.0f;
-    }
+    for (int jc = 0; jc < NI; jc += ENI) {
+        const int cw = (NI - jc) < ENI ? (NI - jc) : ENI;               // column blocks in this pass (1 or 2)
+        const int nin0 = nw + jc * 32 + cl * 4;                         // first input column (N space of W / bias)
+        const int ncol = geglu ? ((nw + jc * 32) >> 1) + cl * 4 : nin0; // first output column of this lane
+        const bool lane_on = (cl * 4) < (geglu ? 32 : cw * 32);
+        const bool full4 = (ncol + 3) < Nout;
+        float bcol[4], bgate[4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        __syncthreads();                    // previous slab fully consumed (and main-loop LDS reads done)
+        for (int e = 0; e < 4; ++e) {
+            const int nin = nin0 + e;
+            bcol[e] = (p.bias && lane_on && nin < p.N) ? p.bias[nin] : 0.0f;
+            bgate[e] = (p.bias && geglu && lane_on && (nin + 32) < p.N) ? p.bias[nin + 32] : 0.0f;
+        }
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int i = 0; i < MI; ++i) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // previous slab fully read
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][j][r];
-        __syncthreads();
+            for (int j = 0; j < ENI; ++j)
+                if (j < cw) {
 #pragma unroll
-        for (int ps = 0; ps < 32 / rpp; ++ps) {
-            const int row = ps * rpp + rl;
-            const int m = mw + i * 32 + row;
-            if (!lane_on || m >= p.M || ncol >= Nout) continue;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ep + row * EPITCH + cl * 4);
-            float v[4];
-            if (geglu) {
-                const f32x4 gt = *reinterpret_cast<const f32x4*>(ep + row * EPITCH + 32 + cl * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (a[e] + bcol[e]) * gelu_erf_f(gt[e] + bgate[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = a[e] + bcol[e];
-                if (p.rowbias) {
-                    const float* rb = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rb[e];
+                    for (int r = 0; r < 16; ++r)
+                        ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][jc + j][r];
                 }
-                if (p.act == PNC_ACT_SILU) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int ps = 0; ps < 32 / rpp; ++ps) {
+                const int row = ps * rpp + rl;
+                const int m = mw + i * 32 + row;
+                if (!lane_on || m >= p.M || ncol >= Nout) continue;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ep + row * EPITCH + cl * 4);
+                float v[4];
+                if (geglu) {
+                    const f32x4 gt = *reinterpret_cast<const f32x4*>(ep + row * EPITCH + 32 + cl * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                }
-                if (p.res1) {
-                    const float* rp = p.res1 + (int64_t)m * p.ldr1 + ncol;
-                    if (full4 && vecr1) { const f32x4 r = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += r[e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rp[e];
-                    }
-                }
-                if (p.res2) {
-                    const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
-                    if (full4 && vecr2) { const f32x4 r = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += r[e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rp[e];
-                    }
-                }
-            }
-            if (p.out32) {
-                float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
-                if (full4 && vec32) { f32x4 o = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(op) = o; }
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (ncol + e < Nout) op[e] = v[e];
-                }
-            }
-            if (out16 && (geglu || ncol < p.n_split || out16t == nullptr)) {
-                half_t* op = out16 + (int64_t)m * p.ldc16 + ncol;
-                if (full4 && vec16) {
-                    half4v o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    *reinterpret_cast<half4v*>(op) = o;
+                    for (int e = 0; e < 4; ++e) v[e] = (a[e] + bcol[e]) * gelu_erf_f(gt[e] + bgate[e]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (ncol + e < Nout) op[e] = (half_t)v[e];
+                    for (int e = 0; e < 4; ++e) v[e] = a[e] + bcol[e];
+                    if (p.rowbias) {
+                        const float* rb = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rb[e];
+                    }
+                    if (p.act == PNC_ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+                    if (p.res1) {
+                        const float* rp = p.res1 + (int64_t)m * p.ldr1 + ncol;
+                        if (full4 && vecr1) { const f32x4 r = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += r[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rp[e];
+                        }
+                    }
+                    if (p.res2) {
+                        const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
+                        if (full4 && vecr2) { const f32x4 r = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += r[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rp[e];
+                        }
+                    }
+                }
+                if (p.out32) {
+                    float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
+                    if (full4 && vec32) { f32x4 o = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(op) = o; }
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (ncol + e < Nout) op[e] = v[e];
+                    }
+                }
+                if (out16) {
+                    half_t* op = out16 + (int64_t)m * p.ldc16 + ncol;
+                    if (full4 && vec16) {
+                        half4v o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        *reinterpret_cast<half4v*>(op) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (ncol + e < Nout) op[e] = (half_t)v[e];
+                    }
                 }
             }
         }
     }
 }
 
-template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES>
+template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE>
 int launch(const PncGemmParams& p, hipStream_t st) {
     constexpr int lds = STAGES * (BM + BN) * 128;
     constexpr int threads = 64 * WGM * WGN;
-    static_assert(lds >= WGM * WGN * 32 * ((BN / WGN) + 4) * 4, "epilogue staging must fit the operand ring");
+    static_assert(lds <= 160 * 1024, "LDS budget of one CU");
+    static_assert(lds >= WGM * WGN * 32 * 68 * 4, "epilogue staging must fit the operand ring");
     static bool attr_done = false;   // per-instantiation; idempotent
-    auto kern = gemm_glds_kernel<AMODE, BM, BN, WGM, WGN, STAGES>;
+    auto kern = gemm_glds_kernel<AMODE, BM, BN, WGM, WGN, STAGES, PIPE>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -359,17 +389,25 @@ int launch(const PncGemmParams& p, hipStream_t st) {
     return pnc_launch_status();
 }
 
-// Tile choice: 256x128 / 8 waves / 3-stage ring (two K tiles = 96 KB in flight per CU, 25 % fewer operand
-// bytes per flop) whenever it still yields >= 2 workgroups per CU; 128x128 / 4 waves / 2 stages for small
-// grids; 128x32 for the few narrow-N convs (hint stem, output head).
+// Tile choice.  Every channel width of the network is a multiple of 320, so the preferred tile is 256x320
+// (8 waves as 4x2, wave tile 64x160, 2 stages = 144 KB): no column waste at N = 320, A is read once per 320
+// output columns, 9 DMA instructions per 40 MFMAs (vs 6 per 16 for 256x128).  GEGLU pairs 32-column value /
+// gate blocks inside one wave and therefore keeps 256x128 (wave tile 64x64).  Small grids fall back to
+// 128x128 so that every CU still gets work; 128x32 serves the narrow-N convs (hint stem, output head).
 template <int AMODE>
 int dispatch(const PncGemmParams& p, hipStream_t st) {
-    static const int force = getenv("PNC_GEMM_TILE") ? atoi(getenv("PNC_GEMM_TILE")) : 0;   // A/B runs: 1 = 128x128, 2 = 256x128
-    if (p.N <= 32 && !p.geglu) return launch<AMODE, 128, 32, 4, 1, 2>(p, st);
-    const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
-    const bool big = force ? (force == 2) : (big_tiles >= 512);
-    if (big) return launch<AMODE, 256, 128, 4, 2, 3>(p, st);
-    return launch<AMODE, 128, 128, 2, 2, 2>(p, st);
+    static const int force = getenv("PNC_GEMM_TILE") ? atoi(getenv("PNC_GEMM_TILE")) : 0;   // A/B runs
+    if (p.N <= 32 && !p.geglu) return launch<AMODE, 128, 32, 4, 1, 2, true>(p, st);
+    const long mt256 = (p.M + 255) / 256;
+    const bool w320_ok = !p.geglu && (p.N % 320 == 0) && (!p.out16t || p.n_split % 320 == 0);
+    const bool w256_ok = (p.N % 256 == 0) && (!p.out16t || p.n_split % 256 == 0);
+    const bool use320 = force ? (force == 3 && w320_ok) : (w320_ok && mt256 * (p.N / 320) >= 512);
+    if (use320) return launch<AMODE, 256, 320, 4, 2, 2, false>(p, st);
+    const bool use256 = force ? (force == 4 && w256_ok) : (w256_ok && mt256 * (p.N / 256) >= 512);
+    if (use256) return launch<AMODE, 256, 256, 4, 2, 2, true>(p, st);
+    const bool big = force ? (force == 2) : (mt256 * ((p.N + 127) / 128) >= 512);
+    if (big) return launch<AMODE, 256, 128, 4, 2, 3, true>(p, st);
+    return launch<AMODE, 128, 128, 2, 2, 2, true>(p, st);
 }
 
 }  // namespace

@@ -47,7 +47,8 @@ def _run_both(fn_name, make_outs, kwargs_fn):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (128, 256, 128), (300, 320, 320), (130, 96, 72),
-                                   (1000, 32, 64), (77, 16, 216), (16, 1280, 320), (3072, 640, 1920)])
+                                   (1000, 32, 64), (77, 16, 216), (16, 1280, 320), (3072, 640, 1920),
+                                   (700, 960, 320), (513, 320, 1280)])
 def test_gemm_plain_bias_out32_out16(M, N, K):
     a = rnd(M, K, dtype=torch.float16)
     w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
@@ -98,7 +99,7 @@ def test_gemm_act_silu():
     check("silu", h["o"], e["o"], 4e-3)
 
 
-@pytest.mark.parametrize("M,C", [(256, 64), (384, 320)])
+@pytest.mark.parametrize("M,C", [(256, 64), (384, 320), (300, 128)])
 def test_gemm_geglu(M, C):
     N, K = 8 * C, C
     a, w = rnd(M, K, dtype=torch.float16), rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
@@ -108,7 +109,7 @@ def test_gemm_geglu(M, C):
     check("geglu", h["o"], e["o"], 4e-3)
 
 
-@pytest.mark.parametrize("G,t_rows,C", [(2, 128, 64), (3, 96, 128), (2, 80, 64)])
+@pytest.mark.parametrize("G,t_rows,C", [(2, 128, 64), (3, 96, 128), (2, 80, 64), (2, 192, 320)])
 def test_gemm_split_transposed_output(G, t_rows, C):
     # q|k row-major for n < 2C, V^T channel-major for n >= 2C  (QKV projection epilogue)
     M, N, K = G * t_rows, 3 * C, C

@@ -83,6 +83,139 @@ __device__ __forceinline__ void glds16(const half_t* src, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Row-major epilogue of one wave tile (MI x NI blocks of 32x32).  Each 32-row x 64-column slab goes through a
+// wave-private LDS region so that a lane ends up with 8 CONSECUTIVE columns of one row: 16-byte fp16 stores, two
+// 16-byte fp32 loads/stores.  All LDS reads of a slab are issued before the first use (the loop is instruction- and
+// latency-bound, not bandwidth-bound: at K = 320 it is half of a tile's lifetime).  LDS operations of one wave
+// execute in order, so only lgkmcnt waits separate the phases — no workgroup barrier.
+template <int MI, int NI, bool GEGLU>
+__device__ __forceinline__ void epilogue_rowmajor(const PncGemmParams& p, f32x16 (&acc)[MI][NI], float* ep, int lane,
+                                                  int mw, int nw, bool ab_nostage, bool ab_nostore) {
+    constexpr int ENI = NI < 2 ? NI : 2;
+    constexpr int EPITCH = ENI * 32 + 4;
+    constexpr int OUTC = GEGLU ? 32 : ENI * 32;             // output columns of one staged chunk
+    constexpr int CPL = OUTC / 8;                           // lanes per row (8 columns per lane)
+    constexpr int RPP = 64 / CPL;                           // rows per pass
+    constexpr int NP = 32 / RPP;                            // passes per 32-row slab
+    const int cl = lane % CPL, rl = lane / CPL;
+    const int Nout = GEGLU ? (p.N >> 1) : p.N;
+    half_t* out16 = reinterpret_cast<half_t*>(p.out16);
+    const bool v32 = ((p.ldc32 & 3) == 0) && (((uintptr_t)p.out32 & 15) == 0);
+    const bool v16 = ((p.ldc16 & 7) == 0) && (((uintptr_t)p.out16 & 15) == 0);
+    const bool vr1 = ((p.ldr1 & 3) == 0) && (((uintptr_t)p.res1 & 15) == 0);
+    const bool vr2 = ((p.ldr2 & 3) == 0) && (((uintptr_t)p.res2 & 15) == 0);
+    const int act = p.act & 0xff;
+#pragma unroll
+    for (int jc = 0; jc < NI; jc += ENI) {
+        const int cw = (NI - jc) < ENI ? (NI - jc) : ENI;               // column blocks in this chunk (1 or 2)
+        const int nin0 = nw + jc * 32 + cl * 8;                         // first input column (N space of W / bias)
+        const int ncol = GEGLU ? ((nw + jc * 32) >> 1) + cl * 8 : nin0; // first output column of this lane
+        const bool lane_on = (cl * 8) < (GEGLU ? 32 : cw * 32) && ncol < Nout;
+        const bool full8 = (ncol + 7) < Nout;
+        float bcol[8], bgate[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int nin = nin0 + e;
+            bcol[e] = (p.bias && lane_on && nin < p.N) ? p.bias[nin] : 0.0f;
+            bgate[e] = (GEGLU && p.bias && lane_on && (nin + 32) < p.N) ? p.bias[nin + 32] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // previous slab fully read
+#pragma unroll
+            for (int j = 0; j < ENI; ++j)
+                if (j < cw && !ab_nostage) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][jc + j][r];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f32x4 a0[NP], a1[NP], g0[NP], g1[NP];
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const float* src = ep + (ps * RPP + rl) * EPITCH + cl * 8;
+                a0[ps] = *reinterpret_cast<const f32x4*>(src);
+                a1[ps] = *reinterpret_cast<const f32x4*>(src + 4);
+                if (GEGLU) {
+                    g0[ps] = *reinterpret_cast<const f32x4*>(src + 32);
+                    g1[ps] = *reinterpret_cast<const f32x4*>(src + 36);
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const int m = mw + i * 32 + ps * RPP + rl;
+                if (!lane_on || m >= p.M) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = a0[ps][e] + bcol[e]; v[e + 4] = a1[ps][e] + bcol[e + 4]; }
+                if (GEGLU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] *= gelu_erf_f(g0[ps][e] + bgate[e]);
+                        v[e + 4] *= gelu_erf_f(g1[ps][e] + bgate[e + 4]);
+                    }
+                } else {
+                    if (p.rowbias) {
+                        const float* rb = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) if (ncol + e < Nout) v[e] += rb[e];
+                    }
+                    if (act == PNC_ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                    }
+                    if (p.res1) {
+                        const float* rp = p.res1 + (int64_t)m * p.ldr1 + ncol;
+                        if (full8 && vr1) {
+                            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) if (ncol + e < Nout) v[e] += rp[e];
+                        }
+                    }
+                    if (p.res2) {
+                        const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
+                        if (full8 && vr2) {
+                            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) if (ncol + e < Nout) v[e] += rp[e];
+                        }
+                    }
+                }
+                if (ab_nostore) { if (v[0] == 123.456f) p.out32[0] = v[1] + v[5]; continue; }
+                if (p.out32) {
+                    float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
+                    if (full8 && v32) {
+                        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                        *reinterpret_cast<f32x4*>(op) = o0;
+                        *reinterpret_cast<f32x4*>(op + 4) = o1;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) if (ncol + e < Nout) op[e] = v[e];
+                    }
+                }
+                if (out16) {
+                    half_t* op = out16 + (int64_t)m * p.ldc16 + ncol;
+                    if (full8 && v16) {
+                        half8v o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+                        *reinterpret_cast<half8v*>(op) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) if (ncol + e < Nout) op[e] = (half_t)v[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams p) {
     constexpr int NW = WGM * WGN;                          // waves per workgroup
@@ -142,6 +275,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
 
     const int ntiles = (p.K + BK - 1) / BK;
     const int frow = lane & 31, fk = lane >> 5;
+    // timing-experiment switches (tools/kbench.py PNC_ABLATE): results are garbage when any is set
+    const bool ab_nodma = (p.act & 0x100) != 0, ab_nomfma = (p.act & 0x200) != 0, ab_noepi = (p.act & 0x400) != 0;
+    const bool ab_nostage = (p.act & 0x800) != 0, ab_nostore = (p.act & 0x1000) != 0;
     auto compute = [&](int stage) {
         const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
@@ -194,8 +330,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         issue_tile(0, 0);
         __syncthreads();
         for (int kt = 0; kt < ntiles; ++kt) {
-            if (kt + 1 < ntiles) issue_tile(kt + 1, (kt + 1) & 1);
-            compute(kt & 1);
+            if (kt + 1 < ntiles && !ab_nodma) issue_tile(kt + 1, (kt + 1) & 1);
+            if (!ab_nomfma) compute(kt & 1);
             __syncthreads();
         }
     } else {
@@ -212,9 +348,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         __builtin_amdgcn_s_barrier();
         int st = 0;
         for (int kt = 0; kt < ntiles; ++kt) {
-            const bool ahead = (kt + 2) < ntiles;
+            const bool ahead = (kt + 2) < ntiles && !ab_nodma;
             if (ahead) issue_tile(kt + 2, st == 0 ? 2 : st - 1);      // (kt + 2) % 3
-            compute(st);
+            if (!ab_nomfma) compute(st);
             if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -224,6 +360,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     }
 
     // ------------------------------ epilogue ------------------------------
+    if (ab_noepi) { if (acc[0][0][0] == 123.456f) p.out32[0] = 1.0f; return; }
     const int mw = m0 + wm * (MI * 32), nw = n0 + wn * (NI * 32);
     half_t* out16 = reinterpret_cast<half_t*>(p.out16);
     half_t* out16t = reinterpret_cast<half_t*>(p.out16t);
@@ -266,108 +403,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         return;
     }
 
-    // row-major outputs: each 32-row x (ENI*32)-column slab of the wave tile goes through a wave-private LDS
-    // region (LDS operations of one wave execute in order, so only lgkmcnt waits separate the phases)
+    // row-major outputs
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EPITCH);
-    const bool geglu = p.geglu != 0;
-    constexpr int CPL_FULL = ENI * 8;                       // lanes per staged row at 4 columns per lane
-    const int cpl = (geglu && ENI >= 2) ? CPL_FULL / 2 : CPL_FULL;   // GEGLU: a lane pairs value and gate columns
-    const int cl = lane % cpl, rl = lane / cpl;
-    const int rpp = 64 / cpl;                               // rows per pass
-    const int Nout = geglu ? (p.N >> 1) : p.N;
-    const bool vec32 = ((p.ldc32 & 3) == 0) && (((uintptr_t)p.out32 & 15) == 0);
-    const bool vec16 = ((p.ldc16 & 3) == 0) && (((uintptr_t)p.out16 & 7) == 0);
-    const bool vecr1 = ((p.ldr1 & 3) == 0) && (((uintptr_t)p.res1 & 15) == 0);
-    const bool vecr2 = ((p.ldr2 & 3) == 0) && (((uintptr_t)p.res2 & 15) == 0);
     __syncthreads();                        // every wave is done reading operand tiles from LDS
-#pragma unroll
-    for (int jc = 0; jc < NI; jc += ENI) {
-        const int cw = (NI - jc) < ENI ? (NI - jc) : ENI;               // column blocks in this pass (1 or 2)
-        const int nin0 = nw + jc * 32 + cl * 4;                         // first input column (N space of W / bias)
-        const int ncol = geglu ? ((nw + jc * 32) >> 1) + cl * 4 : nin0; // first output column of this lane
-        const bool lane_on = (cl * 4) < (geglu ? 32 : cw * 32);
-        const bool full4 = (ncol + 3) < Nout;
-        float bcol[4], bgate[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int nin = nin0 + e;
-            bcol[e] = (p.bias && lane_on && nin < p.N) ? p.bias[nin] : 0.0f;
-            bgate[e] = (p.bias && geglu && lane_on && (nin + 32) < p.N) ? p.bias[nin + 32] : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // previous slab fully read
-#pragma unroll
-            for (int j = 0; j < ENI; ++j)
-                if (j < cw) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][jc + j][r];
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            for (int ps = 0; ps < 32 / rpp; ++ps) {
-                const int row = ps * rpp + rl;
-                const int m = mw + i * 32 + row;
-                if (!lane_on || m >= p.M || ncol >= Nout) continue;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(ep + row * EPITCH + cl * 4);
-                float v[4];
-                if (geglu) {
-                    const f32x4 gt = *reinterpret_cast<const f32x4*>(ep + row * EPITCH + 32 + cl * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (a[e] + bcol[e]) * gelu_erf_f(gt[e] + bgate[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = a[e] + bcol[e];
-                    if (p.rowbias) {
-                        const float* rb = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rb[e];
-                    }
-                    if (p.act == PNC_ACT_SILU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                    }
-                    if (p.res1) {
-                        const float* rp = p.res1 + (int64_t)m * p.ldr1 + ncol;
-                        if (full4 && vecr1) { const f32x4 r = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += r[e];
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rp[e];
-                        }
-                    }
-                    if (p.res2) {
-                        const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
-                        if (full4 && vecr2) { const f32x4 r = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += r[e];
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (ncol + e < Nout) v[e] += rp[e];
-                        }
-                    }
-                }
-                if (p.out32) {
-                    float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
-                    if (full4 && vec32) { f32x4 o = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(op) = o; }
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (ncol + e < Nout) op[e] = v[e];
-                    }
-                }
-                if (out16) {
-                    half_t* op = out16 + (int64_t)m * p.ldc16 + ncol;
-                    if (full4 && vec16) {
-                        half4v o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *reinterpret_cast<half4v*>(op) = o;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (ncol + e < Nout) op[e] = (half_t)v[e];
-                    }
-                }
-            }
-        }
+    if (p.geglu) {
+        if constexpr (NI >= 2) epilogue_rowmajor<MI, NI, true>(p, acc, ep, lane, mw, nw, ab_nostage, ab_nostore);
+    } else {
+        epilogue_rowmajor<MI, NI, false>(p, acc, ep, lane, mw, nw, ab_nostage, ab_nostore);
     }
 }
 
@@ -401,7 +443,8 @@ int dispatch(const PncGemmParams& p, hipStream_t st) {
     const long mt256 = (p.M + 255) / 256;
     const bool w320_ok = !p.geglu && (p.N % 320 == 0) && (!p.out16t || p.n_split % 320 == 0);
     const bool w256_ok = (p.N % 256 == 0) && (!p.out16t || p.n_split % 256 == 0);
-    const bool use320 = force ? (force == 3 && w320_ok) : (w320_ok && mt256 * (p.N / 320) >= 512);
+    const long t320 = mt256 * (p.N / 320);
+    const bool use320 = force ? (force == 3 && w320_ok) : (w320_ok && (t320 >= 512 || (t320 >= 384 && p.K >= 2048)));
     if (use320) return launch<AMODE, 256, 320, 4, 2, 2, false>(p, st);
     const bool use256 = force ? (force == 4 && w256_ok) : (w256_ok && mt256 * (p.N / 256) >= 512);
     if (use256) return launch<AMODE, 256, 256, 4, 2, 2, true>(p, st);

@@ -16,17 +16,19 @@ F = 16
 LEVELS = [(320, 32, 384), (640, 16, 192), (1280, 8, 96), (1280, 4, 48)]
 
 
-def timeit(fn, iters=10, warm=3):
+def timeit(fn, iters=24, warm=4):
+    """median of per-launch HIP-event times (single-launch numbers on this box scatter by +-15 %)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record()
         fn()
-    e.record()
+        e.record()
     torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters * 1e-3
+    ts = sorted(s.elapsed_time(e) for s, e in evs)
+    return ts[len(ts) // 2] * 1e-3
 
 
 def h16(*shape):
@@ -42,6 +44,10 @@ def report(name, t, flops=None, bytes_=None):
     print(s, flush=True)
 
 
+import os
+ABL = int(os.environ.get("PNC_ABLATE", "0"))
+
+
 def bench_gemm(flt):
     for li, (C, H, W) in enumerate(LEVELS):
         M = F * H * W
@@ -54,13 +60,13 @@ def bench_gemm(flt):
             bias = torch.zeros(N, device=DEV)
             if kw.get("geglu"):
                 o = torch.empty(M, N // 2, device=DEV, dtype=torch.float16)
-                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, geglu=True, out16=o, ldc16=N // 2)
+                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, geglu=True, out16=o, ldc16=N // 2, act=ABL)
             elif kw.get("res"):
                 o = torch.zeros(M, N, device=DEV)
-                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, res1=o, ldr1=N, out32=o, ldc32=N)
+                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, res1=o, ldr1=N, out32=o, ldc32=N, act=ABL)
             else:
                 o = torch.empty(M, N, device=DEV, dtype=torch.float16)
-                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, out16=o, ldc16=N)
+                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, out16=o, ldc16=N, act=ABL)
             report(tag, timeit(fn), flops=2.0 * M * N * K)
             del a, w, o
         # conv3x3 C->C and temporal conv1d

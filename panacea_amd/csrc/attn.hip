@@ -146,37 +146,44 @@ __global__ __launch_bounds__(256) void attn_views_kernel(const PncAttnParams p) 
                 s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ds], s[kh], 0, 0, 0);
             }
         }
-        // lane holds keys key0 + kh*32 + grp*16 + r  (r = 0..15)
+        // lane holds keys key0 + kh*32 + grp*16 + r  (r = 0..15).  Scores stay raw; the softmax scale is folded
+        // into the exp2 argument (one fma per score).  Masking only runs on the tile that crosses kv_valid.
+        if (key0 + KT > p.kv_valid) {
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + kh * 32 + grp * 16 + r >= p.kv_valid) s[kh][r] = -1e30f;
+        }
         float tmax = -1e30f;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + kh * 32 + grp * 16 + r;
-                const float v = (key < p.kv_valid) ? s[kh][r] * sc : -1e30f;
-                s[kh][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(mrun, tmax);
-        const float alpha = exp2f(mrun - mnew);
-        mrun = mnew;
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kh][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sc;              // scaled (exp2) domain; masked -> -inf-ish
+        // running max: rescale the accumulators only when some query of the wave actually raised its max
+        if (__builtin_amdgcn_ballot_w64(tmax > mrun) != 0) {
+            const float mnew = fmaxf(mrun, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+            mrun = mnew;
+            lrun *= alpha;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dh][r] *= alpha;
+        }
         float psum = 0.0f;
         half8v pf[2][2];
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // masked entries: (-1e30 - mnew) -> exp2 -> 0 (mnew is finite once any key is valid)
-                const float pv = exp2f(s[kh][r] - mnew);
+                // masked entries: fma(-1e30, sc, -mrun) -> exp2 -> 0 (mrun is finite once any key is valid)
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kh][r], sc, -mrun));
                 psum += pv;
                 pf[kh][r >> 3][r & 7] = (half_t)pv;
             }
-        lrun = lrun * alpha + psum;
-#pragma unroll
-        for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dh][r] *= alpha;
+        lrun += psum;
 
         // ---- O^T += V^T P^T ----
 #pragma unroll

@@ -6,72 +6,65 @@
 namespace {
 
 constexpr int GROUPS = 32;
-constexpr int MAXV = 3;        // float4 channel vectors per thread: C <= 4*256*3 = 3072
 
-// thread t owns channel vectors cv = (t % CVT) + j*CVT  and pixel lane pl = t / CVT
-struct ChanMap { int CV, CVT, PL, cv0, pl; bool active; };
-__device__ __forceinline__ ChanMap chan_map(int C, int tid) {
-    ChanMap m;
-    m.CV = C >> 2;
-    m.CVT = m.CV < 256 ? m.CV : 256;
-    m.PL = 256 / m.CVT;
-    m.cv0 = tid % m.CVT;
-    m.pl = tid / m.CVT;
-    m.active = m.pl < m.PL;
-    return m;
-}
-
+// Spatial GroupNorm, two launches over (pixel chunk, frame) workgroups of 4 waves.  A wave walks whole pixel rows
+// (C contiguous floats): lane l owns the float4 channel vectors l, l+64, ... (J per lane), so every load is a
+// fully coalesced 1 KiB wave access for any channel count, and the per-channel accumulators stay in registers.
+//   stats: per-channel sums -> LDS [wave][C] -> one thread per group adds them in a FIXED order (deterministic:
+//          a 1e-7 run-to-run wobble here would decorrelate the fp16 rounding of everything downstream)
+//          -> partial {n, mean, M2} per (frame, chunk, group)
+//   apply: Chan-combine the chunk partials, tabulate y = x*A[c] + B[c] per channel in LDS, stream.
+template <int J>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int ldx, int Npix, int C,
                                                        int ppc, float* __restrict__ partial) {
-    // Deterministic: per-thread channel sums go to LDS [pixel lane][channel] and ONE thread per group adds
-    // them in a fixed order (no float atomics: a 1e-7 run-to-run wobble here would decorrelate the fp16
-    // rounding of everything downstream).
-    extern __shared__ __attribute__((aligned(16))) float sm[];     // [PL][C] sums, then [PL][C] squares
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // [4][C]: per-wave sums, then per-wave squares
     const int f = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int tid = threadIdx.x;
-    const ChanMap cm = chan_map(C, tid);
-    const int cpg = C / GROUPS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int CV = C >> 2, cpg = C / GROUPS;
     const int p0 = chunk * ppc;
     const int p1 = min(Npix, p0 + ppc);
-    float* s_sum = sm;
-    float* s_sq = sm + cm.PL * C;
-    float sum[MAXV][4], sq[MAXV][4];
+    f32x4 sum[J], sq[J];
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j)
+    for (int j = 0; j < J; ++j) { sum[j] = z; sq[j] = z; }
+#pragma unroll 2
+    for (int pix = p0 + wave; pix < p1; pix += 4) {
+        const float* row = x + ((int64_t)f * Npix + pix) * ldx;
+        f32x4 v[J];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { sum[j][e] = 0.0f; sq[j][e] = 0.0f; }
-    if (cm.active) {
-        for (int pix = p0 + cm.pl; pix < p1; pix += cm.PL) {
-            const float* row = x + ((int64_t)f * Npix + pix) * ldx;
-#pragma unroll
-            for (int j = 0; j < MAXV; ++j) {
-                const int cv = cm.cv0 + j * cm.CVT;
-                if (cv < cm.CV) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(row + cv * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { sum[j][e] += v[e]; sq[j][e] = fmaf(v[e], v[e], sq[j][e]); }
-                }
-            }
+        for (int j = 0; j < J; ++j) {
+            const int cv = lane + j * 64;
+            v[j] = (cv < CV) ? *reinterpret_cast<const f32x4*>(row + cv * 4) : z;
         }
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int cv = cm.cv0 + j * cm.CVT;
-            if (cv < cm.CV) {
-                f32x4 a = {sum[j][0], sum[j][1], sum[j][2], sum[j][3]};
-                f32x4 b = {sq[j][0], sq[j][1], sq[j][2], sq[j][3]};
-                *reinterpret_cast<f32x4*>(s_sum + cm.pl * C + cv * 4) = a;
-                *reinterpret_cast<f32x4*>(s_sq + cm.pl * C + cv * 4) = b;
-            }
+        for (int j = 0; j < J; ++j) {
+            sum[j] += v[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sq[j][e] = fmaf(v[j][e], v[j][e], sq[j][e]);
         }
+    }
+    // two rounds through one [4][C] LDS array (sums, then squares): 16*C bytes, 40 KB at C = 2560
+    float* mine = sm + wave * C;
+    float ts = 0.0f, tq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int cv = lane + j * 64;
+        if (cv < CV) *reinterpret_cast<f32x4*>(mine + cv * 4) = sum[j];
+    }
+    __syncthreads();
+    if (tid < GROUPS)
+        for (int w = 0; w < 4; ++w)
+            for (int c = 0; c < cpg; ++c) ts += sm[w * C + tid * cpg + c];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int cv = lane + j * 64;
+        if (cv < CV) *reinterpret_cast<f32x4*>(mine + cv * 4) = sq[j];
     }
     __syncthreads();
     if (tid < GROUPS) {
-        float ts = 0.0f, tq = 0.0f;
-        for (int pl = 0; pl < cm.PL; ++pl)
-            for (int c = 0; c < cpg; ++c) {
-                ts += s_sum[pl * C + tid * cpg + c];
-                tq += s_sq[pl * C + tid * cpg + c];
-            }
+        for (int w = 0; w < 4; ++w)
+            for (int c = 0; c < cpg; ++c) tq += sm[w * C + tid * cpg + c];
         const float n = (float)(p1 - p0) * (float)cpg;
         const float mean = n > 0 ? ts / n : 0.0f;
         const float m2 = n > 0 ? fmaxf(tq - ts * mean, 0.0f) : 0.0f;
@@ -80,61 +73,88 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     }
 }
 
+template <int J>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int ldx, int Npix, int C,
                                                        int ppc, const float* __restrict__ partial,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu,
                                                        half_t* __restrict__ y, int ldy) {
-    __shared__ float s_mean[GROUPS], s_rstd[GROUPS];
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // A[C], B[C], then mean[32], rstd[32]
+    const int tabw = 2 * C > 24 * GROUPS ? 2 * C : 24 * GROUPS;
+    float* sA = sm;
+    float* sB = sm + C;
+    float* s_mean = sm + tabw;
+    float* s_rstd = s_mean + GROUPS;
     const int f = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int tid = threadIdx.x;
-    if (tid < GROUPS) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        // Chan-combine the chunk partials of this frame: 8 thread slices per group walk every 8th chunk (loads of a
+        // slice are independent and branch-free), then one thread per group merges the 8 slices in a fixed order.
+        float* s_pn = sm;                // [8][32] n, mean, M2 — scratch, overwritten by A/B afterwards
+        float* s_pm = sm + 8 * GROUPS;
+        float* s_p2 = sm + 16 * GROUPS;
+        const int g = tid & 31, part = tid >> 5;
         float n = 0.0f, mean = 0.0f, m2 = 0.0f;
-        for (int c = 0; c < nchunk; ++c) {
-            const float* q = partial + ((int64_t)(f * nchunk + c) * GROUPS + tid) * 3;
+        for (int c = part; c < nchunk; c += 8) {
+            const float* q = partial + ((int64_t)(f * nchunk + c) * GROUPS + g) * 3;
             const float nb = q[0], mb = q[1], m2b = q[2];
-            if (nb > 0.0f) {
-                const float nt = n + nb, d = mb - mean;
-                mean += d * (nb / nt);
-                m2 += m2b + d * d * (n * nb / nt);
-                n = nt;
-            }
+            const float nt = n + nb, d = mb - mean;
+            const float w = nb / fmaxf(nt, 1.0f);
+            mean = fmaf(d, w, mean);
+            m2 += m2b + d * d * (n * w);
+            n = nt;
         }
-        s_mean[tid] = mean;
-        s_rstd[tid] = rsqrtf(m2 / n + eps);
+        s_pn[part * GROUPS + g] = n; s_pm[part * GROUPS + g] = mean; s_p2[part * GROUPS + g] = m2;
+        __syncthreads();
+        float fm = 0.0f, fr = 0.0f;
+        if (tid < GROUPS) {
+            float tn = 0.0f, tm = 0.0f, t2 = 0.0f;
+            for (int k = 0; k < 8; ++k) {
+                const float nb = s_pn[k * GROUPS + tid], mb = s_pm[k * GROUPS + tid], m2b = s_p2[k * GROUPS + tid];
+                const float nt = tn + nb, d = mb - tm;
+                const float w = nb / fmaxf(nt, 1.0f);
+                tm = fmaf(d, w, tm);
+                t2 += m2b + d * d * (tn * w);
+                tn = nt;
+            }
+            fm = tm; fr = rsqrtf(t2 / tn + eps);
+        }
+        __syncthreads();
+        if (tid < GROUPS) { s_mean[tid] = fm; s_rstd[tid] = fr; }
     }
     __syncthreads();
-    const ChanMap cm = chan_map(C, tid);
-    if (!cm.active) return;
-    const int cpg = C / GROUPS;
+    const int CV = C >> 2, cpg = C / GROUPS;
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float a = gamma[c] * s_rstd[g];
+        sA[c] = a;
+        sB[c] = fmaf(-s_mean[g], a, beta[c]);
+    }
+    __syncthreads();
     const int p0 = chunk * ppc;
     const int p1 = min(Npix, p0 + ppc);
-    float ga[MAXV][4], be[MAXV][4], mu[MAXV][4];
-#pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        const int cv = cm.cv0 + j * cm.CVT;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (cv < cm.CV) {
-                const int c = cv * 4 + e, gidx = c / cpg;
-                const float g = gamma[c] * s_rstd[gidx];
-                ga[j][e] = g; mu[j][e] = s_mean[gidx]; be[j][e] = beta[c];
-            } else { ga[j][e] = 0.0f; mu[j][e] = 0.0f; be[j][e] = 0.0f; }
-        }
-    }
-    for (int pix = p0 + cm.pl; pix < p1; pix += cm.PL) {
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 2
+    for (int pix = p0 + wave; pix < p1; pix += 4) {
         const int64_t r = (int64_t)f * Npix + pix;
         const float* row = x + r * ldx;
         half_t* yrow = y + r * ldy;
+        f32x4 v[J];
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int cv = cm.cv0 + j * cm.CVT;
-            if (cv < cm.CV) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(row + cv * 4);
+        for (int j = 0; j < J; ++j) {
+            const int cv = lane + j * 64;
+            v[j] = (cv < CV) ? *reinterpret_cast<const f32x4*>(row + cv * 4) : z;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int cv = lane + j * 64;
+            if (cv < CV) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sA + cv * 4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(sB + cv * 4);
                 half4v h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float o = fmaf(v[e] - mu[j][e], ga[j][e], be[j][e]);
+                    float o = fmaf(v[j][e], a[e], b[e]);
                     if (silu) o = silu_f(o);
                     h[e] = (half_t)o;
                 }
@@ -208,65 +228,110 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restric
     }
 }
 
-// ---- LayerNorm: one wave per row, float4 vectors, two-pass variance in registers ------------------
-constexpr int LN_MAXV = 12;    // C <= 4*64*12 = 3072
+// ---- LayerNorm: one wave per row, LN_R rows per wave in flight (all loads issued before the first reduction),
+// float4 vectors, two-pass variance in registers ------------------------------------------------------------
+constexpr int LN_R = 4;
+template <int J>     // J = float4 vectors per lane = ceil(C / 256)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, int M, int C,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         half_t* __restrict__ y, int ldy) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_R;
+    if (row0 >= M) return;
     const int CV = C >> 2;
-    const float* xr = x + row * ldx;
-    f32x4 v[LN_MAXV];
-    float s = 0.0f;
+    f32x4 v[LN_R][J];
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-        const int cv = lane + j * 64;
-        if (cv < CV) {
-            v[j] = *reinterpret_cast<const f32x4*>(xr + cv * 4);
-            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    for (int r = 0; r < LN_R; ++r) {
+        const int64_t row = (row0 + r < M) ? row0 + r : (int64_t)M - 1;
+        const float* xr = x + row * ldx;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int cv = lane + j * 64;
+            v[r][j] = (cv < CV) ? *reinterpret_cast<const f32x4*>(xr + cv * 4) : z;
         }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.0f;
+    f32x4 g[J], b[J];
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < J; ++j) {
         const int cv = lane + j * 64;
-        if (cv < CV) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q = fmaf(d, d, q); }
-        }
+        g[j] = (cv < CV) ? *reinterpret_cast<const f32x4*>(gamma + cv * 4) : z;
+        b[j] = (cv < CV) ? *reinterpret_cast<const f32x4*>(beta + cv * 4) : z;
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    half_t* yr = y + row * ldy;
+    float mean[LN_R], rstd[LN_R];
+    const float invc = 1.0f / (float)C;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-        const int cv = lane + j * 64;
-        if (cv < CV) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + cv * 4);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + cv * 4);
-            half4v h;
+    for (int r = 0; r < LN_R; ++r) {
+        float s = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = (half_t)fmaf((v[j][e] - mean) * rstd, g[e], b[e]);
-            *reinterpret_cast<half4v*>(yr + cv * 4) = h;
+        for (int j = 0; j < J; ++j) s += (v[r][j][0] + v[r][j][1]) + (v[r][j][2] + v[r][j][3]);
+        mean[r] = s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < LN_R; ++r) mean[r] += __shfl_xor(mean[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) {
+        mean[r] *= invc;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int cv = lane + j * 64;
+            if (cv < CV) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[r][j][e] - mean[r]; q = fmaf(d, d, q); }
+            }
+        }
+        rstd[r] = q;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < LN_R; ++r) rstd[r] += __shfl_xor(rstd[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) {
+        if (row0 + r >= M) break;
+        const float rs = rsqrtf(rstd[r] * invc + eps);
+        half_t* yr = y + (row0 + r) * ldy;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int cv = lane + j * 64;
+            if (cv < CV) {
+                half4v h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (half_t)fmaf((v[r][j][e] - mean[r]) * rs, g[j][e], b[j][e]);
+                *reinterpret_cast<half4v*>(yr + cv * 4) = h;
+            }
         }
     }
 }
 
 }  // namespace
 
+constexpr int GN_MAXC = 4 * 64 * 12;       // J <= 12 float4 vectors per lane
+
+#define PNC_GN_DISPATCH(KERNEL, ...)                                                                           \
+    do {                                                                                                       \
+        const int J = (C / 4 + 63) / 64;                                                                       \
+        if (J <= 1) hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__);                                                \
+        else if (J == 2) hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__);                                           \
+        else if (J == 3) hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__);                                           \
+        else if (J <= 5) hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__);                                           \
+        else if (J <= 8) hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__);                                           \
+        else hipLaunchKernelGGL(KERNEL<12>, __VA_ARGS__);                                                      \
+    } while (0)
+
 extern "C" int pnc_groupnorm_stats(const float* x, int ldx, int F, int Npix, int C,
                                    int pix_per_chunk, float* partial, void* stream) {
     if (!x || !partial || F < 1 || Npix < 1 || pix_per_chunk < 1) return PNC_EINVAL;
-    if (C % 64 || C > 4 * 256 * MAXV || ldx % 4) return PNC_EINVAL;
+    if (C % 64 || C > GN_MAXC || ldx % 4) return PNC_EINVAL;
     if ((uintptr_t)x & 15) return PNC_EALIGN;
     const int nchunk = (Npix + pix_per_chunk - 1) / pix_per_chunk;
-    const int CV = C / 4, CVT = CV < 256 ? CV : 256, PL = 256 / CVT;
-    const size_t lds = (size_t)2 * PL * C * sizeof(float);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, F), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
-                       x, ldx, Npix, C, pix_per_chunk, partial);
+    const size_t lds = (size_t)4 * C * sizeof(float);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    PNC_GN_DISPATCH(gn_stats_kernel, dim3(nchunk, F), dim3(256), lds, st, x, ldx, Npix, C, pix_per_chunk, partial);
     return pnc_launch_status();
 }
 
@@ -275,12 +340,14 @@ extern "C" int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int
                                    const float* gamma, const float* beta, float eps, int silu,
                                    void* y16, int ldy, void* stream) {
     if (!x || !partial || !gamma || !beta || !y16 || F < 1 || Npix < 1 || pix_per_chunk < 1) return PNC_EINVAL;
-    if (C % 64 || C > 4 * 256 * MAXV || ldx % 4 || ldy % 4) return PNC_EINVAL;
+    if (C % 64 || C > GN_MAXC || ldx % 4 || ldy % 4) return PNC_EINVAL;
     if (((uintptr_t)x & 15) || ((uintptr_t)y16 & 7)) return PNC_EALIGN;
     const int nchunk = (Npix + pix_per_chunk - 1) / pix_per_chunk;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, F), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       x, ldx, Npix, C, pix_per_chunk, partial, gamma, beta, eps, silu,
-                       reinterpret_cast<half_t*>(y16), ldy);
+    const size_t lds = ((size_t)(2 * C > 24 * GROUPS ? 2 * C : 24 * GROUPS) + 2 * GROUPS) * sizeof(float);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    half_t* y = reinterpret_cast<half_t*>(y16);
+    PNC_GN_DISPATCH(gn_apply_kernel, dim3(nchunk, F), dim3(256), lds, st, x, ldx, Npix, C, pix_per_chunk, partial,
+                    gamma, beta, eps, silu, y, ldy);
     return pnc_launch_status();
 }
 
@@ -309,11 +376,16 @@ extern "C" int pnc_layernorm(const float* x, int ldx, int M, int C,
                              const float* gamma, const float* beta, float eps,
                              void* y16, int ldy, void* stream) {
     if (!x || !gamma || !beta || !y16 || M < 1) return PNC_EINVAL;
-    if (C % 4 || C > 4 * 64 * LN_MAXV || ldx % 4 || ldy % 4) return PNC_EINVAL;
+    if (C % 4 || C > 4 * 64 * 12 || C < 4 || ldx % 4 || ldy % 4) return PNC_EINVAL;
     if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) return PNC_EALIGN;
     if ((uintptr_t)y16 & 7) return PNC_EALIGN;
-    const unsigned blocks = (unsigned)(((int64_t)M + 3) / 4);
-    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       x, ldx, M, C, gamma, beta, eps, reinterpret_cast<half_t*>(y16), ldy);
+    const unsigned blocks = (unsigned)(((int64_t)M + 4 * LN_R - 1) / (4 * LN_R));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    half_t* y = reinterpret_cast<half_t*>(y16);
+    const int J = (C / 4 + 63) / 64;
+#define PNC_LN(JJ) hipLaunchKernelGGL(layernorm_kernel<JJ>, dim3(blocks), dim3(256), 0, st, x, ldx, M, C, gamma, beta, eps, y, ldy)
+    if (J <= 1) PNC_LN(1); else if (J == 2) PNC_LN(2); else if (J == 3) PNC_LN(3); else if (J <= 5) PNC_LN(5);
+    else if (J <= 8) PNC_LN(8); else PNC_LN(12);
+#undef PNC_LN
     return pnc_launch_status();
 }

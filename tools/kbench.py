@@ -124,7 +124,7 @@ def bench_norm(flt):
         x = torch.randn(M, C, device=DEV)
         y = torch.empty(M, C, device=DEV, dtype=torch.float16)
         g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
-        ppc = 128
+        ppc = max(16, min(128, N // 48))      # engine._ppc
         part = torch.empty(F * ((N + ppc - 1) // ppc) * 32 * 3, device=DEV)
         tag = f"groupnorm L{li} C={C}"
         if not flt or flt in tag:

@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--one-stream", action="store_true", help="do not overlap the ControlNet with the UNet encoder")
+    ap.add_argument("--split-samples", action="store_true", help="issue the two CFG halves as independent stream pairs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,6 +105,8 @@ def main():
     net = build_network(kw)
     net.diffusion_model.load_state_dict(sd, strict=True)
     net = net.to(dev)
+    net.diffusion_model.two_stream = not args.one_stream
+    net.diffusion_model.split_samples = bool(args.split_samples)
     log(f"[rank {rank}] network built in {time.time() - t0:.0f}s")
 
     # one sample per rank: c / uc conditioning of ONE 6-view x T-frame clip (seed offset by rank, inference.py:250)
@@ -177,7 +181,7 @@ def main():
         "config": {"workload": "BASELINE config 3: Panacea+ stage-2 UNet+ControlNet, CFG 2 x 8 frames, 6 views, latent 32x384, "
                                "hint 256x3072, Euler/LegacyDDPM 50-step schedule" if args.config == "full" else "tiny",
                    "frames_per_step": 2 * T, "parallelism": f"replica x{world}" if world > 1 else "single",
-                   "graph": bool(args.graph)},
+                   "graph": bool(args.graph), "streams": 1 if args.one_stream else 2},
     }
     if args.config == "full":
         ach = ALGO_TFLOP_PER_STEP * (value / world)
@@ -190,8 +194,11 @@ def main():
     if rank == 0 and not args.no_kernel_breakdown:
         prof = hip.Profiler()
         hip.set_profiler(prof)
+        two = net.diffusion_model.two_stream
+        net.diffusion_model.two_stream = False        # one stream: per-launch event times do not overlap
         with torch.no_grad():
             step(0, x)
+        net.diffusion_model.two_stream = two
         hip.set_profiler(None)
         summ = prof.summary()
         tot = sum(v["ms"] for v in summ.values())

@@ -159,18 +159,71 @@ class ControlledUNetModel3D(UNetModel3D):
             out = self._run_unet(rt, self._stem_tokens(rt, x), emb, acts)
         return out.to(x.dtype)
 
+    two_stream = True      # run the ControlNet branch on a second HIP stream, concurrently with the UNet encoder
+    split_samples = False  # additionally run every sample of the batch (CFG half) as its own stream pair
+
     def denoise(self, x, timesteps, context, hint, trace=None) -> torch.Tensor:
         """ControlNet + UNet in one runtime (what OpenAIWrapperControlLDM3D.forward calls): the stem tokens and
-        the text context are prepared once and the 13 residuals stay in the resident layout."""
+        the text context are prepared once and the 13 residuals stay in the resident layout.  The ControlNet only
+        feeds the UNet from its middle block on (controlmodel.py:191-195), so it runs on a side stream next to the
+        UNet encoder: its small-grid kernels (L2/L3, 4x48 tokens) fill CUs the encoder's leave idle, and vice versa.
+        Samples of the batch never interact inside the network, so they can be issued as independent stream pairs."""
+        T = self.num_frames
+        B = x.shape[0] // T
+        if self.split_samples and self.two_stream and x.is_cuda and trace is None and B > 1:
+            main = torch.cuda.current_stream()
+            outs = []
+            for b in range(B):
+                sb = _side_stream(x.device, 2 * b)
+                sb.wait_stream(main)
+                with torch.cuda.stream(sb):
+                    sl = slice(b * T, (b + 1) * T)
+                    outs.append(self._denoise_one(x[sl], timesteps[sl], context[b:b + 1], hint[sl], None, 2 * b + 1))
+                for t in (x, timesteps, context, hint):
+                    t.record_stream(sb)
+            for b in range(B):
+                main.wait_stream(_side_stream(x.device, 2 * b))
+                outs[b].record_stream(main)
+            return torch.cat(outs, dim=0)
+        return self._denoise_one(x, timesteps, context, hint, trace, 0)
+
+    def _denoise_one(self, x, timesteps, context, hint, trace, side_idx) -> torch.Tensor:
         with torch.no_grad():
             rt = runtime_for(x, self.num_frames)
             rt.trace = trace
             rt.set_context(context)
             x16 = self._stem_tokens(rt, x)
             cn = self.controlnet
-            control = cn._run_control(rt, x16, hint, cn._time_embedding(rt, timesteps))
-            if trace is not None:
-                for j, c in enumerate(control):
-                    trace[f"control.{j}"] = c.to_nchw()
-            out = self._run_unet(rt, x16, self._time_embedding(rt, timesteps), control)
+            hint32 = hint.detach().to(torch.float32).contiguous()
+            if self.two_stream and x.is_cuda and trace is None:
+                main = torch.cuda.current_stream()
+                side = _side_stream(x.device, side_idx)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    control = cn._run_control(rt, x16, hint32, cn._time_embedding(rt, timesteps))
+                for t in (x16.f16, rt.ctx16, hint32, timesteps):
+                    t.record_stream(side)
+
+                def join():
+                    main.wait_stream(side)
+                    for c in control:
+                        c.f32.record_stream(main)
+                    return control
+                out = self._run_unet(rt, x16, self._time_embedding(rt, timesteps), join)
+            else:
+                control = cn._run_control(rt, x16, hint32, cn._time_embedding(rt, timesteps))
+                if trace is not None:
+                    for j, c in enumerate(control):
+                        trace[f"control.{j}"] = c.to_nchw()
+                out = self._run_unet(rt, x16, self._time_embedding(rt, timesteps), control)
         return out.to(x.dtype)
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device, idx: int = 0) -> "torch.cuda.Stream":
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), idx)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]

@@ -358,8 +358,10 @@ class UNetModel3D(nn.Module, Packable):
         rt.be.nchw_to_tokens_f16(x32, C, None, 0, F, H * W, cp, t16)
         return Act(F, H, W, cp, f16=t16)
 
-    def _run_unet(self, rt: Runtime, x16: Act, emb32: torch.Tensor, control: Optional[list]) -> torch.Tensor:
-        """controlmodel.py:186-202 / openaimodel.py:1305-1319 on tokens."""
+    def _run_unet(self, rt: Runtime, x16: Act, emb32: torch.Tensor, control) -> torch.Tensor:
+        """controlmodel.py:186-202 / openaimodel.py:1305-1319 on tokens.  `control` is None, the list of ControlNet
+        residuals, or a callable returning that list (called after the middle block: the join point when the
+        ControlNet runs on a second stream)."""
         hs, h = [], x16
         nb = len(self.input_blocks)
         for i, module in enumerate(self.input_blocks):
@@ -372,6 +374,8 @@ class UNetModel3D(nn.Module, Packable):
         h = self.middle_block._run(rt, h, emb32)
         if rt.trace is not None:
             rt.trace["middle_block"] = h.to_nchw()
+        if callable(control):
+            control = control()
         if control is not None:
             c = control.pop()
             rt.be.add_f32(h.f32, c.f32, h.M * h.C, h.f32, None)                       # h += control.pop()

@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--device", type=int, default=None, help="override the HIP device index (default LOCAL_RANK)")
     ap.add_argument("--one-stream", action="store_true", help="do not overlap the ControlNet with the UNet encoder")
     ap.add_argument("--split-samples", action="store_true", help="issue the two CFG halves as independent stream pairs")
     args = ap.parse_args()
@@ -88,12 +90,16 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.device is None else args.device
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from panacea_amd import build_network, configs, hip, sampling, synth
     hip.load()
@@ -135,6 +141,9 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    if world > 1 or args.no_cpu_baseline:
+        del sd                         # only the N = 1 cpu_baseline leg needs the fp32 state dict again
+
     with torch.no_grad():
         # parity guard inside the bench run: eps of the very first network call vs the reference's own output
         parity = None
@@ -167,7 +176,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t_start
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = tt.item()
     assert torch.isfinite(xx).all()

@@ -18,10 +18,20 @@
 // on 4 consecutive columns.  Workgroup ids are remapped so that each XCD walks a contiguous tile range.
 #include "common.h"
 #include <stdlib.h>
+#include <utility>
 
 namespace {
 
 constexpr int BK = 64;          // fp16 elements per K tile = 128 B per LDS row
+
+// compile-time loop: the index reaches the body as a constant, so accumulator arrays are always indexed statically
+// (a loop the optimizer declines to unroll would otherwise push the 256-register accumulator file to scratch)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct RowState {               // per staged A row, fixed over the K loop
     int64_t base;               // element offset of the row origin
@@ -105,9 +115,9 @@ __device__ __forceinline__ void epilogue_rowmajor(const PncGemmParams& p, f32x16
     const bool vr1 = ((p.ldr1 & 3) == 0) && (((uintptr_t)p.res1 & 15) == 0);
     const bool vr2 = ((p.ldr2 & 3) == 0) && (((uintptr_t)p.res2 & 15) == 0);
     const int act = p.act & 0xff;
-#pragma unroll
-    for (int jc = 0; jc < NI; jc += ENI) {
-        const int cw = (NI - jc) < ENI ? (NI - jc) : ENI;               // column blocks in this chunk (1 or 2)
+    static_for<(NI + ENI - 1) / ENI>([&](auto jc_) {
+        constexpr int jc = decltype(jc_)::value * ENI;
+        constexpr int cw = (NI - jc) < ENI ? (NI - jc) : ENI;           // column blocks in this chunk (1 or 2)
         const int nin0 = nw + jc * 32 + cl * 8;                         // first input column (N space of W / bias)
         const int ncol = GEGLU ? ((nw + jc * 32) >> 1) + cl * 8 : nin0; // first output column of this lane
         const bool lane_on = (cl * 8) < (GEGLU ? 32 : cw * 32) && ncol < Nout;
@@ -119,16 +129,17 @@ __device__ __forceinline__ void epilogue_rowmajor(const PncGemmParams& p, f32x16
             bcol[e] = (p.bias && lane_on && nin < p.N) ? p.bias[nin] : 0.0f;
             bgate[e] = (GEGLU && p.bias && lane_on && (nin + 32) < p.N) ? p.bias[nin + 32] : 0.0f;
         }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        static_for<MI>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // previous slab fully read
-#pragma unroll
-            for (int j = 0; j < ENI; ++j)
-                if (j < cw && !ab_nostage) {
+            static_for<cw>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                if (!ab_nostage) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][jc + j][r];
                 }
+            });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             f32x4 a0[NP], a1[NP], g0[NP], g1[NP];
 #pragma unroll
@@ -212,8 +223,8 @@ __device__ __forceinline__ void epilogue_rowmajor(const PncGemmParams& p, f32x16
                     }
                 }
             }
-        }
-    }
+        });
+    });
 }
 
 template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE>
@@ -277,7 +288,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     const int frow = lane & 31, fk = lane >> 5;
     // timing-experiment switches (tools/kbench.py PNC_ABLATE): results are garbage when any is set
     const bool ab_nodma = (p.act & 0x100) != 0, ab_nomfma = (p.act & 0x200) != 0, ab_noepi = (p.act & 0x400) != 0;
-    const bool ab_nostage = (p.act & 0x800) != 0, ab_nostore = (p.act & 0x1000) != 0;
+    const bool ab_nostage = (p.act & 0x800) != 0, ab_nostore = (p.act & 0x1000) != 0, ab_nobar = (p.act & 0x2000) != 0;
+    const bool prio = (p.act & 0x4000) != 0;
     auto compute = [&](int stage) {
         const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
@@ -298,11 +310,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 if (ks + 1 < BK / 16) frags(ks + 1, (ks + 1) & 1);
+                // keep the reads of k-step ks+1 AHEAD of the MFMAs of k-step ks (hipcc otherwise sinks them behind the
+                // MFMAs and then waits lgkmcnt(0) right after issuing them, exposing the LDS latency every k-step)
+                __builtin_amdgcn_sched_barrier(0);
+                if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+                if (prio) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         for (int kt = 0; kt < ntiles; ++kt) {
             if (kt + 1 < ntiles && !ab_nodma) issue_tile(kt + 1, (kt + 1) & 1);
             if (!ab_nomfma) compute(kt & 1);
-            __syncthreads();
+            if (!ab_nobar) __syncthreads();
         }
     } else {
         // ring of three stages, TWO tiles in flight.  Counted waits: after issuing tile kt+2 only its LOADS
@@ -368,12 +386,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     if ((out16t != nullptr) && (n0 >= p.n_split)) {
         // channel-major ("V^T") output: a lane already holds 4 consecutive rows of one column
         const int col = lane & 31;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
+        static_for<MI * NI>([&](auto ij_) {
+            constexpr int i = decltype(ij_)::value / NI, j = decltype(ij_)::value % NI;
+            {
                 const int n = nw + j * 32 + col;
-                if (n >= p.N) continue;
+                if (n >= p.N) return;
                 const float bn = p.bias ? p.bias[n] : 0.0f;
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
@@ -400,6 +417,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
                     }
                 }
             }
+        });
         return;
     }
 
@@ -436,20 +454,36 @@ int launch(const PncGemmParams& p, hipStream_t st) {
 // output columns, 9 DMA instructions per 40 MFMAs (vs 6 per 16 for 256x128).  GEGLU pairs 32-column value /
 // gate blocks inside one wave and therefore keeps 256x128 (wave tile 64x64).  Small grids fall back to
 // 128x128 so that every CU still gets work; 128x32 serves the narrow-N convs (hint stem, output head).
+// expected relative throughput of a geometry on `slots` concurrently resident workgroups
+static inline double tile_score(long tiles, int slots, double eff) {
+    if (tiles <= 0) return 0.0;
+    const long rounds = (tiles + slots - 1) / slots;
+    return eff * (double)tiles / (double)(rounds * slots);
+}
+
 template <int AMODE>
 int dispatch(const PncGemmParams& p, hipStream_t st) {
     static const int force = getenv("PNC_GEMM_TILE") ? atoi(getenv("PNC_GEMM_TILE")) : 0;   // A/B runs
     if (p.N <= 32 && !p.geglu) return launch<AMODE, 128, 32, 4, 1, 2, true>(p, st);
-    const long mt256 = (p.M + 255) / 256;
+    const long mt256 = (p.M + 255) / 256, mt128 = (p.M + 127) / 128;
     const bool w320_ok = !p.geglu && (p.N % 320 == 0) && (!p.out16t || p.n_split % 320 == 0);
     const bool w256_ok = (p.N % 256 == 0) && (!p.out16t || p.n_split % 256 == 0);
-    const long t320 = mt256 * (p.N / 320);
-    const bool use320 = force ? (force == 3 && w320_ok) : (w320_ok && (t320 >= 512 || (t320 >= 384 && p.K >= 2048)));
-    if (use320) return launch<AMODE, 256, 320, 4, 2, 2, false>(p, st);
-    const bool use256 = force ? (force == 4 && w256_ok) : (w256_ok && mt256 * (p.N / 256) >= 512);
-    if (use256) return launch<AMODE, 256, 256, 4, 2, 2, true>(p, st);
-    const bool big = force ? (force == 2) : (mt256 * ((p.N + 127) / 128) >= 512);
-    if (big) return launch<AMODE, 256, 128, 4, 2, 3, true>(p, st);
+    int pick = force;
+    if (!pick) {
+        // measured main-loop efficiencies (relative): wide wave tiles win whenever they still fill ~3/4 of the CUs
+        const double s320 = w320_ok ? tile_score(mt256 * (p.N / 320), 256, p.K >= 1024 ? 1.0 : 0.92) : 0.0;
+        const double s256 = w256_ok ? tile_score(mt256 * (p.N / 256), 256, 0.97) : 0.0;
+        const double s2x1 = tile_score(mt256 * ((p.N + 127) / 128), 256, 0.80);
+        const double s1x1 = tile_score(mt128 * ((p.N + 127) / 128), 512, 0.70);
+        pick = 1;
+        double best = s1x1;
+        if (s2x1 > best) { best = s2x1; pick = 2; }
+        if (s256 > best) { best = s256; pick = 4; }
+        if (s320 > best) { best = s320; pick = 3; }
+    }
+    if (pick == 3 && w320_ok) return launch<AMODE, 256, 320, 4, 2, 2, false>(p, st);
+    if (pick == 4 && w256_ok) return launch<AMODE, 256, 256, 4, 2, 2, true>(p, st);
+    if (pick == 2) return launch<AMODE, 256, 128, 4, 2, 3, true>(p, st);
     return launch<AMODE, 128, 128, 2, 2, 2, true>(p, st);
 }
 

@@ -41,8 +41,10 @@ const char* pnc_version(void);
  *        398-403,509-514,959,980,1040-1059) and 1x1 convs
  *        (sgm/modules/diffusionmodules/openaimodel.py:486, controlmodel.py:81-84)
  *   a_mode PNC_A_CONV3X3 : implicit GEMM over an NHWC fp16 image
- *        [F][Hin][Win][Cin], K = 9*Cin ordered (ky,kx,ci), pad 1, stride 1|2,
- *        optional nearest x2 upsample of the input
+ *        [F][Hin][Win][Cin], K = 9*Cin, pad 1, stride 1|2, optional nearest x2
+ *        upsample of the input.  K order of W: (ky,kx,ci) when Cin % 64 != 0, else
+ *        (ci/64, ky, kx, ci%64) — the nine taps of a 64-channel slice are adjacent
+ *        K tiles, so their reads of one pixel neighbourhood hit L1/L2
  *     -> nn.Conv2d 3x3 (openaimodel.py:413,459,125 (Upsample),187 (Downsample),
  *        974 (stem), 1251 (out); controlmodel.py:44-58 (hint stem))
  *   a_mode PNC_A_CONV1D_T: temporal conv1d k=3 pad 1 over frames of one pixel,

@@ -69,7 +69,15 @@ __device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, con
     if (AMODE == PNC_A_PLAIN) {
         return A + s.base + kc;
     } else if (AMODE == PNC_A_CONV3X3) {
-        const int tap = kc / p.Cin, ci = kc - tap * p.Cin;
+        // K order: (ky,kx,ci) for narrow inputs; (ci/64, ky, kx, ci%64) when Cin % 64 == 0, so that the nine tap
+        // reads of one 64-channel slice of a pixel neighbourhood are consecutive K tiles and hit L1/L2
+        int tap, ci;
+        if ((p.Cin & 63) == 0) {
+            const int cc = kc / 576, r = kc - cc * 576;
+            tap = r >> 6; ci = (cc << 6) + (r & 63);
+        } else {
+            tap = kc / p.Cin; ci = kc - tap * p.Cin;
+        }
         const int ky = tap / 3, kx = tap - ky * 3;
         int iy, ix; bool ok;
         if (p.upsample) {
@@ -471,7 +479,7 @@ int dispatch(const PncGemmParams& p, hipStream_t st) {
     int pick = force;
     if (!pick) {
         // measured main-loop efficiencies (relative): wide wave tiles win whenever they still fill ~3/4 of the CUs
-        const double s320 = w320_ok ? tile_score(mt256 * (p.N / 320), 256, p.K >= 1024 ? 1.0 : 0.92) : 0.0;
+        const double s320 = w320_ok ? tile_score(mt256 * (p.N / 320), 256, p.K >= 2048 ? 1.08 : (p.K >= 1024 ? 1.0 : 0.92)) : 0.0;
         const double s256 = w256_ok ? tile_score(mt256 * (p.N / 256), 256, 0.97) : 0.0;
         const double s2x1 = tile_score(mt256 * ((p.N + 127) / 128), 256, 0.80);
         const double s1x1 = tile_score(mt128 * ((p.N + 127) / 128), 512, 0.70);

@@ -125,11 +125,14 @@ def pk_linear(w: torch.Tensor) -> torch.Tensor:
 
 
 def pk_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
-    """[Cout, Cin, 3, 3] -> [Cout, 9*Cin_pad] with K ordered (ky, kx, ci)."""
+    """[Cout, Cin, 3, 3] -> [Cout, 9*Cin_pad].  K order (ky, kx, ci) for narrow inputs; (ci/64, ky, kx, ci%64) when
+    Cin_pad % 64 == 0 (see include/panacea_hip.h: the nine taps of a 64-channel slice become adjacent K tiles)."""
     co, ci = w.shape[0], w.shape[1]
     cp = cin_pad or ((ci + 7) // 8 * 8)
     p = torch.zeros((co, 3, 3, cp), device=w.device, dtype=torch.float16)
     p[..., :ci] = w.detach().permute(0, 2, 3, 1).to(torch.float16)
+    if cp % 64 == 0:
+        p = p.view(co, 9, cp // 64, 64).permute(0, 2, 1, 3)
     return p.reshape(co, 9 * cp).contiguous()
 
 

@@ -24,6 +24,19 @@ def test_emu_conv3x3_modes():
         assert torch.allclose(out.view(F, Hout, Wout, N).permute(0, 3, 1, 2), ref, atol=1e-4)
 
 
+def test_emu_conv3x3_chunked_k_order_matches_packer():
+    from panacea_amd import engine as E
+    torch.manual_seed(5)
+    F, H, W, Cin, N = 1, 5, 7, 128, 32
+    x = torch.randn(F, Cin, H, W).half()
+    w = torch.randn(N, Cin, 3, 3).half() * 0.05
+    ref = TF.conv2d(x.float(), w.float(), padding=1)
+    out = torch.zeros(F * H * W, N)
+    emu.gemm(x.permute(0, 2, 3, 1).contiguous(), E.pk_conv3x3(w), M=F * H * W, N=N, K=9 * Cin, a_mode=emu.A_CONV3X3,
+             conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0), out32=out, ldc32=N)
+    assert torch.allclose(out.view(F, H, W, N).permute(0, 3, 1, 2), ref, atol=2e-3)
+
+
 def test_emu_conv1d_temporal_and_gn():
     torch.manual_seed(1)
     B, T, Npix, C = 2, 4, 5, 64

@@ -84,7 +84,7 @@ class Runtime:
         self.ctx16: Optional[torch.Tensor] = None      # [B*TEXT_PAD, context_dim] fp16, zero padded
         self.n_text = 77
         self.trace: Optional[Dict[str, torch.Tensor]] = None
-        self.launches = 0
+        self.text_kv: Dict[int, tuple] = {}            # per cross-attention site: (k, ldk, vt, ldvt, vt_gstride)
 
     def empty(self, shape, dtype) -> torch.Tensor:
         return torch.empty(shape, device=self.device, dtype=dtype)
@@ -166,7 +166,7 @@ class Packable:
         self._pk = None
 
     def _apply(self, fn, *a, **k):          # .to() / .cuda() / .half() move the parameters
-        self._pk = None
+        self.invalidate_packed()
         return super()._apply(fn, *a, **k)
 
     def packed(self) -> dict:

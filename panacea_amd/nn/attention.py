@@ -122,20 +122,30 @@ class _AttentionBase(nn.Module, Packable):
         return pk
 
     # ---- text cross-attention: x16 [M, C] queries of F frames vs the 77 context tokens of each sample
-    def _run_text(self, rt: Runtime, x16, F, H, W, res32, out32):
+    def _text_kv(self, rt: Runtime):
+        """(k, ldk, vt, ldvt, vt_gstride) of this site.  The network projects the text keys/values of ALL its
+        cross-attention sites of one width in two GEMMs up front (`project_text_kv`); a module used on its own
+        projects its own."""
+        hit = rt.text_kv.get(id(self))
+        if hit is not None:
+            return hit
         pk = self.packed()
-        C, M = self.inner_dim, F * H * W
-        D = rt.ctx16.shape[1]
-        rows = rt.B * E.TEXT_PAD
-        q = rt.empty((M, C), torch.float16)
-        rt.be.gemm(x16, pk["wq"], M=M, N=C, K=self.query_dim, lda=self.query_dim, out16=q, ldc16=C)
+        C, D, rows = self.inner_dim, rt.ctx16.shape[1], rt.B * E.TEXT_PAD
         k = rt.empty((rows, C), torch.float16)
         vt = rt.empty((rt.B, C, E.TEXT_PAD), torch.float16)
         rt.be.gemm(rt.ctx16, pk["wk"], M=rows, N=C, K=D, lda=D, out16=k, ldc16=C)
         rt.be.gemm(rt.ctx16, pk["wv"], M=rows, N=C, K=D, lda=D, out16t=vt, ldt=E.TEXT_PAD, t_rows=E.TEXT_PAD,
                    t_gstride=C * E.TEXT_PAD, n_split=0)
+        return k, C, vt, E.TEXT_PAD, C * E.TEXT_PAD
+
+    def _run_text(self, rt: Runtime, x16, F, H, W, res32, out32):
+        pk = self.packed()
+        C, M = self.inner_dim, F * H * W
+        q = rt.empty((M, C), torch.float16)
+        rt.be.gemm(x16, pk["wq"], M=M, N=C, K=self.query_dim, lda=self.query_dim, out16=q, ldc16=C)
+        k, ldk, vt, ldvt, vt_gs = self._text_kv(rt)
         o = rt.empty((M, C), torch.float16)
-        rt.be.attn_views(q, C, k, C, vt, E.TEXT_PAD, C * E.TEXT_PAD, o, C, groups=F, heads=self.heads, H=H, W=W,
+        rt.be.attn_views(q, C, k, ldk, vt, ldvt, vt_gs, o, C, groups=F, heads=self.heads, H=H, W=W,
                          views=1, kvH=1, kvW=E.TEXT_PAD, kv_views=1, kv_rows_per_group=E.TEXT_PAD,
                          q_per_kv=rt.T, kv_valid=rt.n_text, segs=[[0]], scale=self.scale)
         rt.be.gemm(o, pk["wo"], M=M, N=self.query_dim, K=C, lda=C, bias=pk["bo"], res1=res32,
@@ -361,6 +371,48 @@ class SpatialTemporalTransformer(nn.Module, Packable):
         rt.set_context(ctx.view(rt.B, rt.T, *ctx.shape[1:])[:, 0])
         a = act_from_nchw(rt, x)
         return self._run(rt, a).to_nchw().to(x.dtype)
+
+
+class TextKVProjector:
+    """Batches the text K/V projections of every cross-attention site of a network.  They depend only on the
+    (B, 77, D) context, so all sites of one width C share two GEMMs: K_all = ctx W_k^T (row-major, one column block
+    per site) and V_all^T (channel-major).  138 launches of M = 160 rows become 16 per step (the reference instead
+    re-projects them once per PIXEL in the temporal branch: attention.py:1122-1125)."""
+
+    def __init__(self, root: nn.Module):
+        self.groups = {}
+        for m in root.modules():
+            if isinstance(m, BasicTransformerBlock):
+                a = m.attn2
+                self.groups.setdefault((a.inner_dim, a.context_dim), []).append(a)
+        self._pk = None
+
+    def pack(self):
+        pk = {}
+        for key, mods in self.groups.items():
+            wk = torch.cat([m.to_k.weight for m in mods], dim=0)
+            wv = torch.cat([m.to_v.weight for m in mods], dim=0)
+            pk[key] = (E.pk_f16(wk), E.pk_f16(wv))
+        return pk
+
+    def run(self, rt: Runtime):
+        if self._pk is None:
+            with torch.no_grad():
+                self._pk = self.pack()
+        rows, D = rt.B * E.TEXT_PAD, rt.ctx16.shape[1]
+        for (C, Dm), mods in self.groups.items():
+            if Dm != D:
+                raise ValueError(f"context width {D} does not match the cross-attention context_dim {Dm}")
+            wk, wv = self._pk[(C, Dm)]
+            NT = C * len(mods)
+            k = rt.empty((rows, NT), torch.float16)
+            vt = rt.empty((rt.B, NT, E.TEXT_PAD), torch.float16)
+            rt.be.gemm(rt.ctx16, wk, M=rows, N=NT, K=D, lda=D, out16=k, ldc16=NT)
+            rt.be.gemm(rt.ctx16, wv, M=rows, N=NT, K=D, lda=D, out16t=vt, ldt=E.TEXT_PAD, t_rows=E.TEXT_PAD,
+                       t_gstride=NT * E.TEXT_PAD, n_split=0)
+            kf, vf = k.view(-1), vt.view(-1)
+            for i, m in enumerate(mods):
+                rt.text_kv[id(m)] = (kf[i * C:], NT, vf[i * C * E.TEXT_PAD:], E.TEXT_PAD, NT * E.TEXT_PAD)
 
 
 def _is_listconfig(v) -> bool:

@@ -94,6 +94,7 @@ class ControlNet3D(UNetModel3D):
 
     def _run_control(self, rt: Runtime, x16: Act, hint: torch.Tensor, emb32: torch.Tensor) -> List[Act]:
         pk = self.packed()
+        self._project_text(rt)
         guided = self._hint_stem(rt, hint)
         outs, h = [], x16
         for i, (module, (zw, zb)) in enumerate(zip(self.input_blocks, pk["zero"])):

@@ -227,6 +227,17 @@ class ResBlock3D(TimestepBlock, Packable):
         return self._run(rt, act_from_nchw(rt, x), emb.to(torch.float32).contiguous()).to_nchw().to(x.dtype)
 
 
+class _OwnBlocks:
+    """The blocks a network runs itself (a ControlledUNetModel3D must not walk into its `.controlnet` child)."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def modules(self):
+        for blk in self.net._own_blocks():
+            yield from blk.modules()
+
+
 class UNetModel3D(nn.Module, Packable):
     """openaimodel.py:774-1319 — same constructor, same module tree, same state dict."""
 
@@ -320,6 +331,19 @@ class UNetModel3D(nn.Module, Packable):
                                  zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
         self._init_packable()
 
+    def invalidate_packed(self):
+        super().invalidate_packed()
+        self.__dict__.pop("_text_proj", None)
+
+    def _project_text(self, rt: Runtime):
+        """Text K/V of every cross-attention site of this network, batched (attention.TextKVProjector)."""
+        from .attention import TextKVProjector
+        tp = self.__dict__.get("_text_proj")
+        if tp is None:
+            tp = TextKVProjector(_OwnBlocks(self))
+            self.__dict__["_text_proj"] = tp
+        tp.run(rt)
+
     # ---- packed parameters owned by the network itself (time embedding MLP, output head)
     def _pack(self):
         te = self.time_embed
@@ -358,10 +382,16 @@ class UNetModel3D(nn.Module, Packable):
         rt.be.nchw_to_tokens_f16(x32, C, None, 0, F, H * W, cp, t16)
         return Act(F, H, W, cp, f16=t16)
 
+    def _own_blocks(self):
+        for name in ("input_blocks", "middle_block", "output_blocks"):
+            if hasattr(self, name):
+                yield getattr(self, name)
+
     def _run_unet(self, rt: Runtime, x16: Act, emb32: torch.Tensor, control) -> torch.Tensor:
         """controlmodel.py:186-202 / openaimodel.py:1305-1319 on tokens.  `control` is None, the list of ControlNet
         residuals, or a callable returning that list (called after the middle block: the join point when the
         ControlNet runs on a second stream)."""
+        self._project_text(rt)
         hs, h = [], x16
         nb = len(self.input_blocks)
         for i, module in enumerate(self.input_blocks):

@@ -20,15 +20,21 @@
 // 2. attn_temporal_kernel: self-attention over the T <= 8 frames of one pixel.  25 GFLOP per step
 //    in total, so it is a bandwidth-bound VALU kernel: 8 lanes per (token, head), 16-byte loads.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int QT = 128;   // queries per workgroup (4 waves x 32)
-constexpr int KT = 64;    // keys per tile
+constexpr int KT = 64;    // keys per tile; a workgroup of NW waves serves NW*32 queries that share every K/V tile
 
 __device__ __forceinline__ int kperm(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
 
-__global__ __launch_bounds__(256) void attn_views_kernel(const PncAttnParams p) {
+// NW waves per workgroup, QB blocks of 32 queries per wave: a workgroup serves NW*QB*32 queries that share every
+// K/V tile, and with QB = 2 every K / V^T fragment read from LDS feeds two MFMAs (the inner loop is LDS-read bound).
+template <int NW, int QB>
+__global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams p) {
+    constexpr int QT = NW * QB * 32;
+    constexpr int ROWS_PER_IT = NW * 8;          // K / V^T rows staged per iteration (8 rows per wave)
+    constexpr int ST_IT = 64 / ROWS_PER_IT;      // 2 (4 waves) or 1 (8 waves)
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];   // [stage][K | Vt][64 rows x 128 B]
     const half_t* __restrict__ Q = reinterpret_cast<const half_t*>(p.q);
     const half_t* __restrict__ K = reinterpret_cast<const half_t*>(p.k);
@@ -44,48 +50,57 @@ __global__ __launch_bounds__(256) void attn_views_kernel(const PncAttnParams p) 
     const bool vec_v = ((kvWv & 7) == 0) && ((p.kvW & 7) == 0) && ((p.ldvt & 7) == 0) && ((p.vt_gstride & 7) == 0);
     const int kvg = g / p.q_per_kv;
     const int hc = head * 64;
-
-    // ---- this lane's query (column of S^T / O^T) ----
-    const int ql = qtile * QT + wave * 32 + (lane & 31);   // view-local query index
-    const bool qok = ql < Nq;
-    const int qlc = qok ? ql : (Nq - 1);
-    const int qy = qlc / Wv, qx = view * Wv + (qlc - qy * Wv);
-    const int64_t qrow = ((int64_t)g * p.H + qy) * p.W + qx;
     const int grp = lane >> 5;
-    half8v qf[4];
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds)
-        qf[ds] = *reinterpret_cast<const half8v*>(Q + qrow * p.ldq + hc + ds * 16 + grp * 8);
 
-    f32x16 oacc[2];
+    // ---- this lane's queries (columns of S^T / O^T): one per query block ----
+    bool qok[QB];
+    int64_t qrow[QB];
+    half8v qf[QB][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.0f; oacc[1][r] = 0.0f; }
-    float mrun = -1e30f, lrun = 0.0f;
+    for (int qb = 0; qb < QB; ++qb) {
+        const int ql = qtile * QT + (wave * QB + qb) * 32 + (lane & 31);   // view-local query index
+        qok[qb] = ql < Nq;
+        const int qlc = qok[qb] ? ql : (Nq - 1);
+        const int qy = qlc / Wv, qx = view * Wv + (qlc - qy * Wv);
+        qrow[qb] = ((int64_t)g * p.H + qy) * p.W + qx;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds)
+            qf[qb][ds] = *reinterpret_cast<const half8v*>(Q + qrow[qb] * p.ldq + hc + ds * 16 + grp * 8);
+    }
+
+    f32x16 oacc[QB][2];
+    float mrun[QB], lrun[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        mrun[qb] = -1e30f; lrun[qb] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[qb][0][r] = 0.0f; oacc[qb][1][r] = 0.0f; }
+    }
     const float sc = p.scale * 1.44269504088896340736f;   // exp2 domain
 
-    // ---- staging assignment: 16-B chunk column sc8 of rows sr and sr+32 ----
+    // ---- staging assignment: 16-B chunk column sc8 of rows sr (+ ROWS_PER_IT) ----
     const int sc8 = tid & 7, sr = tid >> 3;
     const int nseg = p.nseg[view];
     const int tiles_per_seg = (Nkv + KT - 1) / KT;
     const int ntiles = nseg * tiles_per_seg;
 
-    half8v rk[2], rv[2];
+    half8v rk[ST_IT], rv[ST_IT];
     auto load_tile = [&](int t) {
         const int s = t / tiles_per_seg, tt = t - s * tiles_per_seg;
         const int kview = p.seg[view][s];
         const int key0 = tt * KT;
         half8v z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            // K: row = key (sr + 32 i), chunk = 8 channels
-            const int key = key0 + sr + 32 * i;
+        for (int i = 0; i < ST_IT; ++i) {
+            // K: row = key, chunk = 8 channels
+            const int key = key0 + sr + ROWS_PER_IT * i;
             if (key < Nkv) {
                 const int ky = key / kvWv, kx = kview * kvWv + (key - ky * kvWv);
                 const int64_t krow = (int64_t)kvg * p.kv_rows_per_group + (int64_t)ky * p.kvW + kx;
                 rk[i] = *reinterpret_cast<const half8v*>(K + krow * p.ldk + hc + sc8 * 8);
             } else rk[i] = z;
-            // V^T: row = channel d (sr + 32 i), chunk = 8 consecutive keys
-            const int d = sr + 32 * i;
+            // V^T: row = channel d, chunk = 8 consecutive keys
+            const int d = sr + ROWS_PER_IT * i;
             const int kc = key0 + sc8 * 8;
             if (kc < Nkv) {
                 const half_t* vrow = VT + (int64_t)kvg * p.vt_gstride + (int64_t)(hc + d) * p.ldvt;
@@ -93,16 +108,16 @@ __global__ __launch_bounds__(256) void attn_views_kernel(const PncAttnParams p) 
                     const int ky = kc / kvWv, kx = kview * kvWv + (kc - ky * kvWv);
                     rv[i] = *reinterpret_cast<const half8v*>(vrow + (int64_t)ky * p.kvW + kx);
                 } else {              // narrow views (< 8 columns or unaligned): gather key by key
-                    half8v g = z;
+                    half8v gth = z;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int key = kc + e;
-                        if (key < Nkv) {
-                            const int ky = key / kvWv, kx = kview * kvWv + (key - ky * kvWv);
-                            g[e] = vrow[(int64_t)ky * p.kvW + kx];
+                        const int key2 = kc + e;
+                        if (key2 < Nkv) {
+                            const int ky = key2 / kvWv, kx = kview * kvWv + (key2 - ky * kvWv);
+                            gth[e] = vrow[(int64_t)ky * p.kvW + kx];
                         }
                     }
-                    rv[i] = g;
+                    rv[i] = gth;
                 }
             } else rv[i] = z;
         }
@@ -111,9 +126,9 @@ __global__ __launch_bounds__(256) void attn_views_kernel(const PncAttnParams p) 
         char* sk = smem + stage * (2 * KT * 128);
         char* sv = sk + KT * 128;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<half8v*>(sk + lds_off128(sr + 32 * i, sc8)) = rk[i];
-            *reinterpret_cast<half8v*>(sv + lds_off128(sr + 32 * i, sc8)) = rv[i];
+        for (int i = 0; i < ST_IT; ++i) {
+            *reinterpret_cast<half8v*>(sk + lds_off128(sr + ROWS_PER_IT * i, sc8)) = rk[i];
+            *reinterpret_cast<half8v*>(sv + lds_off128(sr + ROWS_PER_IT * i, sc8)) = rv[i];
         }
     };
 
@@ -133,59 +148,67 @@ __global__ __launch_bounds__(256) void attn_views_kernel(const PncAttnParams p) 
         const int tt = t % tiles_per_seg;
         const int key0 = tt * KT;
 
-        // ---- S^T = K Q^T : two 32-key halves ----
-        f32x16 s[2];
+        // ---- S^T = K Q^T : two 32-key halves; every K fragment feeds the MFMAs of all query blocks ----
+        f32x16 s[QB][2];
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kh][r] = 0.0f;
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[qb][kh][r] = 0.0f;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int ds = 0; ds < 4; ++ds) {
                 const half8v kf = *reinterpret_cast<const half8v*>(
                     sk + lds_off128(kh * 32 + krow_lds, ds * 2 + grp));
-                s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ds], s[kh], 0, 0, 0);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    s[qb][kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ds], s[qb][kh], 0, 0, 0);
             }
-        }
         // lane holds keys key0 + kh*32 + grp*16 + r  (r = 0..15).  Scores stay raw; the softmax scale is folded
         // into the exp2 argument (one fma per score).  Masking only runs on the tile that crosses kv_valid.
-        if (key0 + KT > p.kv_valid) {
+        half8v pf[QB][2][2];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (key0 + KT > p.kv_valid) {
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key0 + kh * 32 + grp * 16 + r >= p.kv_valid) s[qb][kh][r] = -1e30f;
+            }
+            float tmax = -1e30f;
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (key0 + kh * 32 + grp * 16 + r >= p.kv_valid) s[kh][r] = -1e30f;
-        }
-        float tmax = -1e30f;
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[qb][kh][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sc;          // scaled (exp2) domain; masked -> -inf-ish
+            // running max: rescale the accumulators only when some query of the wave actually raised its max
+            if (__builtin_amdgcn_ballot_w64(tmax > mrun[qb]) != 0) {
+                const float mnew = fmaxf(mrun[qb], tmax);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[qb] - mnew);
+                mrun[qb] = mnew;
+                lrun[qb] *= alpha;
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
+                for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kh][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sc;              // scaled (exp2) domain; masked -> -inf-ish
-        // running max: rescale the accumulators only when some query of the wave actually raised its max
-        if (__builtin_amdgcn_ballot_w64(tmax > mrun) != 0) {
-            const float mnew = fmaxf(mrun, tmax);
-            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-            mrun = mnew;
-            lrun *= alpha;
-#pragma unroll
-            for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dh][r] *= alpha;
-        }
-        float psum = 0.0f;
-        half8v pf[2][2];
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // masked entries: fma(-1e30, sc, -mrun) -> exp2 -> 0 (mrun is finite once any key is valid)
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kh][r], sc, -mrun));
-                psum += pv;
-                pf[kh][r >> 3][r & 7] = (half_t)pv;
+                    for (int r = 0; r < 16; ++r) oacc[qb][dh][r] *= alpha;
             }
-        lrun += psum;
+            float psum = 0.0f;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // masked entries: fma(-1e30, sc, -mrun) -> exp2 -> 0 (mrun is finite once any key is valid)
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[qb][kh][r], sc, -mrun[qb]));
+                    psum += pv;
+                    pf[qb][kh][r >> 3][r & 7] = (half_t)pv;
+                }
+            lrun[qb] += psum;
+        }
 
-        // ---- O^T += V^T P^T ----
+        // ---- O^T += V^T P^T : every V^T fragment feeds the MFMAs of all query blocks ----
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
@@ -194,26 +217,31 @@ __global__ __launch_bounds__(256) void attn_views_kernel(const PncAttnParams p) 
                 for (int ss = 0; ss < 2; ++ss) {
                     const half8v vf = *reinterpret_cast<const half8v*>(
                         sv + lds_off128(dh * 32 + frow, kh * 4 + grp * 2 + ss));
-                    oacc[dh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kh][ss], oacc[dh], 0, 0, 0);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        oacc[qb][dh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kh][ss], oacc[qb][dh], 0, 0, 0);
                 }
         if (more) store_tile((t + 1) & 1);
         __syncthreads();
     }
 
-    // ---- normalise and store: lane owns query ql, channels d = 32*dh + mfma32_row(r, lane) ----
-    const float ltot = lrun + __shfl_xor(lrun, 32, 64);
-    const float inv = ltot > 0.0f ? 1.0f / ltot : 0.0f;
-    if (qok) {
-        half_t* orow = O + qrow * p.ldo + hc;
+    // ---- normalise and store: lane owns its queries, channels d = 32*dh + mfma32_row(r, lane) ----
 #pragma unroll
-        for (int dh = 0; dh < 2; ++dh)
+    for (int qb = 0; qb < QB; ++qb) {
+        const float ltot = lrun[qb] + __shfl_xor(lrun[qb], 32, 64);
+        const float inv = ltot > 0.0f ? 1.0f / ltot : 0.0f;
+        if (qok[qb]) {
+            half_t* orow = O + qrow[qb] * p.ldo + hc;
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                half4v h;
+            for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) h[q] = (half_t)(oacc[dh][r4 * 4 + q] * inv);
-                *reinterpret_cast<half4v*>(orow + dh * 32 + 8 * r4 + 4 * grp) = h;
-            }
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    half4v h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h[q] = (half_t)(oacc[qb][dh][r4 * 4 + q] * inv);
+                    *reinterpret_cast<half4v*>(orow + dh * 32 + 8 * r4 + 4 * grp) = h;
+                }
+        }
     }
 }
 
@@ -311,8 +339,25 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
             if (p.seg[v][s] < 0 || p.seg[v][s] >= p.kv_views) return PNC_EINVAL;
     }
     const int Nq = p.H * (p.W / p.views);
-    dim3 grid((Nq + QT - 1) / QT, p.views, p.groups * p.heads);
-    hipLaunchKernelGGL(attn_views_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    // variants: (waves, query blocks per wave) -> queries per workgroup.  Large views: 8 waves x 2 blocks (512 queries
+    // share a K/V tile and every fragment read feeds two MFMAs: 600-670 TFLOP/s at level 0 vs 470-500 for 4 x 1);
+    // mid-size: 8 x 1 (256); small views: 4 x 1 (128).  Measured in profiles/round1/kbench_attn_variants.log.
+    static const int force = getenv("PNC_ATTN_VARIANT") ? atoi(getenv("PNC_ATTN_VARIANT")) : 0;
+    const int variant = force ? force : (Nq >= 512 ? 82 : (Nq >= 256 ? 81 : 41));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (variant == 42) {
+        dim3 grid((Nq + 255) / 256, p.views, p.groups * p.heads);
+        hipLaunchKernelGGL((attn_views_kernel<4, 2>), grid, dim3(256), 0, st, p);
+    } else if (variant == 82) {
+        dim3 grid((Nq + 511) / 512, p.views, p.groups * p.heads);
+        hipLaunchKernelGGL((attn_views_kernel<8, 2>), grid, dim3(512), 0, st, p);
+    } else if (variant == 81) {
+        dim3 grid((Nq + 255) / 256, p.views, p.groups * p.heads);
+        hipLaunchKernelGGL((attn_views_kernel<8, 1>), grid, dim3(512), 0, st, p);
+    } else {
+        dim3 grid((Nq + 127) / 128, p.views, p.groups * p.heads);
+        hipLaunchKernelGGL((attn_views_kernel<4, 1>), grid, dim3(256), 0, st, p);
+    }
     return pnc_launch_status();
 }
 

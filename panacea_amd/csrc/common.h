@@ -26,13 +26,14 @@ __device__ __forceinline__ int lds_off128(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions): the results are rounded to fp16
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 // erf-exact GELU (attention.py:98 uses F.gelu's default).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7,
 // one exp + one rcp + 5 fma) instead of libm's erff (~3x the instructions): the result is rounded to fp16
 // (rel. 4.9e-4) right after, and the GEGLU epilogue runs once per 2x(M x 4C) accumulator pair.
 __device__ __forceinline__ float erf_as_f(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);

@@ -176,7 +176,8 @@ def _qkv(G, N, C, seed):
 @pytest.mark.parametrize("G,H,W,heads,segs", [
     (2, 8, 96, 1, INTRA), (2, 8, 96, 2, CROSS), (1, 4, 48, 2, INTRA), (1, 4, 48, 1, CROSS),
     (1, 32, 384, 1, CROSS), (2, 16, 16, 1, [[0]]), (1, 16, 192, 2, INTRA),
-    (2, 2, 24, 1, CROSS), (1, 1, 12, 2, INTRA), (2, 3, 36, 1, CROSS), (1, 5, 10, 1, [[0]])])
+    (2, 2, 24, 1, CROSS), (1, 1, 12, 2, INTRA), (2, 3, 36, 1, CROSS), (1, 5, 10, 1, [[0]]),
+    (1, 24, 150, 1, CROSS), (1, 17, 120, 2, INTRA)])
 def test_attn_views_self(G, H, W, heads, segs):
     C, N, views = heads * 64, H * W, len(segs)
     q, k, _, vt = _qkv(G, N, C, 5)
@@ -188,6 +189,14 @@ def test_attn_views_self(G, H, W, heads, segs):
     emu.attn_views(q, C, k, C, vt, N, C * N, oe, C, **kw)
     torch.cuda.synchronize()
     check("attn_views", oh, oe, 3e-3)
+
+
+@pytest.mark.parametrize("variant", ["41", "81", "42", "82"])
+@pytest.mark.parametrize("G,H,W,heads,segs", [(1, 24, 150, 1, CROSS), (2, 8, 96, 2, CROSS), (1, 3, 36, 1, INTRA)])
+def test_attn_views_every_variant(monkeypatch, variant, G, H, W, heads, segs):
+    # (waves, query blocks per wave) variants of the kernel, forced regardless of the size heuristic
+    monkeypatch.setenv("PNC_ATTN_VARIANT", variant)
+    test_attn_views_self(G, H, W, heads, segs)
 
 
 def test_attn_views_sharp_softmax():

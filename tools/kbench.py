@@ -75,14 +75,14 @@ def bench_gemm(flt):
             x, w = h16(F, H, W, C), h16(C, 9 * C)
             o = torch.empty(M, C, device=DEV)
             conv = dict(Cin=C, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0)
-            report(tag, timeit(lambda: hip.gemm(x, w, M=M, N=C, K=9 * C, a_mode=hip.A_CONV3X3, conv=conv, out32=o, ldc32=C)),
+            report(tag, timeit(lambda: hip.gemm(x, w, M=M, N=C, K=9 * C, a_mode=hip.A_CONV3X3, conv=conv, out32=o, ldc32=C, act=ABL)),
                    flops=2.0 * M * C * 9 * C)
         tag = f"conv1d_t L{li} C={C}"
         if not flt or flt in tag:
             x, w = h16(M, C), h16(C, 3 * C)
             o = torch.zeros(M, C, device=DEV)
             report(tag, timeit(lambda: hip.gemm(x, w, M=M, N=C, K=3 * C, a_mode=hip.A_CONV1D_T,
-                                                tconv=dict(C=C, T=8, Npix=H * W), res1=o, ldr1=C, out32=o, ldc32=C)),
+                                                tconv=dict(C=C, T=8, Npix=H * W), res1=o, ldr1=C, out32=o, ldc32=C, act=ABL)),
                    flops=2.0 * M * C * 3 * C)
 
 

@@ -85,9 +85,17 @@ typedef struct PncGemmParams {
     int32_t n_split;        /* multiple of 128 (or >= N when out16t == NULL) */
     int32_t act;
     int32_t geglu;
+    /* split-K workspace, caller-owned (NULL / 0: K is never split).  Small-M shapes (the 4x48 level: M = 3072)
+     * fill only 60-120 of the 256 CUs with one K loop per output tile; with a workspace of
+     * pnc_gemm_workspace_floats() floats the library runs `s` K-slices per tile and sums the fp32 partials in a
+     * fixed order (deterministic) in a second launch that also applies the epilogue. */
+    float*  ws;
+    int64_t ws_floats;
 } PncGemmParams;
 
 int pnc_gemm_f16(const PncGemmParams* p, void* stream);
+/* floats of workspace with which pnc_gemm_f16 would split K for this problem (0: it would not) */
+int64_t pnc_gemm_workspace_floats(const PncGemmParams* p);
 
 /* ------------------------------------------------------------------------- *
  * 2. View-sliced flash attention, head dim 64, fp16 in/out, fp32 softmax/acc.

@@ -42,7 +42,17 @@ __device__ __forceinline__ float erf_as_f(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf_f(float v) {
-    return 0.5f * v * (1.0f + erf_as_f(v * 0.70710678118654752440f));
+    // v * Phi(v) with Phi(|v|) = 1 - q, q = erfc(|v|/sqrt2)/2 (same A&S polynomial, coefficients halved):
+    // v >= 0: v - v q;  v < 0: v q = -|v| q   ->   max(v, 0) - |v| q   (no copysign / 1+erf / 0.5 v)
+    const float av = fabsf(v);
+    const float ax = av * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    poly = fmaf(poly, t, 0.5f * 1.421413741f);
+    poly = fmaf(poly, t, 0.5f * -0.284496736f);
+    poly = fmaf(poly, t, 0.5f * 0.254829592f);
+    const float q = poly * t * __expf(-ax * ax);
+    return fmaf(-av, q, fmaxf(v, 0.0f));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -148,6 +148,115 @@ __device__ __forceinline__ void epilogue_rowmajor(const PncGemmParams& p, f32x16
                         ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][jc + j][r];
                 }
             });
+            if constexpr (!GEGLU) {
+                if (p.res1 || p.res2 || p.rowbias) {
+                    // Epilogues that READ global memory (residuals, per-frame row bias).  In place (res1 == out32) a
+                    // load may not move above an earlier store, so a load-add-store loop pays one full HBM latency per
+                    // 8-row pass (24 passes per 256x320 tile: most of a K = 320 tile's lifetime).  Instead all global
+                    // loads of the slab (up to two streams x NP passes) are issued here, before the LDS reads.
+                    const bool vrb = ((p.N & 3) == 0) && (((uintptr_t)p.rowbias & 15) == 0);
+                    const float* xs = p.res1 ? p.res1 : (p.res2 ? p.res2 : nullptr);      // stream X: first residual
+                    const int ldx = p.res1 ? p.ldr1 : p.ldr2;
+                    const bool vx = p.res1 ? vr1 : vr2;
+                    const bool y_is_res2 = p.res1 && p.res2;
+                    const bool y_is_rb = !y_is_res2 && p.rowbias;                         // stream Y: res2 or row bias
+                    const bool rb_inloop = y_is_res2 && p.rowbias;                        // all three: bias stays in-loop
+                    f32x4 x0[NP], x1[NP], y0[NP], y1[NP];
+#pragma unroll
+                    for (int ps = 0; ps < NP; ++ps) {
+                        const int m = mw + i * 32 + ps * RPP + rl;
+                        const bool ok = lane_on && m < p.M && full8;
+                        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                        x0[ps] = z; x1[ps] = z; y0[ps] = z; y1[ps] = z;
+                        if (ok && xs && vx) {
+                            const float* rp = xs + (int64_t)m * ldx + ncol;
+                            x0[ps] = *reinterpret_cast<const f32x4*>(rp);
+                            x1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+                        }
+                        if (ok && y_is_res2 && vr2) {
+                            const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
+                            y0[ps] = *reinterpret_cast<const f32x4*>(rp);
+                            y1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+                        }
+                        if (ok && y_is_rb && vrb) {
+                            const float* rp = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
+                            y0[ps] = *reinterpret_cast<const f32x4*>(rp);
+                            y1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int ps = 0; ps < NP; ++ps) {
+                        const float* src = ep + (ps * RPP + rl) * EPITCH + cl * 8;
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+                        const int m = mw + i * 32 + ps * RPP + rl;
+                        if (!lane_on || m >= p.M) continue;
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = a0[e] + bcol[e]; v[e + 4] = a1[e] + bcol[e + 4]; }
+                        if (p.rowbias) {
+                            if (y_is_rb && full8 && vrb) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v[e] += y0[ps][e]; v[e + 4] += y1[ps][e]; }
+                            } else {
+                                const float* rb = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) if (ncol + e < Nout) v[e] += rb[e];
+                            }
+                        }
+                        (void)rb_inloop;
+                        if (act == PNC_ACT_SILU) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                        }
+                        if (xs) {                       // first residual (res1, or res2 when it is the only one)
+                            if (full8 && vx) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v[e] += x0[ps][e]; v[e + 4] += x1[ps][e]; }
+                            } else {
+                                const float* rp = xs + (int64_t)m * ldx + ncol;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) if (ncol + e < Nout) v[e] += rp[e];
+                            }
+                        }
+                        if (y_is_res2) {
+                            if (full8 && vr2) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v[e] += y0[ps][e]; v[e + 4] += y1[ps][e]; }
+                            } else {
+                                const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) if (ncol + e < Nout) v[e] += rp[e];
+                            }
+                        }
+                        if (ab_nostore) { if (v[0] == 123.456f) p.out32[0] = v[1] + v[5]; continue; }
+                        if (p.out32) {
+                            float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
+                            if (full8 && v32) {
+                                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                                *reinterpret_cast<f32x4*>(op) = o0;
+                                *reinterpret_cast<f32x4*>(op + 4) = o1;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) if (ncol + e < Nout) op[e] = v[e];
+                            }
+                        }
+                        if (out16) {
+                            half_t* op = out16 + (int64_t)m * p.ldc16 + ncol;
+                            if (full8 && v16) {
+                                half8v o;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+                                *reinterpret_cast<half8v*>(op) = o;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) if (ncol + e < Nout) op[e] = (half_t)v[e];
+                            }
+                        }
+                    }
+                    return;
+                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             f32x4 a0[NP], a1[NP], g0[NP], g1[NP];
 #pragma unroll
@@ -236,7 +345,8 @@ __device__ __forceinline__ void epilogue_rowmajor(const PncGemmParams& p, f32x16
 }
 
 template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams p) {
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams pin, const int ksplit) {
+    PncGemmParams p = pin;
     constexpr int NW = WGM * WGN;                          // waves per workgroup
     constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
     constexpr int RPI = NW * 8;                            // rows staged per DMA iteration (8 rows per wave)
@@ -253,9 +363,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
 
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    // split K (ksplit > 1): block b = (slice, tile); slice s runs K tiles [s*nt/S, (s+1)*nt/S) and writes its raw fp32
+    // accumulators to ws[s][M][N]; splitk_reduce_kernel sums the slices in order and applies the epilogue
+    const int ntile_mn = tiles_m * tiles_n;
+    const int blk = xcd_remap(blockIdx.x, ntile_mn * ksplit);
+    const int kslice = blk / ntile_mn, tile = blk - kslice * ntile_mn;
     const int tn = tile % tiles_n, tm = tile / tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    const int ntiles_all = (p.K + BK - 1) / BK;
+    const int kt_begin = (int)((int64_t)kslice * ntiles_all / ksplit);
+    const int ntiles = (int)((int64_t)(kslice + 1) * ntiles_all / ksplit) - kt_begin;
+    if (ksplit > 1) {            // raw partial sums; the reduce launch owns bias / residuals / outputs
+        p.out32 = p.ws + (int64_t)kslice * p.M * p.N;
+        p.ldc32 = p.N;
+        p.bias = nullptr; p.rowbias = nullptr; p.res1 = nullptr; p.res2 = nullptr;
+        p.out16 = nullptr; p.out16t = nullptr; p.n_split = p.N; p.act &= ~0xff;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -273,7 +396,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         const int n = n0 + i * RPI + srow;
         wrow[i] = (n < p.N) ? Wt + (int64_t)n * p.K : nullptr;
     }
-    auto issue_tile = [&](int kt, int stage) {
+    auto issue_tile = [&](int kt_local, int stage) {
+        const int kt = kt_begin + kt_local;
         const int kc = kt * BK + schunk * 8;
         char* sa = smem + stage * STAGE + wave * 1024;
         char* sb = sa + A_BYTES;
@@ -292,7 +416,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int ntiles = (p.K + BK - 1) / BK;
     const int frow = lane & 31, fk = lane >> 5;
     // timing-experiment switches (tools/kbench.py PNC_ABLATE): results are garbage when any is set
     const bool ab_nodma = (p.act & 0x100) != 0, ab_nomfma = (p.act & 0x200) != 0, ab_noepi = (p.act & 0x400) != 0;
@@ -439,8 +562,61 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     }
 }
 
+// Second launch of a split-K GEMM: out = epilogue(sum_s ws[s]) with the slices summed in index order (deterministic).
+// One lane owns 8 consecutive columns of one row (N % 8 == 0 is a precondition of splitting).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const PncGemmParams p, const int ksplit) {
+    const int n8 = p.N >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.M * n8) return;
+    const int m = (int)(idx / n8), ncol = (int)(idx - (int64_t)m * n8) * 8;
+    const int64_t mn = (int64_t)p.M * p.N;
+    const float* src = p.ws + (int64_t)m * p.N + ncol;
+    f32x4 s0 = *reinterpret_cast<const f32x4*>(src), s1 = *reinterpret_cast<const f32x4*>(src + 4);
+    for (int s = 1; s < ksplit; ++s) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src + s * mn), t1 = *reinterpret_cast<const f32x4*>(src + s * mn + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0[e] += t0[e]; s1[e] += t1[e]; }
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = s0[e]; v[e + 4] = s1[e]; }
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p.bias[ncol + e];
+    }
+    if (p.rowbias) {
+        const float* rb = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rb[e];
+    }
+    if ((p.act & 0xff) == PNC_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+    }
+    if (p.res1) {
+        const float* rp = p.res1 + (int64_t)m * p.ldr1 + ncol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rp[e];
+    }
+    if (p.res2) {
+        const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rp[e];
+    }
+    if (p.out32) {
+        float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) op[e] = v[e];
+    }
+    if (p.out16) {
+        half_t* op = reinterpret_cast<half_t*>(p.out16) + (int64_t)m * p.ldc16 + ncol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) op[e] = (half_t)v[e];
+    }
+}
+
 template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE>
-int launch(const PncGemmParams& p, hipStream_t st) {
+int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
     constexpr int lds = STAGES * (BM + BN) * 128;
     constexpr int threads = 64 * WGM * WGN;
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
@@ -453,7 +629,11 @@ int launch(const PncGemmParams& p, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(threads), lds, st, p, ksplit);
+    if (ksplit > 1) {
+        const int64_t work = (int64_t)p.M * (p.N >> 3);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, p, ksplit);
+    }
     return pnc_launch_status();
 }
 
@@ -469,10 +649,30 @@ static inline double tile_score(long tiles, int slots, double eff) {
     return eff * (double)tiles / (double)(rounds * slots);
 }
 
+// Split K when one K loop per output tile would leave most CUs idle (the M = 3072 level: 60 tiles of 256x256).
+// Returns the number of K slices (1 = do not split) for the 256x256 tile.  Slices keep >= 12 K tiles each so that the
+// fp32 partial round trip (2 x 4 B per output and slice) stays small next to the K loop.
+static inline int splitk_slices(const PncGemmParams& p) {
+    if (p.geglu || p.out16t || (p.N % 256) || (p.N % 8)) return 1;
+    if ((p.out32 && (p.ldc32 % 4)) || (p.out16 && (p.ldc16 % 8))) return 1;
+    const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
+    const int ktiles = (p.K + BK - 1) / BK;
+    if (tiles > 96 || ktiles < 48) return 1;
+    int s = (int)(256 / tiles);
+    if (s > ktiles / 12) s = ktiles / 12;
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : s;
+}
+
 template <int AMODE>
 int dispatch(const PncGemmParams& p, hipStream_t st) {
     static const int force = getenv("PNC_GEMM_TILE") ? atoi(getenv("PNC_GEMM_TILE")) : 0;   // A/B runs
     if (p.N <= 32 && !p.geglu) return launch<AMODE, 128, 32, 4, 1, 2, true>(p, st);
+    if (!force || force == 7) {
+        const int ks = splitk_slices(p);
+        if (ks > 1 && p.ws && p.ws_floats >= (int64_t)ks * p.M * p.N)
+            return launch<AMODE, 256, 256, 4, 2, 2, true>(p, st, ks);
+    }
     const long mt256 = (p.M + 255) / 256, mt128 = (p.M + 127) / 128;
     const bool w320_ok = !p.geglu && (p.N % 320 == 0) && (!p.out16t || p.n_split % 320 == 0);
     const bool w256_ok = (p.N % 256 == 0) && (!p.out16t || p.n_split % 256 == 0);
@@ -496,6 +696,13 @@ int dispatch(const PncGemmParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int64_t pnc_gemm_workspace_floats(const PncGemmParams* pp) {
+    if (!pp || pp->M <= 0 || pp->N <= 0 || pp->K <= 0) return 0;
+    if (pp->N <= 32 && !pp->geglu) return 0;
+    const int ks = splitk_slices(*pp);
+    return ks > 1 ? (int64_t)ks * pp->M * pp->N : 0;
+}
 
 extern "C" int pnc_gemm_f16(const PncGemmParams* pp, void* stream) {
     if (!pp) return PNC_EINVAL;

@@ -46,6 +46,7 @@ class GemmParams(C.Structure):
         ("out16", C.c_void_p), ("ldc16", C.c_int32),
         ("out16t", C.c_void_p), ("ldt", C.c_int32), ("t_rows", C.c_int32), ("t_gstride", C.c_int64),
         ("n_split", C.c_int32), ("act", C.c_int32), ("geglu", C.c_int32),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 
@@ -68,6 +69,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGNATURES = {
     "pnc_version": (C.c_char_p, []),
     "pnc_gemm_f16": (_I, [C.POINTER(GemmParams), _P]),
+    "pnc_gemm_workspace_floats": (_L, [C.POINTER(GemmParams)]),
     "pnc_attn_views_f16": (_I, [C.POINTER(AttnParams), _P]),
     "pnc_attn_temporal_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "pnc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
@@ -209,6 +211,12 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
     p.out16t, p.ldt, p.t_rows, p.t_gstride = _ptr(out16t), ldt, t_rows, t_gstride
     p.n_split = n_split if out16t is not None else N
     p.act, p.geglu = act, int(geglu)
+    lib = load()
+    nws = lib.pnc_gemm_workspace_floats(C.byref(p))      # > 0: the library wants to split K (small-M shapes)
+    ws = None
+    if nws > 0:
+        ws = torch.empty(nws, device=a16.device, dtype=torch.float32)
+        p.ws, p.ws_floats = _ptr(ws), nws
     fam = ("gemm_plain", "gemm_conv3x3", "gemm_conv1d_t")[a_mode]
     _check(_timed(fam, 2.0 * M * N * K, 0.0, load().pnc_gemm_f16, C.byref(p), _stream()), "pnc_gemm_f16")
 

@@ -13,12 +13,13 @@ from panacea_amd import configs, hip
 def test_cabi_library_loads_and_exports_header_symbols():
     lib = hip.load()
     syms = hip.header_symbols()
-    assert len(syms) >= 15 and set(syms) == set(hip._SIGNATURES)
+    assert len(syms) >= 16 and set(syms) == set(hip._SIGNATURES)
     for s in syms:
         assert getattr(lib, s) is not None
     assert lib.pnc_version().decode().startswith("panacea_hip")
     # struct layouts of the two parameter blocks (must match include/panacea_hip.h)
-    assert ctypes.sizeof(hip.GemmParams) == 200 and hip.GemmParams.t_gstride.offset == 176
+    assert ctypes.sizeof(hip.GemmParams) == 216 and hip.GemmParams.t_gstride.offset == 176
+    assert hip.GemmParams.ws.offset == 200 and hip.GemmParams.ws_floats.offset == 208
     assert ctypes.sizeof(hip.AttnParams) == 216 and hip.AttnParams.scale.offset == 208
 
 
@@ -27,6 +28,13 @@ def test_argument_validation_without_gpu():
     lib = hip.load()
     p = hip.GemmParams()
     assert lib.pnc_gemm_f16(ctypes.byref(p), None) == -1                  # PNC_EINVAL: null operands
+    # split-K is offered only to small-M / long-K problems (the 4x48 level), never to GEGLU or V^T outputs
+    p.M, p.N, p.K = 3072, 1280, 11520
+    assert lib.pnc_gemm_workspace_floats(ctypes.byref(p)) == 4 * 3072 * 1280
+    p.geglu = 1
+    assert lib.pnc_gemm_workspace_floats(ctypes.byref(p)) == 0
+    p.geglu, p.M = 0, 12288
+    assert lib.pnc_gemm_workspace_floats(ctypes.byref(p)) == 0
     assert lib.pnc_attn_temporal_f16(None, 0, None, 0, None, 0, None, 0, 1, 9, 1, 1, 0.125, None) == -1
     assert lib.pnc_layernorm(None, 0, 0, 0, None, None, 1e-5, None, 0, None) == -1
 

@@ -160,6 +160,63 @@ def test_gemm_conv1d_temporal(B, T, Npix, C):
     check("conv1d_t", h["o"], e["o"], 2e-3)
 
 
+# ---------------------------------------------------------------------------------------- split K
+def _splits(**kw):
+    """K slices the library would run for this problem (0 workspace -> 1 slice)."""
+    import ctypes
+    p = hip.GemmParams()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return hip.load().pnc_gemm_workspace_floats(ctypes.byref(p)) // (kw["M"] * kw["N"])
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 3136), (3072, 1280, 5120), (1000, 512, 6400)])
+def test_gemm_splitk_full_epilogue_and_determinism(M, N, K):
+    # small-M / long-K: K is cut into slices whose fp32 partials are summed in a fixed order by a second launch
+    assert _splits(M=M, N=N, K=K) >= 2
+    a = rnd(M, K, dtype=torch.float16)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    bias, rowb = rnd(N), rnd(4, N)
+    res1_init, res2 = rnd(M, N + 8), rnd(M, N)
+
+    def outs():
+        return dict(o32=res1_init.clone(), o16=torch.zeros(M, N, device=DEV, dtype=torch.float16))
+    kw = lambda o: dict(a16=a, w16=w, M=M, N=N, K=K, lda=K, bias=bias, rowbias=rowb, rb_rows=50, rb_mod=4,
+                        res1=o["o32"], ldr1=N + 8, res2=res2, ldr2=N, out32=o["o32"], ldc32=N + 8,
+                        out16=o["o16"], ldc16=N)
+    h, e = _run_both("gemm", outs, kw)
+    check("out32", h["o32"], e["o32"], 2e-3)
+    check("out16", h["o16"], e["o16"], 6e-3)
+    h2 = outs()
+    hip.gemm(**kw(h2))
+    torch.cuda.synchronize()
+    assert torch.equal(h2["o32"], h["o32"]) and torch.equal(h2["o16"], h["o16"])
+
+
+def test_gemm_splitk_conv3x3_and_conv1d():
+    F, H, W, Cin, N = 2, 8, 24, 384, 256          # K = 3456 -> 54 K tiles, 2 x 1 output tiles
+    M, K = F * H * W, 9 * Cin
+    assert _splits(M=M, N=N, K=K, a_mode=hip.A_CONV3X3) >= 2
+    x = rnd(F, H, W, Cin, dtype=torch.float16)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    bias, emb = rnd(N), rnd(F, N)
+    conv = dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0)
+    h, e = _run_both("gemm", lambda: dict(o=torch.zeros(M, N, device=DEV)), lambda o: dict(
+        a16=x, w16=w, M=M, N=N, K=K, a_mode=hip.A_CONV3X3, conv=conv, bias=bias, rowbias=emb, rb_rows=H * W, rb_mod=F,
+        out32=o["o"], ldc32=N))
+    check("conv3x3 split-K", h["o"], e["o"], 2e-3)
+    B, T, Npix, C = 1, 8, 40, 1280                # K = 3840
+    M, N, K = B * T * Npix, C, 3 * C
+    assert _splits(M=M, N=N, K=K, a_mode=hip.A_CONV1D_T) >= 2
+    x = rnd(M, C, dtype=torch.float16)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    res = rnd(M, N)
+    h, e = _run_both("gemm", lambda: dict(o=res.clone()), lambda o: dict(
+        a16=x, w16=w, M=M, N=N, K=K, a_mode=hip.A_CONV1D_T, tconv=dict(C=C, T=T, Npix=Npix), bias=rnd(N, seed=5),
+        res1=o["o"], ldr1=N, out32=o["o"], ldc32=N))
+    check("conv1d_t split-K", h["o"], e["o"], 2e-3)
+
+
 # -------------------------------------------------------------------------------------- attention
 INTRA = [[0], [1], [2], [3], [4], [5]]
 CROSS = [[5, 1], [0, 2], [1, 3], [2, 4], [3, 5], [4]]      # view 5 sees view 4 only (reference quirk)

@@ -650,18 +650,16 @@ static inline double tile_score(long tiles, int slots, double eff) {
 }
 
 // Split K when one K loop per output tile would leave most CUs idle (the M = 3072 level: 60 tiles of 256x256).
-// Returns the number of K slices (1 = do not split) for the 256x256 tile.  Slices keep >= 12 K tiles each so that the
-// fp32 partial round trip (2 x 4 B per output and slice) stays small next to the K loop.
+// Returns the number of K slices (1 = do not split) for the 256x256 tile.  The slice count is a function of K ALONE
+// and only the on/off decision looks at M, so that a batch and its halves (CFG sharding, tests) run the same K
+// partition and stay bit-identical as long as both are in the split regime.
 static inline int splitk_slices(const PncGemmParams& p) {
     if (p.geglu || p.out16t || (p.N % 256) || (p.N % 8)) return 1;
     if ((p.out32 && (p.ldc32 % 4)) || (p.out16 && (p.ldc16 % 8))) return 1;
     const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
     const int ktiles = (p.K + BK - 1) / BK;
     if (tiles > 96 || ktiles < 48) return 1;
-    int s = (int)(256 / tiles);
-    if (s > ktiles / 12) s = ktiles / 12;
-    if (s > 8) s = 8;
-    return s < 2 ? 1 : s;
+    return ktiles >= 320 ? 8 : (ktiles >= 160 ? 4 : 2);
 }
 
 template <int AMODE>

@@ -345,7 +345,8 @@ __device__ __forceinline__ void epilogue_rowmajor(const PncGemmParams& p, f32x16
 }
 
 template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams pin, const int ksplit) {
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams pin, const int ksplit,
+                                                                   const int nfull, const int tail_f) {
     PncGemmParams p = pin;
     constexpr int NW = WGM * WGN;                          // waves per workgroup
     constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
@@ -365,9 +366,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     const int tiles_m = (p.M + BM - 1) / BM;
     // split K (ksplit > 1): block b = (slice, tile); slice s runs K tiles [s*nt/S, (s+1)*nt/S) and writes its raw fp32
     // accumulators to ws[s][M][N]; splitk_reduce_kernel sums the slices in order and applies the epilogue
+    // Tail split (tail_f = 2 or 4): the last (ntile_mn - nfull) output tiles - the partial round that would leave most
+    // CUs idle - are each run by tail_f workgroups that own BM / tail_f rows of the tile: the waves of the other row
+    // groups skip their MFMAs and epilogue (their A rows are DMA'd as zero chunks), all waves still stage W.  Rows are
+    // independent in a GEMM, so the result does not depend on the split.
     const int ntile_mn = tiles_m * tiles_n;
-    const int blk = xcd_remap(blockIdx.x, ntile_mn * ksplit);
-    const int kslice = blk / ntile_mn, tile = blk - kslice * ntile_mn;
+    int kslice = 0, tile, part = 0;
+    if (ksplit > 1) {
+        const int blk = xcd_remap(blockIdx.x, ntile_mn * ksplit);
+        kslice = blk / ntile_mn; tile = blk - kslice * ntile_mn;
+    } else if ((int)blockIdx.x < nfull) {
+        tile = xcd_remap(blockIdx.x, nfull);
+    } else {
+        const int j = (int)blockIdx.x - nfull;
+        tile = nfull + j / tail_f; part = j - (j / tail_f) * tail_f;
+    }
+    const bool split_rows = (ksplit == 1) && ((int)blockIdx.x >= nfull) && (tail_f > 1);
     const int tn = tile % tiles_n, tm = tile / tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int ntiles_all = (p.K + BK - 1) / BK;
@@ -387,9 +401,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     // chunk slot ^ ((row>>1)&7), and (row>>1)&7 does not depend on i
     const int srow = wave * 8 + (lane >> 3);
     const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
+    const int rows_lo = split_rows ? part * (BM / tail_f) : 0;                 // tile-local row range of this workgroup
+    const int rows_hi = split_rows ? rows_lo + BM / tail_f : BM;
+    const bool wave_on = (wm * (MI * 32) >= rows_lo) && (wm * (MI * 32) < rows_hi);
     RowState rows[A_IT];
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) rows[i] = make_row<AMODE>(p, m0 + i * RPI + srow);
+    for (int i = 0; i < A_IT; ++i) {
+        const int r = i * RPI + srow;
+        rows[i] = make_row<AMODE>(p, m0 + r);
+        rows[i].valid = rows[i].valid && (r >= rows_lo) && (r < rows_hi);
+    }
     const half_t* wrow[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -480,7 +501,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         __syncthreads();
         for (int kt = 0; kt < ntiles; ++kt) {
             if (kt + 1 < ntiles && !ab_nodma) issue_tile(kt + 1, (kt + 1) & 1);
-            if (!ab_nomfma) compute(kt & 1);
+            if (!ab_nomfma && wave_on) compute(kt & 1);
             if (!ab_nobar) __syncthreads();
         }
     } else {
@@ -499,7 +520,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         for (int kt = 0; kt < ntiles; ++kt) {
             const bool ahead = (kt + 2) < ntiles && !ab_nodma;
             if (ahead) issue_tile(kt + 2, st == 0 ? 2 : st - 1);      // (kt + 2) % 3
-            if (!ab_nomfma) compute(st);
+            if (!ab_nomfma && wave_on) compute(st);
             if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -510,6 +531,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
 
     // ------------------------------ epilogue ------------------------------
     if (ab_noepi) { if (acc[0][0][0] == 123.456f) p.out32[0] = 1.0f; return; }
+    if (!wave_on) return;                       // row group of another workgroup (tail split)
     const int mw = m0 + wm * (MI * 32), nw = n0 + wn * (NI * 32);
     half_t* out16 = reinterpret_cast<half_t*>(p.out16);
     half_t* out16t = reinterpret_cast<half_t*>(p.out16t);
@@ -560,6 +582,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     } else {
         epilogue_rowmajor<MI, NI, false>(p, acc, ep, lane, mw, nw, ab_nostage, ab_nostore);
     }
+}
+
+// Workgroups of one geometry that are resident at once on the 256 CUs (LDS-limited: 160 KB per CU)
+template <int LDS_BYTES>
+constexpr int resident_slots() { return 256 * ((160 * 1024) / LDS_BYTES < 1 ? 1 : (160 * 1024) / LDS_BYTES > 2 ? 2 : (160 * 1024) / LDS_BYTES); }
+
+// Tail split decision: tiles = q * slots + r.  When the last, partial round holds r <= slots/2 (or /4) tiles, run each of
+// them as 2 (4) workgroups of BM/2 (BM/4) rows so that the round fills the chip: e.g. M = 49152, N = 640 with 256x320
+// tiles is 384 tiles = 1.5 rounds -> 256 full tiles + 128 tiles x 2 halves.
+template <int BM, int WGM, int LDS_BYTES>
+static inline void tail_split(int tiles, int& nfull, int& tail_f) {
+    const bool off = getenv("PNC_GEMM_NOTAIL") != nullptr;             // A/B runs, tests
+    constexpr int slots = resident_slots<LDS_BYTES>();
+    const int r = tiles % slots;
+    nfull = tiles; tail_f = 1;
+    if (off || r == 0) return;
+    if (WGM >= 4 && r * 4 <= slots) tail_f = 4;
+    else if (WGM >= 2 && r * 2 <= slots) tail_f = 2;
+    if (tail_f > 1) nfull = tiles - r;
 }
 
 // Second launch of a split-K GEMM: out = epilogue(sum_s ws[s]) with the slices summed in index order (deterministic).
@@ -629,7 +670,10 @@ int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles * ksplit), dim3(threads), lds, st, p, ksplit);
+    int nfull = tiles, tail_f = 1;
+    if (ksplit == 1) tail_split<BM, WGM, lds>(tiles, nfull, tail_f);
+    const int blocks = ksplit > 1 ? tiles * ksplit : nfull + (tiles - nfull) * tail_f;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, p, ksplit, nfull, tail_f);
     if (ksplit > 1) {
         const int64_t work = (int64_t)p.M * (p.N >> 3);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, p, ksplit);
@@ -645,8 +689,11 @@ int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
 // expected relative throughput of a geometry on `slots` concurrently resident workgroups
 static inline double tile_score(long tiles, int slots, double eff) {
     if (tiles <= 0) return 0.0;
-    const long rounds = (tiles + slots - 1) / slots;
-    return eff * (double)tiles / (double)(rounds * slots);
+    // a partial last round costs a full round, unless tail_split() can run it as half / quarter tiles (the row-split
+    // workgroups still stage the whole W tile: ~0.65 / 0.45 of a full tile's time)
+    const long q = tiles / slots, r = tiles % slots;
+    const double tail = r == 0 ? 0.0 : (r * 4 <= slots ? 0.45 : (r * 2 <= slots ? 0.65 : 1.0));
+    return eff * ((double)tiles / slots) / ((double)q + tail);
 }
 
 // Split K when one K loop per output tile would leave most CUs idle (the M = 3072 level: 60 tiles of 256x256).

@@ -160,6 +160,37 @@ def test_gemm_conv1d_temporal(B, T, Npix, C):
     check("conv1d_t", h["o"], e["o"], 2e-3)
 
 
+@pytest.mark.parametrize("M,N,K,geglu", [(1000, 320, 640, False), (49152, 640, 640, False), (700, 1280, 320, True),
+                                         (12288, 1280, 192, False)])
+def test_gemm_tail_row_split_is_bit_identical(monkeypatch, M, N, K, geglu):
+    # the partial last round of tiles is run as half / quarter tiles (BM/2, BM/4 rows per workgroup): same bits
+    a = rnd(M, K, dtype=torch.float16)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    bias, res = rnd(N), rnd(M, N)
+    No = N // 2 if geglu else N
+
+    def run():
+        o32 = res.clone() if not geglu else None
+        o16 = torch.zeros(M, No, device=DEV, dtype=torch.float16)
+        kw = dict(a16=a, w16=w, M=M, N=N, K=K, lda=K, bias=bias, out16=o16, ldc16=No, geglu=geglu)
+        if not geglu:
+            kw.update(res1=o32, ldr1=N, out32=o32, ldc32=N)
+        hip.gemm(**kw)
+        torch.cuda.synchronize()
+        return o32, o16
+    s32, s16 = run()
+    monkeypatch.setenv("PNC_GEMM_NOTAIL", "1")
+    f32, f16 = run()
+    assert torch.equal(s16, f16) and (geglu or torch.equal(s32, f32))
+    e16 = torch.zeros(M, No, device=DEV, dtype=torch.float16)
+    kw = dict(a16=a, w16=w, M=M, N=N, K=K, lda=K, bias=bias, out16=e16, ldc16=No, geglu=geglu)
+    if not geglu:
+        e32 = res.clone()
+        kw.update(res1=e32, ldr1=N, out32=e32, ldc32=N)
+    emu.gemm(**kw)
+    check("tail split vs emu", s16, e16, 6e-3)
+
+
 # ---------------------------------------------------------------------------------------- split K
 def _splits(**kw):
     """K slices the library would run for this problem (0 workspace -> 1 slice)."""

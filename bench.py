@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--device", type=int, default=None, help="override the HIP device index (default LOCAL_RANK)")
     ap.add_argument("--one-stream", action="store_true", help="do not overlap the ControlNet with the UNet encoder")
     ap.add_argument("--split-samples", action="store_true", help="issue the two CFG halves as independent stream pairs")
+    ap.add_argument("--hoist", action="store_true",
+                    help="sampler mode (SURVEY §8 f1): text K/V + ControlNet hint stem computed once per schedule, outside "
+                         "the timed steps.  NOT the headline: the default re-evaluates the whole path every step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,6 +132,9 @@ def main():
     denoiser = lambda xi, sigma, cc: den(net, xi, sigma, cc)   # noqa: E731
 
     sig_rows = [s_in * sig[j] for j in range(nsig + 1)]          # per-step sigma vectors, resident
+    if args.hoist:
+        with torch.no_grad():
+            cond, uc = sampling.hoist_invariants(net, smp.guider, cond, uc)
 
     def step_fn(xi, sigma, next_sigma):
         return smp.sampler_step(sigma, next_sigma, denoiser, xi, cond, uc)
@@ -190,7 +196,8 @@ def main():
         "config": {"workload": "BASELINE config 3: Panacea+ stage-2 UNet+ControlNet, CFG 2 x 8 frames, 6 views, latent 32x384, "
                                "hint 256x3072, Euler/LegacyDDPM 50-step schedule" if args.config == "full" else "tiny",
                    "frames_per_step": 2 * T, "parallelism": f"replica x{world}" if world > 1 else "single",
-                   "graph": bool(args.graph), "streams": 1 if args.one_stream else 2},
+                   "graph": bool(args.graph), "streams": 1 if args.one_stream else 2,
+                   "hoisted_step_invariants": bool(args.hoist)},
     }
     if args.config == "full":
         ach = ALGO_TFLOP_PER_STEP * (value / world)

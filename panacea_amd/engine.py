@@ -85,6 +85,8 @@ class Runtime:
         self.n_text = 77
         self.trace: Optional[Dict[str, torch.Tensor]] = None
         self.text_kv: Dict[int, tuple] = {}            # per cross-attention site: (k, ldk, vt, ldvt, vt_gstride)
+        self.text_frozen = False                       # text_kv / guided come from StepInvariants (sampler hoisting)
+        self.guided: Optional["Act"] = None            # precomputed ControlNet hint-stem output
 
     def empty(self, shape, dtype) -> torch.Tensor:
         return torch.empty(shape, device=self.device, dtype=dtype)

@@ -95,7 +95,7 @@ class ControlNet3D(UNetModel3D):
     def _run_control(self, rt: Runtime, x16: Act, hint: torch.Tensor, emb32: torch.Tensor) -> List[Act]:
         pk = self.packed()
         self._project_text(rt)
-        guided = self._hint_stem(rt, hint)
+        guided = rt.guided if rt.guided is not None else self._hint_stem(rt, hint)
         outs, h = [], x16
         for i, (module, (zw, zb)) in enumerate(zip(self.input_blocks, pk["zero"])):
             h = module._run(rt, h, emb32, want_f16=(i != 0))
@@ -160,10 +160,24 @@ class ControlledUNetModel3D(UNetModel3D):
             out = self._run_unet(rt, self._stem_tokens(rt, x), emb, acts)
         return out.to(x.dtype)
 
+    def prepare(self, context: torch.Tensor, hint: torch.Tensor) -> "StepInvariants":
+        """Everything on the path that does not depend on (x, t): the guided hint (input_hint_block of the BEV layout,
+        controlmodel.py:43-59,125-129) and the text K/V of the 138 cross-attention sites of both networks.  The
+        reference recomputes them in every one of the 25/50 sampler steps; a sampler that keeps `cond` fixed may
+        compute them once — `denoise(..., invariants=inv)` is then bit-identical to the plain call."""
+        with torch.no_grad():
+            F = hint.shape[0]
+            rt = Runtime(hint.device, F // self.num_frames, self.num_frames)
+            rt.set_context(context)
+            self._project_text(rt)
+            self.controlnet._project_text(rt)
+            guided = self.controlnet._hint_stem(rt, hint.detach().to(torch.float32).contiguous())
+        return StepInvariants(rt.ctx16, rt.n_text, dict(rt.text_kv), guided, (context, hint))
+
     two_stream = True      # run the ControlNet branch on a second HIP stream, concurrently with the UNet encoder
     split_samples = False  # additionally run every sample of the batch (CFG half) as its own stream pair
 
-    def denoise(self, x, timesteps, context, hint, trace=None) -> torch.Tensor:
+    def denoise(self, x, timesteps, context, hint, trace=None, invariants=None) -> torch.Tensor:
         """ControlNet + UNet in one runtime (what OpenAIWrapperControlLDM3D.forward calls): the stem tokens and
         the text context are prepared once and the 13 residuals stay in the resident layout.  The ControlNet only
         feeds the UNet from its middle block on (controlmodel.py:191-195), so it runs on a side stream next to the
@@ -171,6 +185,8 @@ class ControlledUNetModel3D(UNetModel3D):
         Samples of the batch never interact inside the network, so they can be issued as independent stream pairs."""
         T = self.num_frames
         B = x.shape[0] // T
+        if invariants is not None:
+            return self._denoise_one(x, timesteps, context, hint, trace, 0, invariants)
         if self.split_samples and self.two_stream and x.is_cuda and trace is None and B > 1:
             main = torch.cuda.current_stream()
             outs = []
@@ -188,14 +204,19 @@ class ControlledUNetModel3D(UNetModel3D):
             return torch.cat(outs, dim=0)
         return self._denoise_one(x, timesteps, context, hint, trace, 0)
 
-    def _denoise_one(self, x, timesteps, context, hint, trace, side_idx) -> torch.Tensor:
+    def _denoise_one(self, x, timesteps, context, hint, trace, side_idx, inv=None) -> torch.Tensor:
         with torch.no_grad():
             rt = runtime_for(x, self.num_frames)
             rt.trace = trace
-            rt.set_context(context)
+            if inv is not None:
+                inv.check(rt, context, hint)
+                rt.ctx16, rt.n_text, rt.text_kv, rt.text_frozen = inv.ctx16, inv.n_text, dict(inv.text_kv), True
+                rt.guided = inv.guided
+            else:
+                rt.set_context(context)
             x16 = self._stem_tokens(rt, x)
             cn = self.controlnet
-            hint32 = hint.detach().to(torch.float32).contiguous()
+            hint32 = hint if inv is not None else hint.detach().to(torch.float32).contiguous()
             if self.two_stream and x.is_cuda and trace is None:
                 main = torch.cuda.current_stream()
                 side = _side_stream(x.device, side_idx)
@@ -218,6 +239,22 @@ class ControlledUNetModel3D(UNetModel3D):
                         trace[f"control.{j}"] = c.to_nchw()
                 out = self._run_unet(rt, x16, self._time_embedding(rt, timesteps), control)
         return out.to(x.dtype)
+
+
+class StepInvariants:
+    """Result of ControlledUNetModel3D.prepare(): tensors that are constant over the sampler steps of one sample."""
+
+    def __init__(self, ctx16, n_text, text_kv, guided, sources):
+        self.ctx16, self.n_text, self.text_kv, self.guided = ctx16, n_text, text_kv, guided
+        self._src = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in sources)
+
+    def check(self, rt: Runtime, context, hint):
+        """The invariants belong to ONE (context, hint) pair: refuse anything else instead of silently reusing them."""
+        now = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in (context, hint))
+        if now != self._src:
+            raise ValueError("StepInvariants were prepared for different (or since modified) context / hint tensors")
+        if self.guided.F != rt.F:
+            raise ValueError(f"StepInvariants hold {self.guided.F} frames, the batch has {rt.F}")
 
 
 _SIDE_STREAMS = {}

@@ -338,6 +338,8 @@ class UNetModel3D(nn.Module, Packable):
     def _project_text(self, rt: Runtime):
         """Text K/V of every cross-attention site of this network, batched (attention.TextKVProjector)."""
         from .attention import TextKVProjector
+        if rt.text_frozen:
+            return
         tp = self.__dict__.get("_text_proj")
         if tp is None:
             tp = TextKVProjector(_OwnBlocks(self))

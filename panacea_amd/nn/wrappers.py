@@ -42,5 +42,8 @@ class OpenAIWrapperControlLDM3D(IdentityWrapper):
         c["crossattn"] = c["crossattn"].to(model_dtype)
         if c.get("vector", None) is not None:
             raise NotImplementedError("class-conditional `vector` conditioning is not on the Panacea path")
-        out = net.denoise(x, t, c["crossattn"], c["cond_feat"], trace=kwargs.get("trace"))
+        # "_invariants": optional ControlledUNetModel3D.prepare() result placed in `c` by a sampler that keeps the
+        # conditioning fixed over its steps (panacea_amd.sampling); never present when the reference's sampler calls
+        out = net.denoise(x, t, c["crossattn"], c["cond_feat"], trace=kwargs.get("trace"),
+                          invariants=c.get("_invariants"))
         return out.to(model_dtype)

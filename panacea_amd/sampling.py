@@ -98,11 +98,14 @@ class VanillaCFG:
 
     def prepare_inputs(self, x, s, c, uc):
         c_out = {}
+        pre = c.get("_cat")                       # hoist_invariants(): uc|c already concatenated once per schedule
         for k in c:
+            if k == "_cat":
+                continue
             if k in self.KEYS:
-                c_out[k] = torch.cat((uc[k], c[k]), 0)
+                c_out[k] = pre[k] if pre is not None else torch.cat((uc[k], c[k]), 0)
             else:
-                assert c[k] == uc[k]
+                assert c[k] is uc[k] or c[k] == uc[k]
                 c_out[k] = c[k]
         return torch.cat([x] * 2), torch.cat([s] * 2), c_out
 
@@ -129,14 +132,38 @@ class EulerEDMSampler:
         d = (x - denoised) / append_dims(sigma, x.ndim)
         return x + append_dims(next_sigma - sigma, x.ndim) * d
 
-    def __call__(self, denoiser, x, cond, uc=None, num_steps=None):
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, network=None):
+        """`network`: optional OpenAIWrapperControlLDM3D.  When given, the step invariants of the conditioning (text
+        K/V of every cross-attention site, ControlNet hint stem) are computed once for the whole schedule instead of
+        once per step; the trajectory is bit-identical to the plain loop."""
         sig = self.sigmas(num_steps)
         uc = cond if uc is None else uc
+        if network is not None:
+            cond, uc = hoist_invariants(network, self.guider, cond, uc)
         x = x * torch.sqrt(1.0 + sig[0] ** 2.0)
         s_in = x.new_ones([x.shape[0]])
         for i in range(len(sig) - 1):
             x = self.sampler_step(s_in * sig[i], s_in * sig[i + 1], denoiser, x, cond, uc)
         return x
+
+
+def hoist_invariants(network, guider, cond: Dict, uc: Dict):
+    """Returns copies of (cond, uc) that carry the network's StepInvariants for the batch the guider will build from
+    them.  The concatenated conditioning tensors are built ONCE here and shared by every step (prepare_inputs would
+    otherwise re-concatenate them per step, which also changes their identity)."""
+    model = network.diffusion_model
+    if guider is None:
+        c2 = dict(cond)
+        c2["crossattn"] = cond["crossattn"].to(model.controlnet.input_hint_block[0].weight.dtype)
+        c2["_invariants"] = model.prepare(c2["crossattn"], c2["cond_feat"])
+        return c2, c2
+    cat = {k: torch.cat((uc[k], cond[k]), 0) for k in cond if k in guider.KEYS}
+    cat["crossattn"] = cat["crossattn"].to(model.controlnet.input_hint_block[0].weight.dtype)
+    inv = model.prepare(cat["crossattn"], cat["cond_feat"])
+    c2, u2 = dict(cond), dict(uc)
+    c2["_invariants"] = u2["_invariants"] = inv
+    c2["_cat"] = u2["_cat"] = cat
+    return c2, u2
 
 
 def timestep_indices(num_steps: int) -> List[int]:

@@ -48,3 +48,45 @@ def test_euler_cfg_trajectory_matches_reference():
         assert np.array_equal(torch.stack(seen)[:, 0].numpy(), G[f"sampler.{n}.timesteps"])
         assert seen[0].dtype == torch.int64 and seen[0].shape == (4,)         # CFG doubles the batch
         assert np.allclose(xs.numpy(), G[f"sampler.{n}.x_final"], atol=2e-5, rtol=1e-5)
+
+
+def test_hoisted_step_invariants_are_bit_identical_and_guarded():
+    """text K/V and the ControlNet hint stem depend only on the conditioning; computing them once
+    per schedule (EulerEDMSampler(network=...)) must not change a bit of the trajectory, and the cached tensors
+    must refuse to serve a different context / hint."""
+    import pytest
+    import emu
+    from helpers import product_network, step_inputs
+    from panacea_amd import engine as E
+    w, _, kw = product_network("tiny")
+    inp = step_inputs("tiny", kw)
+    T = kw["num_frames"]
+    c = {"crossattn": inp["crossattn"][1:2], "concat": inp["concat"][T:], "cond_feat": inp["cond_feat"][T:]}
+    uc = {"crossattn": inp["crossattn"][0:1], "concat": inp["concat"][:T], "cond_feat": inp["cond_feat"][:T]}
+    den = S.DiscreteDenoiser()
+    smp = S.EulerEDMSampler(2, guider=S.VanillaCFG(5.0), device="cpu")
+    x0 = inp["x"][T:]
+    calls = {"stem": 0}
+    stem = w.diffusion_model.controlnet._hint_stem
+
+    def counted(rt, hint):
+        calls["stem"] += 1
+        return stem(rt, hint)
+    w.diffusion_model.controlnet._hint_stem = counted
+    with E.use_backend(emu):
+        plain = smp(lambda a, s, cc: den(w, a, s, cc), x0.clone(), c, uc)
+        n_plain = calls["stem"]
+        hoisted = smp(lambda a, s, cc: den(w, a, s, cc), x0.clone(), c, uc, network=w)
+        assert torch.equal(plain, hoisted)
+        assert n_plain == 2 and calls["stem"] == 3                  # once per step vs once per schedule
+        # the invariants are tied to the tensors they were computed from
+        model = w.diffusion_model
+        inv = model.prepare(inp["crossattn"], inp["cond_feat"])
+        x8 = torch.cat((inp["x"], inp["concat"]), dim=1)
+        ok = model.denoise(x8, inp["t"], inp["crossattn"], inp["cond_feat"], invariants=inv)
+        assert torch.equal(ok, model.denoise(x8, inp["t"], inp["crossattn"], inp["cond_feat"]))
+        with pytest.raises(ValueError):
+            model.denoise(x8, inp["t"], inp["crossattn"].clone(), inp["cond_feat"], invariants=inv)
+        inp["cond_feat"].add_(0.0)                                   # in-place write bumps the version counter
+        with pytest.raises(ValueError):
+            model.denoise(x8, inp["t"], inp["crossattn"], inp["cond_feat"], invariants=inv)

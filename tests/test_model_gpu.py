@@ -154,3 +154,13 @@ def test_streams_and_graph_replay_are_bit_identical():
         g1 = g(g0, s_in * sig[1], s_in * sig[2]).clone()
     torch.cuda.synchronize()
     assert torch.equal(g0, e0) and torch.equal(g1, e1)
+    # hoisted step invariants (text K/V + hint stem computed once per schedule): same bits, eager and graphed
+    with torch.no_grad():
+        c2, u2 = S.hoist_invariants(w, smp.guider, c, uc)
+        hstep = lambda xi, s0, s1: smp.sampler_step(s0, s1, lambda a, b, cc: den(w, a, b, cc), xi, c2, u2)   # noqa: E731
+        h0 = hstep(x0, s_in * sig[0], s_in * sig[1])
+        h1 = hstep(h0, s_in * sig[1], s_in * sig[2])
+        gh = GraphedStep(hstep, x0, s_in * sig[0], s_in * sig[1])
+        gh1 = gh(gh(x0, s_in * sig[0], s_in * sig[1]).clone(), s_in * sig[1], s_in * sig[2]).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(h0, e0) and torch.equal(h1, e1) and torch.equal(gh1, e1)

@@ -28,14 +28,21 @@ constexpr int KT = 64;    // keys per tile; a workgroup of NW waves serves NW*32
 
 __device__ __forceinline__ int kperm(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
 
+__device__ __attribute__((aligned(16))) half_t g_attn_zero_chunk[8];   // zero-initialised: DMA source of masked chunks
+
 // NW waves per workgroup, QB blocks of 32 queries per wave: a workgroup serves NW*QB*32 queries that share every
 // K/V tile, and with QB = 2 every K / V^T fragment read from LDS feeds two MFMAs (the inner loop is LDS-read bound).
-template <int NW, int QB>
-__global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams p) {
+// DMA = true (views whose V^T rows are 16-byte addressable: every level of the network): K / V^T tiles go HBM -> LDS
+// with global_load_lds_dwordx4, no VGPR round trip and no ds_write; wv_shift = log2(view width) when it is a power of
+// two (every level: 64 / 32 / 16 / 8) so that the per-lane key -> (row, column) split of each tile is a shift, not an
+// integer division.  Staging was 25-30 % of the kernel at level 0 (ablation: tools/exp, profiles/round1).
+template <int NW, int QB, bool DMA>
+__global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams p, const int wv_shift) {
     constexpr int QT = NW * QB * 32;
     constexpr int ROWS_PER_IT = NW * 8;          // K / V^T rows staged per iteration (8 rows per wave)
     constexpr int ST_IT = 64 / ROWS_PER_IT;      // 2 (4 waves) or 1 (8 waves)
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KT * 128];   // [stage][K | Vt][64 rows x 128 B]
+    constexpr int NST = DMA ? 3 : 2;             // DMA: ring of three stages, two tiles in flight (counted vmcnt)
+    __shared__ __attribute__((aligned(16))) char smem[NST * 2 * KT * 128];   // [stage][K | Vt][64 rows x 128 B]
     const half_t* __restrict__ Q = reinterpret_cast<const half_t*>(p.q);
     const half_t* __restrict__ K = reinterpret_cast<const half_t*>(p.k);
     const half_t* __restrict__ VT = reinterpret_cast<const half_t*>(p.vt);
@@ -79,7 +86,13 @@ __global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams
     const float sc = p.scale * 1.44269504088896340736f;   // exp2 domain
 
     // ---- staging assignment: 16-B chunk column sc8 of rows sr (+ ROWS_PER_IT) ----
-    const int sc8 = tid & 7, sr = tid >> 3;
+    // register path: thread writes LOGICAL chunk sc8 to its swizzled slot.  DMA path: the wave image is lane-linear, so
+    // physical slot sc8 of row sr receives logical chunk sc8 ^ ((sr>>1)&7) (ROWS_PER_IT is a multiple of 16)
+    const int sc8 = DMA ? ((tid & 7) ^ (((tid >> 3) >> 1) & 7)) : (tid & 7), sr = tid >> 3;
+    auto div_wv = [&](int key, int& ky, int& kxl) {
+        if (wv_shift >= 0) { ky = key >> wv_shift; kxl = key & ((1 << wv_shift) - 1); }
+        else { ky = key / kvWv; kxl = key - ky * kvWv; }
+    };
     const int nseg = p.nseg[view];
     const int tiles_per_seg = (Nkv + KT - 1) / KT;
     const int ntiles = nseg * tiles_per_seg;
@@ -95,8 +108,9 @@ __global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams
             // K: row = key, chunk = 8 channels
             const int key = key0 + sr + ROWS_PER_IT * i;
             if (key < Nkv) {
-                const int ky = key / kvWv, kx = kview * kvWv + (key - ky * kvWv);
-                const int64_t krow = (int64_t)kvg * p.kv_rows_per_group + (int64_t)ky * p.kvW + kx;
+                int ky, kxl;
+                div_wv(key, ky, kxl);
+                const int64_t krow = (int64_t)kvg * p.kv_rows_per_group + (int64_t)ky * p.kvW + kview * kvWv + kxl;
                 rk[i] = *reinterpret_cast<const half8v*>(K + krow * p.ldk + hc + sc8 * 8);
             } else rk[i] = z;
             // V^T: row = channel d, chunk = 8 consecutive keys
@@ -105,8 +119,9 @@ __global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams
             if (kc < Nkv) {
                 const half_t* vrow = VT + (int64_t)kvg * p.vt_gstride + (int64_t)(hc + d) * p.ldvt;
                 if (vec_v) {          // 8 consecutive keys of one grid row: one aligned 16-byte load
-                    const int ky = kc / kvWv, kx = kview * kvWv + (kc - ky * kvWv);
-                    rv[i] = *reinterpret_cast<const half8v*>(vrow + (int64_t)ky * p.kvW + kx);
+                    int ky, kxl;
+                    div_wv(kc, ky, kxl);
+                    rv[i] = *reinterpret_cast<const half8v*>(vrow + (int64_t)ky * p.kvW + kview * kvWv + kxl);
                 } else {              // narrow views (< 8 columns or unaligned): gather key by key
                     half8v gth = z;
 #pragma unroll
@@ -132,18 +147,58 @@ __global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams
         }
     };
 
-    if (ntiles > 0) {
-        load_tile(0);
-        store_tile(0);
+    auto dma_tile = [&](int t, int stage) {        // DMA path: same addresses, destination = this wave's 8 rows
+        const int s = t / tiles_per_seg, tt = t - s * tiles_per_seg;
+        const int kview = p.seg[view][s];
+        const int key0 = tt * KT;
+        char* sk = smem + stage * (2 * KT * 128) + wave * 1024;
+        char* sv = sk + KT * 128;
+#pragma unroll
+        for (int i = 0; i < ST_IT; ++i) {
+            const int key = key0 + sr + ROWS_PER_IT * i;
+            const half_t* ksrc = g_attn_zero_chunk;
+            if (key < Nkv) {
+                int ky, kxl;
+                div_wv(key, ky, kxl);
+                const int64_t krow = (int64_t)kvg * p.kv_rows_per_group + (int64_t)ky * p.kvW + kview * kvWv + kxl;
+                ksrc = K + krow * p.ldk + hc + sc8 * 8;
+            }
+            glds16(ksrc, sk + i * (ROWS_PER_IT * 128));
+            const int d = sr + ROWS_PER_IT * i;
+            const int kc = key0 + sc8 * 8;
+            const half_t* vsrc = g_attn_zero_chunk;
+            if (kc < Nkv) {
+                int ky, kxl;
+                div_wv(kc, ky, kxl);
+                vsrc = VT + (int64_t)kvg * p.vt_gstride + (int64_t)(hc + d) * p.ldvt + (int64_t)ky * p.kvW + kview * kvWv + kxl;
+            }
+            glds16(vsrc, sv + i * (ROWS_PER_IT * 128));
+        }
+    };
+
+    constexpr int LOADS = 2 * ST_IT;             // DMA instructions per thread and tile
+    if (DMA) {
+        if (ntiles > 0) dma_tile(0, 0);
+        if (ntiles > 1) {
+            dma_tile(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");     // tile 0 landed, tile 1 may be in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    } else {
+        if (ntiles > 0) { load_tile(0); store_tile(0); }
+        __syncthreads();
     }
-    __syncthreads();
 
     const int frow = lane & 31;
     const int krow_lds = kperm(frow);
     for (int t = 0; t < ntiles; ++t) {
         const bool more = (t + 1) < ntiles;
-        if (more) load_tile(t + 1);
-        const char* sk = smem + (t & 1) * (2 * KT * 128);
+        const bool ahead = DMA && (t + 2) < ntiles;
+        if (DMA) { if (ahead) dma_tile(t + 2, (t + 2) % 3); }
+        else if (more) load_tile(t + 1);
+        const char* sk = smem + (DMA ? (t % 3) : (t & 1)) * (2 * KT * 128);
         const char* sv = sk + KT * 128;
         const int tt = t % tiles_per_seg;
         const int key0 = tt * KT;
@@ -221,8 +276,17 @@ __global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams
                     for (int qb = 0; qb < QB; ++qb)
                         oacc[qb][dh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qb][kh][ss], oacc[qb][dh], 0, 0, 0);
                 }
-        if (more) store_tile((t + 1) & 1);
-        __syncthreads();
+        if (DMA) {
+            // tile t+1 has landed once at most the LOADS instructions of tile t+2 are outstanding; the raw barrier (no
+            // compiler vmcnt(0)) publishes every wave's part of it and retires all reads of the stage recycled next
+            if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            if (more) store_tile((t + 1) & 1);
+            __syncthreads();
+        }
     }
 
     // ---- normalise and store: lane owns its queries, channels d = 32*dh + mfma32_row(r, lane) ----
@@ -346,19 +410,21 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     const int force = fenv ? atoi(fenv) : 0;
     const int variant = force ? force : (Nq >= 512 ? 82 : (Nq >= 256 ? 81 : 41));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (variant == 42) {
-        dim3 grid((Nq + 255) / 256, p.views, p.groups * p.heads);
-        hipLaunchKernelGGL((attn_views_kernel<4, 2>), grid, dim3(256), 0, st, p);
-    } else if (variant == 82) {
-        dim3 grid((Nq + 511) / 512, p.views, p.groups * p.heads);
-        hipLaunchKernelGGL((attn_views_kernel<8, 2>), grid, dim3(512), 0, st, p);
-    } else if (variant == 81) {
-        dim3 grid((Nq + 255) / 256, p.views, p.groups * p.heads);
-        hipLaunchKernelGGL((attn_views_kernel<8, 1>), grid, dim3(512), 0, st, p);
-    } else {
-        dim3 grid((Nq + 127) / 128, p.views, p.groups * p.heads);
-        hipLaunchKernelGGL((attn_views_kernel<4, 1>), grid, dim3(256), 0, st, p);
-    }
+    const bool dma = ((kvWv & 7) == 0) && ((p.kvW & 7) == 0) && ((p.ldvt & 7) == 0) && ((p.vt_gstride & 7) == 0) &&
+                     !getenv("PNC_ATTN_NODMA");
+    int wv_shift = -1;
+    if (kvWv > 0 && (kvWv & (kvWv - 1)) == 0) { wv_shift = 0; while ((1 << wv_shift) < kvWv) ++wv_shift; }
+#define PNC_ATTN_LAUNCH(NW_, QB_, QTILE_)                                                                         \
+    do {                                                                                                          \
+        dim3 grid((Nq + (QTILE_) - 1) / (QTILE_), p.views, p.groups * p.heads);                                   \
+        if (dma) hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, true>), grid, dim3(64 * NW_), 0, st, p, wv_shift);  \
+        else hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, false>), grid, dim3(64 * NW_), 0, st, p, wv_shift);   \
+    } while (0)
+    if (variant == 42) PNC_ATTN_LAUNCH(4, 2, 256);
+    else if (variant == 82) PNC_ATTN_LAUNCH(8, 2, 512);
+    else if (variant == 81) PNC_ATTN_LAUNCH(8, 1, 256);
+    else PNC_ATTN_LAUNCH(4, 1, 128);
+#undef PNC_ATTN_LAUNCH
     return pnc_launch_status();
 }
 

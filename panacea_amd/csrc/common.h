@@ -55,6 +55,13 @@ __device__ __forceinline__ float gelu_erf_f(float v) {
     return fmaf(-av, q, fmaxf(v, 0.0f));
 }
 
+// LDS DMA (global_load_lds_dwordx4): lane l's 16 bytes land at lds_wave_base + 16*l — the LDS image of one wave
+// instruction is lane-linear (1 KB), so any swizzle has to be applied to the SOURCE address
+__device__ __forceinline__ void glds16(const half_t* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -96,11 +96,6 @@ __device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, con
     }
 }
 
-__device__ __forceinline__ void glds16(const half_t* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 // Row-major epilogue of one wave tile (MI x NI blocks of 32x32).  Each 32-row x 64-column slab goes through a
 // wave-private LDS region so that a lane ends up with 8 CONSECUTIVE columns of one row: 16-byte fp16 stores, two
 // 16-byte fp32 loads/stores.  All LDS reads of a slab are issued before the first use (the loop is instruction- and

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     const bool ab_nodma = (p.act & 0x100) != 0, ab_nomfma = (p.act & 0x200) != 0, ab_noepi = (p.act & 0x400) != 0;
     const bool ab_nostage = (p.act & 0x800) != 0, ab_nostore = (p.act & 0x1000) != 0, ab_nobar = (p.act & 0x2000) != 0;
     const bool prio = (p.act & 0x4000) != 0;
-    auto compute = [&](int stage) {
+    auto compute = [&](int stage, int mid_issue = -1) {
         const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
         if (PIPE) {
@@ -468,6 +468,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
                 if (prio) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (ks == 1 && mid_issue >= 0) { issue_tile(mid_issue, mid_issue & 1); __builtin_amdgcn_sched_barrier(0); }
             }
         } else {
 #pragma unroll
@@ -486,17 +487,47 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                if (ks == 1 && mid_issue >= 0) issue_tile(mid_issue, mid_issue & 1);
             }
         }
     };
 
-    if (STAGES == 2) {
+    // EXPERIMENT (act bit 0x20000, tools/exp/gemm_timeline.py): s_memtime stamps of one mid-grid workgroup, summed per
+    // segment over the K loop, written to p.ws[wave*8 ..] as floats: total, prologue, issue, compute, vmcnt, barrier,
+    // epilogue, K tiles
+    const bool prof = (pin.act & 0x20000) != 0 && pin.ws != nullptr && ksplit == 1 && blockIdx.x == gridDim.x / 2;
+    uint64_t pt0 = 0, p_issue = 0, p_comp = 0, p_vm = 0, p_bar = 0, p_loop0 = 0, p_loop1 = 0;
+    if (prof) pt0 = __builtin_readcyclecounter();
+    if (STAGES == 2 && prof) {
+        issue_tile(0, 0);
+        __syncthreads();
+        p_loop0 = __builtin_readcyclecounter();
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const uint64_t c0 = __builtin_readcyclecounter();
+            if (kt + 1 < ntiles) issue_tile(kt + 1, (kt + 1) & 1);
+            const uint64_t c1 = __builtin_readcyclecounter();
+            if (wave_on) compute(kt & 1);
+            const uint64_t c2 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const uint64_t c3 = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_barrier();
+            const uint64_t c4 = __builtin_readcyclecounter();
+            p_issue += c1 - c0; p_comp += c2 - c1; p_vm += c3 - c2; p_bar += c4 - c3;
+        }
+        p_loop1 = __builtin_readcyclecounter();
+    } else if (STAGES == 2) {
         // one tile in flight: the plain barrier carries the vmcnt(0) that lands the DMA
         issue_tile(0, 0);
         __syncthreads();
+        // The second-dispatched half of the waves (4-7: one per SIMD, the arbitration losers) issues its share of the
+        // next tile's DMA in the MIDDLE of its MFMA stream instead of together with waves 0-3 right after the barrier
+        // (s_memtime timeline: 1870 vs 690 cycles per tile in the issue segment, with waves 0-3 then idling ~1400
+        // cycles at the barrier): each SIMD then has one wave issuing DMA while the other runs MFMAs.
+        const bool late = ((p.act & 0x40000) == 0) && NW == 8 && wave >= 4 && wave_on && ntiles >= 8;   // 2-5 % at long K
         for (int kt = 0; kt < ntiles; ++kt) {
-            if (kt + 1 < ntiles && !ab_nodma) issue_tile(kt + 1, (kt + 1) & 1);
-            if (!ab_nomfma && wave_on) compute(kt & 1);
+            const bool nxt = kt + 1 < ntiles && !ab_nodma;
+            if (nxt && !late) issue_tile(kt + 1, (kt + 1) & 1);
+            if (!ab_nomfma && wave_on) compute(kt & 1, (nxt && late) ? kt + 1 : -1);
             if (!ab_nobar) __syncthreads();
         }
     } else {
@@ -527,6 +558,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     // ------------------------------ epilogue ------------------------------
     if (ab_noepi) { if (acc[0][0][0] == 123.456f) p.out32[0] = 1.0f; return; }
     if (!wave_on) return;                       // row group of another workgroup (tail split)
+    struct ProfDump {                           // written when the kernel body returns (after the epilogue stores issue)
+        bool on; int lane, wave, nt; uint64_t t0, l0, l1, a, b, c, d; float* out;
+        __device__ ~ProfDump() {
+            if (!on || lane != 0) return;
+            const uint64_t t1 = __builtin_readcyclecounter();
+            float* o = out + wave * 8;
+            o[0] = (float)(t1 - t0); o[1] = (float)(l0 - t0); o[2] = (float)a; o[3] = (float)b; o[4] = (float)c;
+            o[5] = (float)d; o[6] = (float)(t1 - l1); o[7] = (float)nt;
+        }
+    } prof_dump{prof, lane, wave, ntiles, pt0, p_loop0, p_loop1, p_issue, p_comp, p_vm, p_bar, pin.ws};
     const int mw = m0 + wm * (MI * 32), nw = n0 + wn * (NI * 32);
     half_t* out16 = reinterpret_cast<half_t*>(p.out16);
     half_t* out16t = reinterpret_cast<half_t*>(p.out16t);
@@ -668,7 +709,9 @@ int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
     int nfull = tiles, tail_f = 1;
     if (ksplit == 1) tail_split<BM, WGM, lds>(tiles, nfull, tail_f);
     const int blocks = ksplit > 1 ? tiles * ksplit : nfull + (tiles - nfull) * tail_f;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, p, ksplit, nfull, tail_f);
+    PncGemmParams q = p;
+    if (getenv("PNC_GEMM_NOLATE")) q.act |= 0x40000;         // A/B runs: all waves issue their DMA share after the barrier
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, q, ksplit, nfull, tail_f);
     if (ksplit > 1) {
         const int64_t work = (int64_t)p.M * (p.N >> 3);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, p, ksplit);

@@ -492,30 +492,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         }
     };
 
-    // EXPERIMENT (act bit 0x20000, tools/exp/gemm_timeline.py): s_memtime stamps of one mid-grid workgroup, summed per
-    // segment over the K loop, written to p.ws[wave*8 ..] as floats: total, prologue, issue, compute, vmcnt, barrier,
-    // epilogue, K tiles
-    const bool prof = (pin.act & 0x20000) != 0 && pin.ws != nullptr && ksplit == 1 && blockIdx.x == gridDim.x / 2;
-    uint64_t pt0 = 0, p_issue = 0, p_comp = 0, p_vm = 0, p_bar = 0, p_loop0 = 0, p_loop1 = 0;
-    if (prof) pt0 = __builtin_readcyclecounter();
-    if (STAGES == 2 && prof) {
-        issue_tile(0, 0);
-        __syncthreads();
-        p_loop0 = __builtin_readcyclecounter();
-        for (int kt = 0; kt < ntiles; ++kt) {
-            const uint64_t c0 = __builtin_readcyclecounter();
-            if (kt + 1 < ntiles) issue_tile(kt + 1, (kt + 1) & 1);
-            const uint64_t c1 = __builtin_readcyclecounter();
-            if (wave_on) compute(kt & 1);
-            const uint64_t c2 = __builtin_readcyclecounter();
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            const uint64_t c3 = __builtin_readcyclecounter();
-            __builtin_amdgcn_s_barrier();
-            const uint64_t c4 = __builtin_readcyclecounter();
-            p_issue += c1 - c0; p_comp += c2 - c1; p_vm += c3 - c2; p_bar += c4 - c3;
-        }
-        p_loop1 = __builtin_readcyclecounter();
-    } else if (STAGES == 2) {
+    if (STAGES == 2) {
         // one tile in flight: the plain barrier carries the vmcnt(0) that lands the DMA
         issue_tile(0, 0);
         __syncthreads();
@@ -558,16 +535,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     // ------------------------------ epilogue ------------------------------
     if (ab_noepi) { if (acc[0][0][0] == 123.456f) p.out32[0] = 1.0f; return; }
     if (!wave_on) return;                       // row group of another workgroup (tail split)
-    struct ProfDump {                           // written when the kernel body returns (after the epilogue stores issue)
-        bool on; int lane, wave, nt; uint64_t t0, l0, l1, a, b, c, d; float* out;
-        __device__ ~ProfDump() {
-            if (!on || lane != 0) return;
-            const uint64_t t1 = __builtin_readcyclecounter();
-            float* o = out + wave * 8;
-            o[0] = (float)(t1 - t0); o[1] = (float)(l0 - t0); o[2] = (float)a; o[3] = (float)b; o[4] = (float)c;
-            o[5] = (float)d; o[6] = (float)(t1 - l1); o[7] = (float)nt;
-        }
-    } prof_dump{prof, lane, wave, ntiles, pt0, p_loop0, p_loop1, p_issue, p_comp, p_vm, p_bar, pin.ws};
     const int mw = m0 + wm * (MI * 32), nw = n0 + wn * (NI * 32);
     half_t* out16 = reinterpret_cast<half_t*>(p.out16);
     half_t* out16t = reinterpret_cast<half_t*>(p.out16t);

@@ -100,6 +100,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    import os
+    global LIB_PATH
+    if os.environ.get("PANACEA_HIP_LIB"):          # A/B runs of two builds of the SAME ABI (tools/exp); never a fallback
+        LIB_PATH = Path(os.environ["PANACEA_HIP_LIB"])
     if not LIB_PATH.exists():
         raise HipLibraryError(
             f"{LIB_PATH} is missing: the HIP extension is the only compute path of panacea_amd. "

@@ -202,7 +202,9 @@ class ResBlock3D(TimestepBlock, Packable):
         h = run_conv3x3(rt, a16, F, H, W, Cin, pk["w1"], pk["c1"], Co).f32
         # h = h + conv1d_t(SiLU(GN_t(h))) + emb_layers(emb)[frame]      (:505-531)
         t16 = E.gn_temporal(rt, h, N, Co, pk["gt1"], pk["bt1"], 1e-5)
-        emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels, silu_in=True)
+        # emb32 arrives as SiLU(emb): the activation of `emb_layers` is applied ONCE per network evaluation by
+        # _time_embedding (32 ResBlocks x 16 x 1280 identical SiLUs otherwise), the Linear runs here
+        emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
         rt.be.gemm(t16, pk["wt1"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct1"],
                    rowbias=emb_out, rb_rows=N, rb_mod=F, res1=h, ldr1=Co, out32=h, ldc32=Co)
         # out_layers: GN + SiLU + conv3x3
@@ -224,7 +226,8 @@ class ResBlock3D(TimestepBlock, Packable):
     def forward(self, x, emb):
         from .util import act_from_nchw, runtime_for
         rt = runtime_for(x, self.num_frames)
-        return self._run(rt, act_from_nchw(rt, x), emb.to(torch.float32).contiguous()).to_nchw().to(x.dtype)
+        semb = torch.nn.functional.silu(emb.to(torch.float32)).contiguous()      # _run takes SiLU(emb)
+        return self._run(rt, act_from_nchw(rt, x), semb).to_nchw().to(x.dtype)
 
 
 class _OwnBlocks:
@@ -364,7 +367,8 @@ class UNetModel3D(nn.Module, Packable):
             raise NotImplementedError("model_channels must be a multiple of 8")
         t_emb = timestep_embedding(timesteps.to(rt.device), mc)
         h = E.small_linear(rt, t_emb, pk["tw0"], pk["tb0"], rt.F, td, mc, silu_out=True)
-        return E.small_linear(rt, h, pk["tw2"], pk["tb2"], rt.F, td, td)
+        # returns SiLU(emb): every consumer of emb (ResBlock3D.emb_layers, :468-476) starts with nn.SiLU
+        return E.small_linear(rt, h, pk["tw2"], pk["tb2"], rt.F, td, td, silu_out=True)
 
     def _head(self, rt: Runtime, h: Act) -> torch.Tensor:
         """self.out: GN + SiLU + conv3x3 -> NCHW fp32 (:1245-1253, controlmodel.py:197-202)."""

@@ -1,4 +1,7 @@
-"""s_memtime timeline of one mid-grid workgroup of a GEMM (act bit 0x20000).  usage: gemm_timeline.py M N K [geglu|res]"""
+"""s_memtime timeline of one mid-grid workgroup of a GEMM (act bit 0x20000).  usage: gemm_timeline.py M N K [geglu|res]
+
+Needs the instrumented kernel of commit 781529f (the stamps cost ~5 ms/step in the product kernels through register
+pressure in the epilogue and were removed again); its output is kept in profiles/round1/gemm_timeline_r1i.txt."""
 import ctypes, sys
 from pathlib import Path
 import torch

@@ -96,6 +96,160 @@ __device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, con
     }
 }
 
+// Row-major epilogue for GEMMs that READ global memory in the epilogue (residuals, per-frame row bias).  In place
+// (res1 == out32) a load may not move above an earlier store, so a load-add-store loop pays one full HBM latency per
+// 8-row pass (24 passes per 256x320 tile: most of a K = 320 tile's lifetime) and keeps far too few bytes in flight.
+// Two measures: (1) all loads of a slab (32 rows x 64 columns) are issued together; (2) ROLLING prefetch of the first
+// residual: as soon as pass ps of slab s has consumed its 8 residual values, the same registers receive the loads of
+// pass ps of slab s+1 — issued before the stores of pass ps, so they travel together with those stores and under the
+// LDS staging of slab s+1, at no extra VGPR cost.  Rows/columns of different slabs are disjoint, so the reordering
+// is safe also when res1 aliases out32.
+template <int MI, int NI>
+__device__ __forceinline__ void epilogue_rowmajor_loads(const PncGemmParams& p, f32x16 (&acc)[MI][NI], float* ep, int lane,
+                                                        int mw, int nw, bool ab_nostage, bool ab_nostore) {
+    constexpr int ENI = NI < 2 ? NI : 2;
+    constexpr int EPITCH = ENI * 32 + 4;
+    constexpr int CPL = ENI * 4, RPP = 64 / CPL, NP = 32 / RPP;
+    constexpr int NJ = (NI + ENI - 1) / ENI, NS = NJ * MI;
+    const int cl = lane % CPL, rl = lane / CPL;
+    half_t* out16 = reinterpret_cast<half_t*>(p.out16);
+    const bool v32 = ((p.ldc32 & 3) == 0) && (((uintptr_t)p.out32 & 15) == 0);
+    const bool v16 = ((p.ldc16 & 7) == 0) && (((uintptr_t)p.out16 & 15) == 0);
+    const bool vr1 = ((p.ldr1 & 3) == 0) && (((uintptr_t)p.res1 & 15) == 0);
+    const bool vr2 = ((p.ldr2 & 3) == 0) && (((uintptr_t)p.res2 & 15) == 0);
+    const bool vrb = ((p.N & 3) == 0) && (((uintptr_t)p.rowbias & 15) == 0);
+    const int act = p.act & 0xff;
+    const float* xs = p.res1 ? p.res1 : p.res2;                               // stream X: the first residual
+    const int ldx = p.res1 ? p.ldr1 : p.ldr2;
+    const bool vx = p.res1 ? vr1 : vr2;
+    const bool y_is_res2 = p.res1 && p.res2;
+    const bool y_is_rb = !y_is_res2 && p.rowbias;                             // stream Y: res2, else the row bias
+    const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 x0[NP], x1[NP];
+    auto load_x = [&](auto s_, auto ps_) {
+        constexpr int s = decltype(s_)::value, ps = decltype(ps_)::value;
+        constexpr int jc = (s / MI) * ENI, i = s % MI, cw = (NI - jc) < ENI ? (NI - jc) : ENI;
+        const int ncol = nw + jc * 32 + cl * 8;
+        const int m = mw + i * 32 + ps * RPP + rl;
+        x0[ps] = z4; x1[ps] = z4;
+        if ((cl * 8) < cw * 32 && (ncol + 7) < p.N && xs && vx && m < p.M) {
+            const float* rp = xs + (int64_t)m * ldx + ncol;
+            x0[ps] = *reinterpret_cast<const f32x4*>(rp);
+            x1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+        }
+    };
+    static_for<NP>([&](auto ps_) { load_x(std::integral_constant<int, 0>{}, ps_); });
+    static_for<NS>([&](auto s_) {
+        constexpr int s = decltype(s_)::value, jc = (s / MI) * ENI, i = s % MI;
+        constexpr int cw = (NI - jc) < ENI ? (NI - jc) : ENI;
+        const int ncol = nw + jc * 32 + cl * 8;
+        const bool lane_on = (cl * 8) < cw * 32 && ncol < p.N;
+        const bool full8 = (ncol + 7) < p.N;
+        // this slab's second stream and bias
+        f32x4 y0[NP], y1[NP];
+        float bcol[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bcol[e] = (p.bias && lane_on && (ncol + e) < p.N) ? p.bias[ncol + e] : 0.0f;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int m = mw + i * 32 + ps * RPP + rl;
+            const bool ok = lane_on && full8 && m < p.M;
+            y0[ps] = z4; y1[ps] = z4;
+            if (ok && y_is_res2 && vr2) {
+                const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
+                y0[ps] = *reinterpret_cast<const f32x4*>(rp);
+                y1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+            }
+            if (ok && y_is_rb && vrb) {
+                const float* rp = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
+                y0[ps] = *reinterpret_cast<const f32x4*>(rp);
+                y1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // previous slab fully read back from LDS
+        static_for<cw>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if (!ab_nostage) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][jc + j][r];
+            }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<NP>([&](auto ps_) {
+            constexpr int ps = decltype(ps_)::value;
+            const float* src = ep + (ps * RPP + rl) * EPITCH + cl * 8;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+            const int m = mw + i * 32 + ps * RPP + rl;
+            const bool row_on = lane_on && m < p.M;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a0[e] + bcol[e]; v[e + 4] = a1[e] + bcol[e + 4]; }
+            if (p.rowbias && row_on) {
+                if (y_is_rb && full8 && vrb) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += y0[ps][e]; v[e + 4] += y1[ps][e]; }
+                } else {
+                    const float* rb = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (ncol + e < p.N) v[e] += rb[e];
+                }
+            }
+            if (act == PNC_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+            }
+            if (xs && row_on) {                 // first residual (res1, or res2 when it is the only one)
+                if (full8 && vx) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += x0[ps][e]; v[e + 4] += x1[ps][e]; }
+                } else {
+                    const float* rp = xs + (int64_t)m * ldx + ncol;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (ncol + e < p.N) v[e] += rp[e];
+                }
+            }
+            // rolling prefetch: these registers are free now; the loads go out before this pass's stores
+            if constexpr (s + 1 < NS) load_x(std::integral_constant<int, s + 1>{}, ps_);
+            if (y_is_res2 && row_on) {
+                if (full8 && vr2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += y0[ps][e]; v[e + 4] += y1[ps][e]; }
+                } else {
+                    const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (ncol + e < p.N) v[e] += rp[e];
+                }
+            }
+            if (!row_on) return;
+            if (ab_nostore) { if (v[0] == 123.456f) p.out32[0] = v[1] + v[5]; return; }
+            if (p.out32) {
+                float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
+                if (full8 && v32) {
+                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4*>(op) = o0;
+                    *reinterpret_cast<f32x4*>(op + 4) = o1;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (ncol + e < p.N) op[e] = v[e];
+                }
+            }
+            if (out16) {
+                half_t* op = out16 + (int64_t)m * p.ldc16 + ncol;
+                if (full8 && v16) {
+                    half8v o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+                    *reinterpret_cast<half8v*>(op) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (ncol + e < p.N) op[e] = (half_t)v[e];
+                }
+            }
+        });
+    });
+}
+
 // Row-major epilogue of one wave tile (MI x NI blocks of 32x32).  Each 32-row x 64-column slab goes through a
 // wave-private LDS region so that a lane ends up with 8 CONSECUTIVE columns of one row: 16-byte fp16 stores, two
 // 16-byte fp32 loads/stores.  All LDS reads of a slab are issued before the first use (the loop is instruction- and
@@ -118,6 +272,12 @@ __device__ __forceinline__ void epilogue_rowmajor(const PncGemmParams& p, f32x16
     const bool vr1 = ((p.ldr1 & 3) == 0) && (((uintptr_t)p.res1 & 15) == 0);
     const bool vr2 = ((p.ldr2 & 3) == 0) && (((uintptr_t)p.res2 & 15) == 0);
     const int act = p.act & 0xff;
+    if constexpr (!GEGLU) {
+        if (p.res1 || p.res2 || p.rowbias) {
+            epilogue_rowmajor_loads<MI, NI>(p, acc, ep, lane, mw, nw, ab_nostage, ab_nostore);
+            return;
+        }
+    }
     static_for<(NI + ENI - 1) / ENI>([&](auto jc_) {
         constexpr int jc = decltype(jc_)::value * ENI;
         constexpr int cw = (NI - jc) < ENI ? (NI - jc) : ENI;           // column blocks in this chunk (1 or 2)
@@ -143,115 +303,6 @@ __device__ __forceinline__ void epilogue_rowmajor(const PncGemmParams& p, f32x16
                         ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][jc + j][r];
                 }
             });
-            if constexpr (!GEGLU) {
-                if (p.res1 || p.res2 || p.rowbias) {
-                    // Epilogues that READ global memory (residuals, per-frame row bias).  In place (res1 == out32) a
-                    // load may not move above an earlier store, so a load-add-store loop pays one full HBM latency per
-                    // 8-row pass (24 passes per 256x320 tile: most of a K = 320 tile's lifetime).  Instead all global
-                    // loads of the slab (up to two streams x NP passes) are issued here, before the LDS reads.
-                    const bool vrb = ((p.N & 3) == 0) && (((uintptr_t)p.rowbias & 15) == 0);
-                    const float* xs = p.res1 ? p.res1 : (p.res2 ? p.res2 : nullptr);      // stream X: first residual
-                    const int ldx = p.res1 ? p.ldr1 : p.ldr2;
-                    const bool vx = p.res1 ? vr1 : vr2;
-                    const bool y_is_res2 = p.res1 && p.res2;
-                    const bool y_is_rb = !y_is_res2 && p.rowbias;                         // stream Y: res2 or row bias
-                    const bool rb_inloop = y_is_res2 && p.rowbias;                        // all three: bias stays in-loop
-                    f32x4 x0[NP], x1[NP], y0[NP], y1[NP];
-#pragma unroll
-                    for (int ps = 0; ps < NP; ++ps) {
-                        const int m = mw + i * 32 + ps * RPP + rl;
-                        const bool ok = lane_on && m < p.M && full8;
-                        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                        x0[ps] = z; x1[ps] = z; y0[ps] = z; y1[ps] = z;
-                        if (ok && xs && vx) {
-                            const float* rp = xs + (int64_t)m * ldx + ncol;
-                            x0[ps] = *reinterpret_cast<const f32x4*>(rp);
-                            x1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
-                        }
-                        if (ok && y_is_res2 && vr2) {
-                            const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
-                            y0[ps] = *reinterpret_cast<const f32x4*>(rp);
-                            y1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
-                        }
-                        if (ok && y_is_rb && vrb) {
-                            const float* rp = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
-                            y0[ps] = *reinterpret_cast<const f32x4*>(rp);
-                            y1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int ps = 0; ps < NP; ++ps) {
-                        const float* src = ep + (ps * RPP + rl) * EPITCH + cl * 8;
-                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
-                        const int m = mw + i * 32 + ps * RPP + rl;
-                        if (!lane_on || m >= p.M) continue;
-                        float v[8];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] = a0[e] + bcol[e]; v[e + 4] = a1[e] + bcol[e + 4]; }
-                        if (p.rowbias) {
-                            if (y_is_rb && full8 && vrb) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { v[e] += y0[ps][e]; v[e + 4] += y1[ps][e]; }
-                            } else {
-                                const float* rb = p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) if (ncol + e < Nout) v[e] += rb[e];
-                            }
-                        }
-                        (void)rb_inloop;
-                        if (act == PNC_ACT_SILU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-                        }
-                        if (xs) {                       // first residual (res1, or res2 when it is the only one)
-                            if (full8 && vx) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { v[e] += x0[ps][e]; v[e + 4] += x1[ps][e]; }
-                            } else {
-                                const float* rp = xs + (int64_t)m * ldx + ncol;
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) if (ncol + e < Nout) v[e] += rp[e];
-                            }
-                        }
-                        if (y_is_res2) {
-                            if (full8 && vr2) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { v[e] += y0[ps][e]; v[e + 4] += y1[ps][e]; }
-                            } else {
-                                const float* rp = p.res2 + (int64_t)m * p.ldr2 + ncol;
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) if (ncol + e < Nout) v[e] += rp[e];
-                            }
-                        }
-                        if (ab_nostore) { if (v[0] == 123.456f) p.out32[0] = v[1] + v[5]; continue; }
-                        if (p.out32) {
-                            float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
-                            if (full8 && v32) {
-                                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                                *reinterpret_cast<f32x4*>(op) = o0;
-                                *reinterpret_cast<f32x4*>(op + 4) = o1;
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) if (ncol + e < Nout) op[e] = v[e];
-                            }
-                        }
-                        if (out16) {
-                            half_t* op = out16 + (int64_t)m * p.ldc16 + ncol;
-                            if (full8 && v16) {
-                                half8v o;
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-                                *reinterpret_cast<half8v*>(op) = o;
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) if (ncol + e < Nout) op[e] = (half_t)v[e];
-                            }
-                        }
-                    }
-                    return;
-                }
-            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             f32x4 a0[NP], a1[NP], g0[NP], g1[NP];
 #pragma unroll

@@ -1,0 +1,94 @@
+"""Checkpoint and image I/O at the edges of the denoising path — host-side Python only.
+
+* `read_state_dict` / `load_denoiser` accept what the reference's `model_load_ckpt` accepts (inference.py:204-228):
+  a Lightning `.ckpt` (`{"state_dict": ...}`), a DeepSpeed-consolidated `.ckpt` (flat dict whose keys carry a
+  `_forward_module.` prefix) or a `.safetensors` file, and load the `model.diffusion_model.*` sub-tree (UNet +
+  `controlnet.*`) into an `OpenAIWrapperControlLDM3D` of this package with `strict=False`, reporting missing and
+  unexpected keys like the reference does.  The module tree and parameter names of `panacea_amd.nn` equal the
+  reference's (tests/golden/manifest_full.json: 2 478 tensors), so the published checkpoint drops in.
+* `save_view_frames` / `save_gif` write what `logs_frames` / `save_gif` write (inference.py:128-137,181-202): one JPEG
+  per (camera view, frame) cut out of the 6-view panorama, and an animated GIF of the panorama frames (Pillow only;
+  the reference uses imageio + torchvision for the same bytes-on-disk layout).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, List, Tuple
+
+import torch
+
+DENOISER_PREFIX = "model.diffusion_model."
+CAMERA_VIEWS = ("CAM_FRONT_LEFT", "CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_BACK_RIGHT", "CAM_BACK", "CAM_BACK_LEFT")
+# position of each camera inside the panorama (inference.py:115-122)
+VIEW_SLOT = {"CAM_FRONT": 0, "CAM_FRONT_RIGHT": 1, "CAM_BACK_RIGHT": 5, "CAM_BACK": 3, "CAM_BACK_LEFT": 4,
+             "CAM_FRONT_LEFT": 2}
+
+
+def read_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """The flat `name -> tensor` dict of a checkpoint file, in the three formats of inference.py:205-214."""
+    if path.endswith("safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    if path.endswith("ckpt"):
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        if isinstance(sd, dict) and "state_dict" in sd and not any(torch.is_tensor(v) for v in sd.values()):
+            sd = sd["state_dict"]                                   # Lightning
+        return {k.replace("_forward_module.", ""): v for k, v in sd.items() if torch.is_tensor(v)}   # DeepSpeed
+    raise NotImplementedError(f"Unknown checkpoint format: {path}")
+
+
+def denoiser_state_dict(sd: Dict[str, torch.Tensor], prefix: str = DENOISER_PREFIX) -> Dict[str, torch.Tensor]:
+    """Keys of the wrapped network only, with the engine prefix stripped (`model.diffusion_model.x` -> `x`)."""
+    out = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    if not out:                      # a state dict of the bare network (as written by our own tools)
+        out = {k: v for k, v in sd.items() if not k.startswith(("first_stage_model.", "conditioner.", "denoiser."))}
+    return out
+
+
+def load_denoiser(wrapper: torch.nn.Module, path: str, verbose: bool = True) -> Tuple[List[str], List[str]]:
+    """Load a reference checkpoint into `wrapper.diffusion_model` (strict=False, inference.py:216-226).
+    Returns (missing, unexpected).  Packed kernel-layout copies are invalidated by the load hook."""
+    sd = denoiser_state_dict(read_state_dict(path))
+    res = wrapper.diffusion_model.load_state_dict({k: v.to(torch.float32) for k, v in sd.items()}, strict=False)
+    missing, unexpected = list(res.missing_keys), list(res.unexpected_keys)
+    if verbose:
+        print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
+        if missing:
+            print(f"Missing Keys: {missing}")
+        if unexpected:
+            print(f"Unexpected Keys: {unexpected}")
+    return missing, unexpected
+
+
+def _to_uint8(img: torch.Tensor):
+    """(C, H, W) in [-1, 1] -> (H, W, C) uint8, like inference.py:189-193 (clamp, (x+1)/2, *255 truncated)."""
+    import numpy as np
+    x = torch.clamp(img.detach().float().cpu(), -1.0, 1.0)
+    x = ((x + 1.0) / 2.0).permute(1, 2, 0).numpy()
+    return (x * 255).astype(np.uint8)
+
+
+def save_view_frames(frames: torch.Tensor, root: str, sample_names: Iterable[str], view_width: int = 512) -> List[str]:
+    """frames: (T, 3, H, 6*view_width) panorama frames in [-1, 1]; `sample_names[i]` names the clip of camera slot i.
+    Writes `<root>/<name>/_{frame:06}.jpg` per view and frame (inference.py:181-202) and returns the paths."""
+    from PIL import Image
+    names = list(sample_names)
+    paths = []
+    for view in CAMERA_VIEWS:
+        i = VIEW_SLOT[view]
+        d = os.path.join(root, names[i])
+        os.makedirs(d, exist_ok=True)
+        for t in range(frames.shape[0]):
+            tile = frames[t][:, :, view_width * i: view_width * (i + 1)]
+            path = os.path.join(d, "_{:06}.jpg".format(t))
+            Image.fromarray(_to_uint8(tile)).save(path)
+            paths.append(path)
+    return paths
+
+
+def save_gif(frames: torch.Tensor, filename: str, fps: int = 4) -> str:
+    """(T, 3, H, W) in [-1, 1] -> looping GIF at 4 frames/s (inference.py:128-137)."""
+    from PIL import Image
+    imgs = [Image.fromarray(_to_uint8(f)) for f in frames]
+    imgs[0].save(filename, save_all=True, append_images=imgs[1:], duration=1000 // fps, loop=0)
+    return filename

@@ -28,33 +28,6 @@ __device__ __forceinline__ int lds_off128(int row, int chunk) {
 
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions): the results are rounded to fp16
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-// erf-exact GELU (attention.py:98 uses F.gelu's default).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7,
-// one exp + one rcp + 5 fma) instead of libm's erff (~3x the instructions): the result is rounded to fp16
-// (rel. 4.9e-4) right after, and the GEGLU epilogue runs once per 2x(M x 4C) accumulator pair.
-__device__ __forceinline__ float erf_as_f(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float r = 1.0f - poly * t * __expf(-ax * ax);
-    return copysignf(r, x);
-}
-__device__ __forceinline__ float gelu_erf_f(float v) {
-    // v * Phi(v) with Phi(|v|) = 1 - q, q = erfc(|v|/sqrt2)/2 (same A&S polynomial, coefficients halved):
-    // v >= 0: v - v q;  v < 0: v q = -|v| q   ->   max(v, 0) - |v| q   (no copysign / 1+erf / 0.5 v)
-    const float av = fabsf(v);
-    const float ax = av * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-    poly = fmaf(poly, t, 0.5f * 1.421413741f);
-    poly = fmaf(poly, t, 0.5f * -0.284496736f);
-    poly = fmaf(poly, t, 0.5f * 0.254829592f);
-    const float q = poly * t * __expf(-ax * ax);
-    return fmaf(-av, q, fmaxf(v, 0.0f));
-}
-
 // LDS DMA (global_load_lds_dwordx4): lane l's 16 bytes land at lds_wave_base + 16*l — the LDS image of one wave
 // instruction is lane-linear (1 KB), so any swizzle has to be applied to the SOURCE address
 __device__ __forceinline__ void glds16(const half_t* src, char* lds_wave_base) {

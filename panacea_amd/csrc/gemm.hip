@@ -61,6 +61,24 @@ __device__ __forceinline__ RowState make_row(const PncGemmParams& p, int m) {
 
 __device__ __attribute__((aligned(16))) half_t g_zero_chunk[8];   // zero-initialised: source of padded chunks
 
+// GEGLU gate: Phi(g) = (1 + erf(g / sqrt 2)) / 2 tabulated on [-8, 8) in steps of 1/128 as {Phi(x_i), Phi(x_{i+1}) - Phi(x_i)}
+// (16 KB, copied into LDS by the GEGLU GEMMs).  Linear interpolation error <= h^2/8 max|Phi''| = 1.8e-6 — 250x below
+// the fp16 rounding of the product it feeds — for 9 VALU + one ds_read_b64 per gate instead of ~14 VALU incl. exp + rcp:
+// the GEGLU epilogue is VALU-issue bound and ~40 % of a K = 320 GEMM (profiles/round1/gemm_timeline_r1i.txt).
+constexpr int PHI_N = 2048;
+constexpr float PHI_SCALE = 128.0f, PHI_X0 = -8.0f;
+constexpr int PHI_BYTES = PHI_N * 8;
+__device__ __attribute__((aligned(16))) float g_phi_table[2 * PHI_N];
+
+__device__ __forceinline__ float gelu_tab_f(float g, const float* tab) {
+    float t = fmaf(g, PHI_SCALE, -PHI_X0 * PHI_SCALE);
+    t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)PHI_N - 0.001f);
+    const int i = (int)t;
+    const float f = t - (float)i;
+    const float2 e = *reinterpret_cast<const float2*>(tab + 2 * i);
+    return g * fmaf(f, e.y, e.x);
+}
+
 // global source of the 16-byte chunk (row state s, k index kc) or the zero block
 template <int AMODE>
 __device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, const half_t* __restrict__ A,
@@ -257,7 +275,8 @@ __device__ __forceinline__ void epilogue_rowmajor_loads(const PncGemmParams& p, 
 // execute in order, so only lgkmcnt waits separate the phases — no workgroup barrier.
 template <int MI, int NI, bool GEGLU>
 __device__ __forceinline__ void epilogue_rowmajor(const PncGemmParams& p, f32x16 (&acc)[MI][NI], float* ep, int lane,
-                                                  int mw, int nw, bool ab_nostage, bool ab_nostore) {
+                                                  int mw, int nw, bool ab_nostage, bool ab_nostore,
+                                                  const float* phi_tab) {
     constexpr int ENI = NI < 2 ? NI : 2;
     constexpr int EPITCH = ENI * 32 + 4;
     constexpr int OUTC = GEGLU ? 32 : ENI * 32;             // output columns of one staged chunk
@@ -325,8 +344,8 @@ __device__ __forceinline__ void epilogue_rowmajor(const PncGemmParams& p, f32x16
                 if (GEGLU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] *= gelu_erf_f(g0[ps][e] + bgate[e]);
-                        v[e + 4] *= gelu_erf_f(g1[ps][e] + bgate[e + 4]);
+                        v[e] *= gelu_tab_f(g0[ps][e] + bgate[e], phi_tab);
+                        v[e + 4] *= gelu_tab_f(g1[ps][e] + bgate[e + 4], phi_tab);
                     }
                 } else {
                     if (p.rowbias) {
@@ -474,6 +493,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         for (int i = 0; i < B_IT; ++i)
             glds16((wrow[i] && kc < p.K) ? wrow[i] + kc : g_zero_chunk, sb + i * (RPI * 128));
     };
+
+    // GEGLU: the Phi table rides into LDS (behind the operand ring) with the first K tile
+    constexpr int RING_BYTES = STAGES * STAGE;
+    if (p.geglu) {
+#pragma unroll
+        for (int c = wave; c < PHI_BYTES / 1024; c += NW)
+            glds16(reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(g_phi_table) + c * 1024 + lane * 16),
+                   smem + RING_BYTES + c * 1024);
+    }
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -632,10 +660,31 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EPITCH);
     __syncthreads();                        // every wave is done reading operand tiles from LDS
     if (p.geglu) {
-        if constexpr (NI >= 2) epilogue_rowmajor<MI, NI, true>(p, acc, ep, lane, mw, nw, ab_nostage, ab_nostore);
+        if constexpr (NI >= 2)
+            epilogue_rowmajor<MI, NI, true>(p, acc, ep, lane, mw, nw, ab_nostage, ab_nostore,
+                                            reinterpret_cast<const float*>(smem + RING_BYTES));
     } else {
-        epilogue_rowmajor<MI, NI, false>(p, acc, ep, lane, mw, nw, ab_nostage, ab_nostore);
+        epilogue_rowmajor<MI, NI, false>(p, acc, ep, lane, mw, nw, ab_nostage, ab_nostore, nullptr);
     }
+}
+
+// One-time upload of the Phi table (host-computed in double).  Synchronous, hence not legal during stream capture: the
+// first GEGLU GEMM of a process has to run eagerly (every warm-up does).
+static int ensure_phi_table(hipStream_t st) {
+    static bool ready = false;
+    if (ready) return PNC_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return PNC_EINVAL;
+    static float host[2 * PHI_N];
+    auto phi = [](double x) { return 0.5 * (1.0 + erf(x * 0.70710678118654752440)); };
+    for (int i = 0; i < PHI_N; ++i) {
+        const double x0 = (double)PHI_X0 + (double)i / PHI_SCALE, x1 = (double)PHI_X0 + (double)(i + 1) / PHI_SCALE;
+        host[2 * i] = (float)phi(x0);
+        host[2 * i + 1] = (float)(phi(x1) - phi(x0));
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phi_table), host, sizeof(host)) != hipSuccess) return (int)hipGetLastError();
+    ready = true;
+    return PNC_OK;
 }
 
 // Workgroups of one geometry that are resident at once on the 256 CUs (LDS-limited: 160 KB per CU)
@@ -714,13 +763,13 @@ template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE>
 int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
     constexpr int lds = STAGES * (BM + BN) * 128;
     constexpr int threads = 64 * WGM * WGN;
-    static_assert(lds <= 160 * 1024, "LDS budget of one CU");
+    static_assert(lds + PHI_BYTES <= 160 * 1024, "LDS budget of one CU (operand ring + GEGLU table)");
     static_assert(lds >= WGM * WGN * 32 * 68 * 4, "epilogue staging must fit the operand ring");
     static bool attr_done = false;   // per-instantiation; idempotent
     auto kern = gemm_glds_kernel<AMODE, BM, BN, WGM, WGN, STAGES, PIPE>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds + PHI_BYTES);
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -729,7 +778,11 @@ int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
     const int blocks = ksplit > 1 ? tiles * ksplit : nfull + (tiles - nfull) * tail_f;
     PncGemmParams q = p;
     if (getenv("PNC_GEMM_NOLATE")) q.act |= 0x40000;         // A/B runs: all waves issue their DMA share after the barrier
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, st, q, ksplit, nfull, tail_f);
+    if (p.geglu) {
+        const int rc = ensure_phi_table(st);
+        if (rc != PNC_OK) return rc;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds + (p.geglu ? PHI_BYTES : 0), st, q, ksplit, nfull, tail_f);
     if (ksplit > 1) {
         const int64_t work = (int64_t)p.M * (p.N >> 3);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, p, ksplit);

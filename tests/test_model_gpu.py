@@ -65,6 +65,22 @@ def test_hip_path_other_timesteps_and_frames_vs_oracle():
     assert st["max_abs"] <= 4e-3 and st["mean_abs"] <= 8e-4, st
 
 
+def test_hip_path_single_frame_six_views_vs_oracle():
+    """BASELINE config 2 shape class: the 6-view network with num_frames = 1 (temporal attention over one frame, temporal
+    GroupNorm over C/32 x 1 values, conv1d with both neighbours padded) and a CFG batch of 2.  The T = 1 temporal
+    GroupNorm normalises 2 values per group, which amplifies operand rounding (same band as `plain1`)."""
+    kw = configs.with_frames(configs.get("tiny"), 1)
+    w, sd, _ = product_network("tiny", DEV, kw=kw)
+    inp = step_inputs("tiny", kw, "cpu", t_index=666, shape=(2, 1, 8, 96))
+    ref = po.wrapper_forward(sd, oracle_cfg(kw), inp["x"], inp["t"], cond(inp))
+    g = {k: v.to(DEV) for k, v in inp.items()}
+    eps = w(g["x"], g["t"], cond(g))
+    st = err_stats(eps, ref)
+    print("tiny, T=1, 6 views:", st)
+    assert st["ref_max"] > 1.0
+    assert st["max_abs"] <= 1.2e-2 and st["mean_abs"] <= 2e-3, st
+
+
 def test_full_network_small_panorama_vs_oracle():
     """Every tensor of the Panacea+ stage-2 network at its real width; latent 16x192 (L2 views 4x8, L3 views
     2x4 tokens: exercises the narrow-view gather of the attention kernel), B=1, T=2."""

@@ -67,8 +67,78 @@ def cpu_baseline(kw, sd, threads_note=True):
             "sample_seconds": dt}
 
 
+VAE_FULL = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                num_res_blocks=2, attn_resolutions=[], dropout=0.0)            # configs/inference_nuscenes.yaml:101-111
+
+
+def run_vae_decode(args, dev):
+    """`--stage vae-decode` (the step after the sampler loop): AutoencoderKL.decode of the 8 latent
+    frames of one sample, (8, 4, 32, 384) -> (8, 3, 256, 3072), synthetic weights, latents resident in HBM.  One "step"
+    = one decode.  Separate metric, never the headline."""
+    from panacea_amd import hip, synth
+    from panacea_amd.nn import model
+    hip.load()
+    fs = model.FirstStageDecoder(4, VAE_FULL)
+    man = {k: list(v.shape) for k, v in fs.state_dict().items()}
+    sd = synth.synth_state_dict(man)
+    fs.load_state_dict(sd, strict=True)
+    fs = fs.to(dev)
+    z = (torch.randn(8, 4, 32, 384, generator=torch.Generator().manual_seed(4)) * 2.0).to(dev)
+    with torch.no_grad():
+        for _ in range(max(1, args.warmup)):
+            img = fs.decode(z)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            img = fs.decode(z)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        assert img.shape == (8, 3, 256, 3072) and torch.isfinite(img).all()
+        prof = hip.Profiler()
+        hip.set_profiler(prof)
+        fs.decode(z)
+        hip.set_profiler(None)
+    summ = prof.summary()
+    flops = sum(v["flops"] for v in summ.values())
+    tot = sum(v["ms"] for v in summ.values())
+    kern = {}
+    for fam, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+        e = {"launches": v["launches"], "ms": round(v["ms"], 3), "share": round(v["ms"] / tot, 4)}
+        if v["flops"]:
+            e["TFLOP/s"] = round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)
+        elif v["bytes"]:
+            e["GB/s"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0)
+        kern[fam] = e
+    ach = flops / dt / 1e12
+    out = {"metric": "first-stage decodes/s (8 frames x 6 views x 256x512)", "value": 1.0 / dt, "unit": "decodes/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": dt * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": "AutoencoderKL.decode (ch 128, mult 1-2-4-4, 2 res blocks, mid attention over 12288 tokens) of "
+                                  "(8, 4, 32, 384) latents -> (8, 3, 256, 3072)", "stage": "vae-decode"},
+           "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                        "basis": f"{flops / 1e12:.2f} TFLOP per decode (2MNK of every contraction launched) / measured time",
+                        "kernels": kern, "kernel_ms_sum": round(tot, 2)}}
+    if not args.no_cpu_baseline:
+        from oracle import vae_oracle as vo
+        zs = torch.randn(1, 4, 16, 96, generator=torch.Generator().manual_seed(5)) * 2.0
+        with torch.no_grad():
+            vo.decode(sd, vo.VaeConfig(), zs[:, :, :8, :48])
+            t0 = time.time()
+            vo.decode(sd, vo.VaeConfig(), zs)
+            cdt = time.time() - t0
+        out["cpu_baseline"] = {"value": 1.0 / (cdt * 64), "unit": "decodes/s", "cores": torch.get_num_threads(),
+                               "host_cpus": os.cpu_count(), "kind": "port",
+                               "sample": f"oracle (fp32 torch) decode of 1 frame of a 16x96 latent: {cdt:.1f} s; x64 linear "
+                                         "extrapolation to 8 frames x 32x384 (under-counts the quadratic mid attention)",
+                               "sample_seconds": cdt}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--stage", default="denoise", choices=["denoise", "vae-decode"],
+                    help="denoise = the headline metric (default); vae-decode = first-stage decode of one sample's frames")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -96,6 +166,10 @@ def main():
     dev_index = local_rank if args.device is None else args.device
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    if args.stage == "vae-decode":
+        if world > 1:
+            raise SystemExit("--stage vae-decode is a single-GPU measurement")
+        return run_vae_decode(args, dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -5,7 +5,8 @@
 (see panacea_amd/dropin.py and INTEGRATION.md)."""
 try:
     import panacea_amd.dropin as _d
-    _d.install(lazy=True)
+    import os as _os
+    _d.install(lazy=True, first_stage=_os.environ.get("PANACEA_DROPIN_FIRST_STAGE") == "1")
 except Exception as _e:  # pragma: no cover - never break interpreter start-up
     import sys
     print(f"[panacea_amd] drop-in not armed: {_e}", file=sys.stderr)

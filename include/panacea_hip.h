@@ -190,6 +190,18 @@ int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16
 /* fp32 -> fp16 */
 int pnc_cast_f16(const float* x, int64_t n, void* y16, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * 5. First-stage decoder: row softmax of a materialised score
+ *    matrix, p[m][:] = softmax(scale * s[m][:]) (fp32 in, fp32 statistics, fp16
+ *    out), N <= 16384, N % 4 == 0.  The single-head d = 512 attention of the VAE
+ *    mid block runs as  S = Q K^T (pnc_gemm_f16, fp32 out) -> this -> O = P V
+ *    (pnc_gemm_f16 against the channel-major V^T).
+ *     -> AttnBlock / MemoryEfficientAttnBlock.attention
+ *        (sgm/modules/diffusionmodules/model.py:393-408, 444-472)
+ * ------------------------------------------------------------------------- */
+int pnc_softmax_rows_f16(const float* s, int64_t lds, int M, int N, float scale,
+                         void* p16, int64_t ldp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

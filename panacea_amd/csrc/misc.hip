@@ -199,6 +199,66 @@ extern "C" int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32
     return pnc_launch_status();
 }
 
+// row softmax: one 256-thread block per row, the row lives in registers (<= 16 x float4 per thread), one HBM read
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int64_t lds, int N, float scale,
+                                                           half_t* __restrict__ p, int64_t ldp) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = s + (int64_t)blockIdx.x * lds;
+    half_t* prow = p + (int64_t)blockIdx.x * ldp;
+    const int nv = N >> 2;
+    f32x4 v[16];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = tid + j * 256;
+        if (c < nv) {
+            v[j] = *reinterpret_cast<const f32x4*>(row + c * 4);
+            m = fmaxf(fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])), m);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = scale * 1.44269504088896340736f;
+    const float off = m * sc;
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = tid + j * 256;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[j][e] = __builtin_amdgcn_exp2f(fmaf(v[j][e], sc, -off)); sum += v[j][e]; }
+        }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (((red[4] + red[5]) + red[6]) + red[7]);     // fixed order: deterministic
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = tid + j * 256;
+        if (c < nv) {
+            half4v h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (half_t)(v[j][e] * inv);
+            *reinterpret_cast<half4v*>(prow + c * 4) = h;
+        }
+    }
+}
+
+extern "C" int pnc_softmax_rows_f16(const float* s, int64_t lds, int M, int N, float scale,
+                                    void* p16, int64_t ldp, void* stream) {
+    if (!s || !p16 || M < 1 || N < 4 || N > 16384 || (N & 3)) return PNC_EINVAL;
+    if ((lds & 3) || (ldp & 3) || lds < N || ldp < N) return PNC_EINVAL;
+    if (((uintptr_t)s & 15) || ((uintptr_t)p16 & 7)) return PNC_EALIGN;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)M), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, lds, N,
+                       scale, reinterpret_cast<half_t*>(p16), ldp);
+    return pnc_launch_status();
+}
+
 extern "C" int pnc_cast_f16(const float* x, int64_t n, void* y16, void* stream) {
     return pnc_add_f32(x, nullptr, n, nullptr, y16, stream);
 }

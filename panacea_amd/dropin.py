@@ -30,13 +30,19 @@ TARGETS = {
     "sgm.modules.diffusionmodules.controlmodel": ("ControlNet3D", "ControlledUNetModel3D"),
     "sgm.modules.diffusionmodules.wrappers": ("OpenAIWrapperControlLDM3D",),
 }
+# opt-in (install(first_stage=True) / PANACEA_DROPIN_FIRST_STAGE=1): the first-stage Decoder.  `sgm/models/autoencoder.py`
+# does `from ..modules.diffusionmodules.model import Decoder, Encoder`, so the class is rebound right after model.py
+# is first imported; the Encoder, quant / post_quant convs and the engine stay the reference's.
+FIRST_STAGE_TARGETS = {"sgm.modules.diffusionmodules.model": ("Decoder",)}
 
 
 def _patch(module) -> None:
     from . import nn as mirror
+    from .nn import model as first_stage
+    src = first_stage if module.__name__.endswith("diffusionmodules.model") else mirror
     for cls in TARGETS[module.__name__]:
         setattr(module, "_reference_" + cls, getattr(module, cls, None))
-        setattr(module, cls, getattr(mirror, cls))
+        setattr(module, cls, getattr(src, cls))
     if module.__name__.endswith("controlmodel"):
         # the mirror ControlledUNetModel3D resolves `controlnet_config.target` through the same (patched) module
         module._panacea_amd = True
@@ -71,10 +77,12 @@ class _Finder(importlib.abc.MetaPathFinder):
 _installed = False
 
 
-def install(lazy: bool = False) -> None:
-    """Rebind the three network classes.  lazy=False imports the reference modules now (they must be importable);
-    lazy=True only arms an import hook."""
+def install(lazy: bool = False, first_stage: bool = False) -> None:
+    """Rebind the three network classes (and, with first_stage=True, the VAE `Decoder`).  lazy=False imports the
+    reference modules now (they must be importable); lazy=True only arms an import hook."""
     global _installed
+    if first_stage:
+        TARGETS.update(FIRST_STAGE_TARGETS)
     if not _installed:
         sys.meta_path.insert(0, _Finder())
         _installed = True

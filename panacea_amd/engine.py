@@ -192,7 +192,9 @@ def invalidate_all(module: torch.nn.Module):
 # op helpers: allocate the output, call the backend
 # ----------------------------------------------------------------------------------------------
 def _ppc(npix: int) -> int:
-    return max(16, min(128, npix // 48))
+    """Pixels per GroupNorm chunk.  <= 128 on the denoiser's grids; image-resolution maps (first-stage decoder:
+    256x3072) get larger chunks so that the per-frame chunk count — which every apply block re-combines — stays <= 256."""
+    return max(16, min(128, npix // 48), -(-npix // 256))
 
 
 def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, beta, eps: float, silu: bool) -> torch.Tensor:

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "pnc_gemm_f16": (_I, [C.POINTER(GemmParams), _P]),
     "pnc_gemm_workspace_floats": (_L, [C.POINTER(GemmParams)]),
     "pnc_attn_views_f16": (_I, [C.POINTER(AttnParams), _P]),
+    "pnc_softmax_rows_f16": (_I, [_P, _L, _I, _I, _F, _P, _L, _P]),
     "pnc_attn_temporal_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "pnc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "pnc_groupnorm_apply": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P]),
@@ -242,6 +243,11 @@ def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H
     nkeys = sum(len(sv) for sv in segs) * kv_valid
     _check(_timed("attn_views", 4.0 * groups * heads * nq * nkeys * 64, 0.0, load().pnc_attn_views_f16,
                   C.byref(p), _stream()), "pnc_attn_views_f16")
+
+
+def softmax_rows(s32, lds, M, N, scale, p16, ldp):
+    _check(_timed("softmax_rows", 0.0, 6.0 * M * N, load().pnc_softmax_rows_f16, _ptr(s32), lds, M, N, scale, _ptr(p16),
+                  ldp, _stream()), "pnc_softmax_rows_f16")
 
 
 def attn_temporal(q, ldq, k, ldk, v, ldv, o, ldo, *, B, T, Npix, heads, scale):

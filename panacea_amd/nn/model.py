@@ -1,0 +1,313 @@
+"""First-stage decoder — host-side mirror of `sgm/modules/diffusionmodules/model.py` (Decoder, ResnetBlock,
+AttnBlock, Upsample, Normalize) plus the `post_quant_conv` of `sgm/models/autoencoder.py:AutoencoderKL` (SURVEY.md
+§8 f2).  Same constructor keywords, module tree and state-dict names as the reference, so the `first_stage_model.*`
+sub-tree of a checkpoint loads with `strict=False`; all arithmetic runs through the C-ABI kernels of the denoiser:
+
+* resident layout = channels-last tokens `[F*H*W, C]`, fp32 stream + fp16 operands (engine.py);
+* `Normalize` (GroupNorm 32, eps 1e-6) + swish (= SiLU, model.py:54-57)  -> pnc_groupnorm_stats/apply (silu flag);
+* every 3x3 conv, incl. nearest-2x `Upsample` + conv (model.py:65-77)     -> pnc_gemm_f16 implicit GEMM (upsample flag);
+* 1x1 `nin_shortcut`, q / k / v / proj_out                                 -> pnc_gemm_f16, residual adds in its epilogue;
+* the single-head d = C attention of the mid block (model.py:374-415)     -> S = Q K^T (fp32) -> pnc_softmax_rows_f16
+  -> O = P V against the channel-major V^T the v-projection writes; one frame at a time (12288^2 scores at 256x3072).
+
+The per-module `forward`s take/return NCHW tensors like the reference; `Decoder.forward` keeps everything resident.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .. import engine as E
+from ..engine import Act, Packable, Runtime
+from .util import act_from_nchw
+
+
+def Normalize(in_channels, num_groups=32):
+    """model.py:59-62"""
+    return torch.nn.GroupNorm(num_groups=num_groups, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+def _conv3x3_params(conv: nn.Conv2d):
+    return E.pk_conv3x3(conv.weight), E.pk_f32(conv.bias)
+
+
+def _conv1x1_params(conv: nn.Conv2d):
+    return E.pk_linear(conv.weight), E.pk_f32(conv.bias)
+
+
+def _gn_params(gn: nn.GroupNorm):
+    if gn.num_groups != 32:
+        raise NotImplementedError("only GroupNorm(32, C) is on the path")
+    return E.pk_f32(gn.weight), E.pk_f32(gn.bias)
+
+
+def _conv3x3(rt: Runtime, x16, F, Hin, Win, Cin, w16, b, Cout, *, upsample=False, res32=None, out16=False) -> Act:
+    Hout, Wout = (2 * Hin, 2 * Win) if upsample else (Hin, Win)
+    M = F * Hout * Wout
+    o32 = rt.empty((M, Cout), torch.float32)
+    o16 = rt.empty((M, Cout), torch.float16) if out16 else None
+    rt.be.gemm(x16, w16, M=M, N=Cout, K=9 * Cin, a_mode=E._hip.A_CONV3X3,
+               conv=dict(Cin=Cin, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=1, upsample=int(upsample)),
+               bias=b, res1=res32, ldr1=Cout, out32=o32, ldc32=Cout, out16=o16, ldc16=Cout)
+    return Act(F, Hout, Wout, Cout, f32=o32, f16=o16)
+
+
+class Upsample(nn.Module, Packable):
+    """model.py:65-77: nearest x2, then conv3x3 (folded into the conv's input gather)."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        self.with_conv = with_conv
+        if not with_conv:
+            raise NotImplementedError("Upsample without conv is not on the path (resamp_with_conv=True)")
+        self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        self._init_packable()
+
+    def _pack(self):
+        return dict(c=_conv3x3_params(self.conv))
+
+    def _run(self, rt: Runtime, x: Act) -> Act:
+        w, b = self.packed()["c"]
+        return _conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, w, b, x.C, upsample=True)
+
+    def forward(self, x):
+        rt = Runtime(x.device, x.shape[0], 1)
+        return self._run(rt, act_from_nchw(rt, x)).to_nchw().to(x.dtype)
+
+
+class ResnetBlock(nn.Module, Packable):
+    """model.py:139-196 with temb_channels = 0 (the autoencoder has no timestep embedding)."""
+
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=512):
+        super().__init__()
+        self.in_channels = in_channels
+        out_channels = in_channels if out_channels is None else out_channels
+        self.out_channels = out_channels
+        self.use_conv_shortcut = conv_shortcut
+        if temb_channels > 0:
+            raise NotImplementedError("ResnetBlock with a timestep embedding is not on the first-stage path")
+        if in_channels % 64 or out_channels % 64:
+            raise NotImplementedError("GroupNorm(32) kernels need channel counts that are multiples of 64")
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = torch.nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.norm2 = Normalize(out_channels)
+        self.dropout = torch.nn.Dropout(dropout)
+        self.conv2 = torch.nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if self.in_channels != self.out_channels:
+            if self.use_conv_shortcut:
+                self.conv_shortcut = torch.nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+            else:
+                self.nin_shortcut = torch.nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+        self._init_packable()
+
+    def _pack(self):
+        pk = dict(n1=_gn_params(self.norm1), c1=_conv3x3_params(self.conv1), n2=_gn_params(self.norm2),
+                  c2=_conv3x3_params(self.conv2))
+        if self.in_channels != self.out_channels:
+            pk["sc"] = _conv3x3_params(self.conv_shortcut) if self.use_conv_shortcut else _conv1x1_params(self.nin_shortcut)
+        return pk
+
+    def _run(self, rt: Runtime, x: Act) -> Act:
+        pk = self.packed()
+        Ci, Co = self.in_channels, self.out_channels
+        h16 = E.gn_spatial(rt, x.f32, x.F, x.N, Ci, *pk["n1"], 1e-6, True)
+        h = _conv3x3(rt, h16, x.F, x.H, x.W, Ci, *pk["c1"], Co)
+        h16 = E.gn_spatial(rt, h.f32, x.F, x.N, Co, *pk["n2"], 1e-6, True)
+        skip = x.f32
+        if Ci != Co:
+            w, b = pk["sc"]
+            if self.use_conv_shortcut:
+                skip = _conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, Ci, w, b, Co).f32
+            else:
+                skip = rt.empty((x.M, Co), torch.float32)
+                rt.be.gemm(x.need_f16(rt), w, M=x.M, N=Co, K=Ci, lda=Ci, bias=b, out32=skip, ldc32=Co)
+        return _conv3x3(rt, h16, x.F, x.H, x.W, Co, *pk["c2"], Co, res32=skip)      # x (or shortcut(x)) + h
+
+    def forward(self, x, temb=None):
+        assert temb is None
+        rt = Runtime(x.device, x.shape[0], 1)
+        return self._run(rt, act_from_nchw(rt, x)).to_nchw().to(x.dtype)
+
+
+class AttnBlock(nn.Module, Packable):
+    """model.py:374-415 (== MemoryEfficientAttnBlock :417-477): single-head self-attention over the h*w tokens of a frame."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        if in_channels % 64:
+            raise NotImplementedError("AttnBlock needs a channel count that is a multiple of 64")
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = torch.nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.k = torch.nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.v = torch.nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.proj_out = torch.nn.Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self._init_packable()
+
+    def _pack(self):
+        return dict(n=_gn_params(self.norm), q=_conv1x1_params(self.q), k=_conv1x1_params(self.k),
+                    v=_conv1x1_params(self.v), o=_conv1x1_params(self.proj_out))
+
+    def _run(self, rt: Runtime, x: Act) -> Act:
+        pk = self.packed()
+        C, N, M, F = self.in_channels, x.N, x.M, x.F
+        if N > 16384 or N % 8:
+            raise NotImplementedError(f"AttnBlock over {N} tokens per frame (supported: multiples of 8 up to 16384)")
+        h16 = E.gn_spatial(rt, x.f32, F, N, C, *pk["n"], 1e-6, False)
+        q16, k16 = rt.empty((M, C), torch.float16), rt.empty((M, C), torch.float16)
+        vt16 = rt.empty((F, C, N), torch.float16)                       # channel-major V^T per frame
+        rt.be.gemm(h16, pk["q"][0], M=M, N=C, K=C, lda=C, bias=pk["q"][1], out16=q16, ldc16=C)
+        rt.be.gemm(h16, pk["k"][0], M=M, N=C, K=C, lda=C, bias=pk["k"][1], out16=k16, ldc16=C)
+        rt.be.gemm(h16, pk["v"][0], M=M, N=C, K=C, lda=C, bias=pk["v"][1], out16t=vt16, ldt=N, t_rows=N,
+                   t_gstride=C * N, n_split=0)
+        o16 = rt.empty((M, C), torch.float16)
+        s32 = rt.empty((N, N), torch.float32)                           # one frame's scores at a time (reused)
+        p16 = rt.empty((N, N), torch.float16)
+        for f in range(F):
+            rt.be.gemm(q16[f * N:], k16[f * N:(f + 1) * N], M=N, N=N, K=C, lda=C, out32=s32, ldc32=N)
+            rt.be.softmax_rows(s32, N, N, N, float(C) ** -0.5, p16, N)
+            rt.be.gemm(p16, vt16[f], M=N, N=C, K=N, lda=N, out16=o16[f * N:], ldc16=C)
+        out = rt.empty((M, C), torch.float32)
+        rt.be.gemm(o16, pk["o"][0], M=M, N=C, K=C, lda=C, bias=pk["o"][1], res1=x.f32, ldr1=C, out32=out, ldc32=C)
+        return Act(F, x.H, x.W, C, f32=out)
+
+    def forward(self, x, **kwargs):
+        rt = Runtime(x.device, x.shape[0], 1)
+        return self._run(rt, act_from_nchw(rt, x)).to_nchw().to(x.dtype)
+
+
+def make_attn(in_channels, attn_type="vanilla", attn_kwargs=None, temporal=False):
+    """model.py:551-585: "vanilla" and "vanilla-xformers" are the same single-head attention."""
+    if attn_type in ("vanilla", "vanilla-xformers") and not temporal:
+        assert attn_kwargs is None
+        return AttnBlock(in_channels)
+    if attn_type == "none":
+        return nn.Identity(in_channels)
+    raise NotImplementedError(f"attn_type {attn_type!r} is not on the first-stage path")
+
+
+class Decoder(nn.Module, Packable):
+    """model.py:882-1026.  `forward(z)`: z (F, z_channels, h, w) -> image (F, out_ch, 8h, 8w) for ch_mult of length 4."""
+
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False, tanh_out=False,
+                 use_linear_attn=False, attn_type="vanilla", **ignorekwargs):
+        super().__init__()
+        if use_linear_attn:
+            raise NotImplementedError("linear attention is not on the first-stage path")
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.give_pre_end, self.tanh_out = give_pre_end, tanh_out
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, curr_res, curr_res)
+        self.z_channels = z_channels
+        self.conv_in = torch.nn.Conv2d(z_channels, block_in, kernel_size=3, stride=1, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type=attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks + 1):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(make_attn(block_in, attn_type=attn_type))
+            up = nn.Module()
+            up.block, up.attn = block, attn
+            if i_level != 0:
+                up.upsample = Upsample(block_in, resamp_with_conv)
+                curr_res = curr_res * 2
+            self.up.insert(0, up)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = torch.nn.Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
+        self.out_ch = out_ch
+        self._init_packable()
+
+    def get_last_layer(self, **kwargs):
+        return self.conv_out.weight
+
+    def _pack(self):
+        zc = (self.z_channels + 7) // 8 * 8
+        return dict(cin=(E.pk_conv3x3(self.conv_in.weight, zc), E.pk_f32(self.conv_in.bias)), zc=zc,
+                    no=_gn_params(self.norm_out), cout=_conv3x3_params(self.conv_out))
+
+    def _run(self, rt: Runtime, z16: torch.Tensor, F: int, H: int, W: int) -> Act:
+        """z16: [F*H*W, zc] fp16 tokens (channels zero-padded to zc)."""
+        pk = self.packed()
+        h = _conv3x3(rt, z16, F, H, W, pk["zc"], *pk["cin"], self.conv_in.out_channels)
+        h = self.mid.block_1._run(rt, h)
+        if isinstance(self.mid.attn_1, AttnBlock):
+            h = self.mid.attn_1._run(rt, h)
+        h = self.mid.block_2._run(rt, h)
+        for i_level in reversed(range(self.num_resolutions)):
+            up = self.up[i_level]
+            for i_block in range(self.num_res_blocks + 1):
+                h = up.block[i_block]._run(rt, h)
+                if len(up.attn) > 0:
+                    h = up.attn[i_block]._run(rt, h)
+            if i_level != 0:
+                h = up.upsample._run(rt, h)
+        if self.give_pre_end:
+            return h
+        h16 = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, *pk["no"], 1e-6, True)
+        w, b = pk["cout"]
+        return _conv3x3(rt, h16, h.F, h.H, h.W, h.C, w, b, self.out_ch)
+
+    def forward(self, z, **kwargs):
+        with torch.no_grad():
+            F, C, H, W = z.shape
+            rt = Runtime(z.device, F, 1)
+            zc = self.packed()["zc"]
+            z16 = rt.empty((F * H * W, zc), torch.float16)
+            rt.be.nchw_to_tokens_f16(z.detach().to(torch.float32).contiguous(), C, None, 0, F, H * W, zc, z16)
+            out = self._run(rt, z16, F, H, W).to_nchw()
+            if self.tanh_out:
+                out = torch.tanh(out)
+        return out.to(z.dtype)
+
+
+class FirstStageDecoder(nn.Module, Packable):
+    """The decode half of `AutoencoderKL` (autoencoder.py:333-368): `decoder(post_quant_conv(z))`.  Attribute names
+    match the reference's, so `load_state_dict(first_stage_sd, strict=False)` fills it (encoder / quant_conv /
+    loss keys are reported as unexpected, like any partial load)."""
+
+    def __init__(self, embed_dim: int, ddconfig: dict):
+        super().__init__()
+        self.decoder = Decoder(**ddconfig)
+        self.post_quant_conv = torch.nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+        self.embed_dim = embed_dim
+        self._init_packable()
+
+    def _pack(self):
+        # 1x1 conv embed_dim -> z_channels, both zero-padded to multiples of 8 so that its fp16 output is directly the
+        # padded token matrix conv_in gathers from
+        ec, zc = (self.embed_dim + 7) // 8 * 8, (self.decoder.z_channels + 7) // 8 * 8
+        w = torch.zeros((zc, ec), dtype=torch.float16, device=self.post_quant_conv.weight.device)
+        w[: self.decoder.z_channels, : self.embed_dim] = self.post_quant_conv.weight.detach().reshape(
+            self.decoder.z_channels, self.embed_dim).to(torch.float16)
+        b = torch.zeros(zc, dtype=torch.float32, device=w.device)
+        b[: self.decoder.z_channels] = self.post_quant_conv.bias.detach().float()
+        return dict(w=w.contiguous(), b=b, ec=ec, zc=zc)
+
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            pk = self.packed()
+            F, C, H, W = z.shape
+            rt = Runtime(z.device, F, 1)
+            M = F * H * W
+            e16 = rt.empty((M, pk["ec"]), torch.float16)
+            rt.be.nchw_to_tokens_f16(z.detach().to(torch.float32).contiguous(), C, None, 0, F, H * W, pk["ec"], e16)
+            z16 = rt.empty((M, pk["zc"]), torch.float16)
+            rt.be.gemm(e16, pk["w"], M=M, N=pk["zc"], K=pk["ec"], lda=pk["ec"], bias=pk["b"], out16=z16, ldc16=pk["zc"])
+            out = self.decoder._run(rt, z16, F, H, W).to_nchw()
+        return out.to(z.dtype)
+
+    forward = decode

@@ -123,6 +123,11 @@ def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H
         O[:, :, v * Wv:(v + 1) * Wv] = ov.half()
 
 
+def softmax_rows(s32, lds, M, N, scale, p16, ldp):
+    pr = torch.softmax(_mat(s32, M, N, lds).float() * scale, dim=-1)
+    _mat(p16, M, N, ldp).copy_(pr.half())
+
+
 def attn_temporal(q, ldq, k, ldk, v, ldv, o, ldo, *, B, T, Npix, heads, scale):
     Cc = heads * 64
     M = B * T * Npix

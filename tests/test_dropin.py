@@ -53,8 +53,13 @@ def test_dropin_rebinds_reference_targets():
         if m.startswith("sgm"):
             del sys.modules[m]
     dropin._installed = False
-    dropin.install(lazy=True)                                   # arm first, import the reference afterwards
+    dropin.install(lazy=True, first_stage=True)                 # arm first, import the reference afterwards
     ns = ref_import.import_reference()
+    import importlib
+    from panacea_amd.nn import model as first_stage
+    ref_model = importlib.import_module("sgm.modules.diffusionmodules.model")
+    assert ref_model.Decoder is first_stage.Decoder and ref_model._reference_Decoder is not None
+    assert ref_model.Encoder is not None and not issubclass(ref_model.Encoder, first_stage.Decoder)   # untouched
     assert ns.cm.ControlledUNetModel3D is mirror.ControlledUNetModel3D
     assert ns.cm.ControlNet3D is mirror.ControlNet3D
     assert ns.wr.OpenAIWrapperControlLDM3D is mirror.OpenAIWrapperControlLDM3D
@@ -74,3 +79,5 @@ def test_dropin_rebinds_reference_targets():
             del sys.modules[m]
     sys.meta_path[:] = [f for f in sys.meta_path if not isinstance(f, dropin._Finder)]
     dropin._installed = False
+    for k in dropin.FIRST_STAGE_TARGETS:
+        dropin.TARGETS.pop(k, None)

@@ -72,31 +72,38 @@ VAE_FULL = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_
 
 
 def run_vae_decode(args, dev):
-    """`--stage vae-decode` (the step after the sampler loop): AutoencoderKL.decode of the 8 latent
-    frames of one sample, (8, 4, 32, 384) -> (8, 3, 256, 3072), synthetic weights, latents resident in HBM.  One "step"
-    = one decode.  Separate metric, never the headline."""
+    """`--stage vae-decode` / `vae-encode` (the steps either side of the sampler loop):
+    AutoencoderKL.decode of the 8 latent frames of one sample, (8, 4, 32, 384) -> (8, 3, 256, 3072), or the posterior
+    moments of 8 panorama frames, (8, 3, 256, 3072) -> (8, 8, 32, 384); synthetic weights, inputs resident in HBM.
+    One "step" = one decode / encode.  Separate metrics, never the headline."""
     from panacea_amd import hip, synth
     from panacea_amd.nn import model
     hip.load()
-    fs = model.FirstStageDecoder(4, VAE_FULL)
+    enc = args.stage == "vae-encode"
+    fs = model.FirstStageEncoder(4, VAE_FULL) if enc else model.FirstStageDecoder(4, VAE_FULL)
     man = {k: list(v.shape) for k, v in fs.state_dict().items()}
     sd = synth.synth_state_dict(man)
     fs.load_state_dict(sd, strict=True)
     fs = fs.to(dev)
-    z = (torch.randn(8, 4, 32, 384, generator=torch.Generator().manual_seed(4)) * 2.0).to(dev)
+    if enc:
+        z = torch.tanh(torch.randn(8, 3, 256, 3072, generator=torch.Generator().manual_seed(4))).to(dev)
+        run, oshape = fs.moments, (8, 8, 32, 384)
+    else:
+        z = (torch.randn(8, 4, 32, 384, generator=torch.Generator().manual_seed(4)) * 2.0).to(dev)
+        run, oshape = fs.decode, (8, 3, 256, 3072)
     with torch.no_grad():
         for _ in range(max(1, args.warmup)):
-            img = fs.decode(z)
+            img = run(z)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            img = fs.decode(z)
+            img = run(z)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
-        assert img.shape == (8, 3, 256, 3072) and torch.isfinite(img).all()
+        assert img.shape == oshape and torch.isfinite(img).all()
         prof = hip.Profiler()
         hip.set_profiler(prof)
-        fs.decode(z)
+        run(z)
         hip.set_profiler(None)
     summ = prof.summary()
     flops = sum(v["flops"] for v in summ.values())
@@ -110,35 +117,40 @@ def run_vae_decode(args, dev):
             e["GB/s"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0)
         kern[fam] = e
     ach = flops / dt / 1e12
-    out = {"metric": "first-stage decodes/s (8 frames x 6 views x 256x512)", "value": 1.0 / dt, "unit": "decodes/s",
+    what = "encodes" if enc else "decodes"
+    out = {"metric": f"first-stage {what}/s (8 frames x 6 views x 256x512)", "value": 1.0 / dt, "unit": f"{what}/s",
            "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": dt * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-           "config": {"workload": "AutoencoderKL.decode (ch 128, mult 1-2-4-4, 2 res blocks, mid attention over 12288 tokens) of "
-                                  "(8, 4, 32, 384) latents -> (8, 3, 256, 3072)", "stage": "vae-decode"},
+           "config": {"workload": ("AutoencoderKL.encode moments" if enc else "AutoencoderKL.decode") +
+                      " (ch 128, mult 1-2-4-4, 2 res blocks, mid attention over 12288 tokens): " +
+                      ("(8, 3, 256, 3072) -> (8, 8, 32, 384)" if enc else "(8, 4, 32, 384) -> (8, 3, 256, 3072)"),
+                      "stage": args.stage},
            "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
-                        "basis": f"{flops / 1e12:.2f} TFLOP per decode (2MNK of every contraction launched) / measured time",
+                        "basis": f"{flops / 1e12:.2f} TFLOP per {what[:-1]} (2MNK of every contraction launched) / measured time",
                         "kernels": kern, "kernel_ms_sum": round(tot, 2)}}
     if not args.no_cpu_baseline:
         from oracle import vae_oracle as vo
-        zs = torch.randn(1, 4, 16, 96, generator=torch.Generator().manual_seed(5)) * 2.0
+        g5 = torch.Generator().manual_seed(5)
+        zs = torch.tanh(torch.randn(1, 3, 128, 768, generator=g5)) if enc else torch.randn(1, 4, 16, 96, generator=g5) * 2.0
+        ofn = (lambda t: vo.encode_moments(sd, vo.VaeConfig(), t)) if enc else (lambda t: vo.decode(sd, vo.VaeConfig(), t))
         with torch.no_grad():
-            vo.decode(sd, vo.VaeConfig(), zs[:, :, :8, :48])
+            ofn(zs[:, :, : zs.shape[2] // 2, : zs.shape[3] // 2])
             t0 = time.time()
-            vo.decode(sd, vo.VaeConfig(), zs)
+            ofn(zs)
             cdt = time.time() - t0
-        out["cpu_baseline"] = {"value": 1.0 / (cdt * 64), "unit": "decodes/s", "cores": torch.get_num_threads(),
+        out["cpu_baseline"] = {"value": 1.0 / (cdt * 64), "unit": f"{what}/s", "cores": torch.get_num_threads(),
                                "host_cpus": os.cpu_count(), "kind": "port",
-                               "sample": f"oracle (fp32 torch) decode of 1 frame of a 16x96 latent: {cdt:.1f} s; x64 linear "
-                                         "extrapolation to 8 frames x 32x384 (under-counts the quadratic mid attention)",
+                               "sample": f"oracle (fp32 torch) on 1 frame at 1/8 of the pixels (16x96 latent / 128x768 image): "
+                                         f"{cdt:.1f} s; x64 linear extrapolation (under-counts the quadratic mid attention)",
                                "sample_seconds": cdt}
     print(json.dumps(out), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--stage", default="denoise", choices=["denoise", "vae-decode"],
-                    help="denoise = the headline metric (default); vae-decode = first-stage decode of one sample's frames")
+    ap.add_argument("--stage", default="denoise", choices=["denoise", "vae-decode", "vae-encode"],
+                    help="denoise = the headline metric (default); vae-decode / vae-encode = first stage on one sample's frames")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -166,9 +178,9 @@ def main():
     dev_index = local_rank if args.device is None else args.device
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if args.stage == "vae-decode":
+    if args.stage != "denoise":
         if world > 1:
-            raise SystemExit("--stage vae-decode is a single-GPU measurement")
+            raise SystemExit("--stage vae-decode / vae-encode are single-GPU measurements")
         return run_vae_decode(args, dev)
     if world > 1:
         import torch.distributed as dist

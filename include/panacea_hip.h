@@ -91,6 +91,11 @@ typedef struct PncGemmParams {
      * fixed order (deterministic) in a second launch that also applies the epilogue. */
     float*  ws;
     int64_t ws_floats;
+    /* PNC_A_CONV3X3: 0 = one zero row/column on every side (Conv2d padding=1); 1 = zero padding on the bottom / right
+     * only, i.e. F.pad(x, (0,1,0,1)) + Conv2d(padding=0) — the stride-2 Downsample of the first-stage encoder
+     * (sgm/modules/diffusionmodules/model.py:108-112) */
+    int32_t conv_pad_br;
+    int32_t reserved0;
 } PncGemmParams;
 
 int pnc_gemm_f16(const PncGemmParams* p, void* stream);

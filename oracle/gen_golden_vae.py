@@ -45,6 +45,27 @@ def main():
     np.savez_compressed(ROOT / "tests" / "golden" / "vae_tiny.npz", z=z.numpy(), img=img.numpy(),
                         mid_s7=tr["mid"].reshape(-1)[::7].numpy(), up1_s7=tr["up.1"].reshape(-1)[::7].numpy(),
                         oracle_vs_reference=np.float32(err))
+    # ---- encoder: the reference's own Encoder + a quant_conv (autoencoder.py:346,348)
+    with contextlib.redirect_stdout(io.StringIO()):
+        enc = mdl.Encoder(**TINY).eval()
+    qc = torch.nn.Conv2d(8, 8, 1)
+    enames = {"encoder." + k: list(v.shape) for k, v in enc.state_dict().items()}
+    enames.update({"quant_conv." + k: list(v.shape) for k, v in qc.state_dict().items()})
+    (ROOT / "tests" / "golden" / "manifest_vae_enc_tiny.json").write_text(json.dumps(enames, indent=0))
+    esd = synth.synth_state_dict(enames)
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in esd.items() if k.startswith("encoder.")}, strict=True)
+    qc.load_state_dict({k[len("quant_conv."):]: v for k, v in esd.items() if k.startswith("quant_conv.")})
+    x = torch.tanh(torch.randn(2, 3, 16, 96, generator=g))
+    with torch.no_grad():
+        mom = qc(enc(x))
+        etr = {}
+        eora = vo.encode_moments(esd, vo.VaeConfig(ch=64, ch_mult=[1, 2], num_res_blocks=1), x, trace=etr)
+    eerr = (mom - eora).abs().max().item()
+    print(f"reference encoder {tuple(mom.shape)}  |moments| max {mom.abs().max():.3f} rms {mom.pow(2).mean().sqrt():.3f}; "
+          f"oracle vs reference max-abs {eerr:.2e}")
+    assert eerr < 1e-4
+    np.savez_compressed(ROOT / "tests" / "golden" / "vae_enc_tiny.npz", x=x.numpy(), moments=mom.numpy(),
+                        down0_s7=etr["down.0"].reshape(-1)[::7].numpy(), oracle_vs_reference=np.float32(eerr))
 
 
 if __name__ == "__main__":

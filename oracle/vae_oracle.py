@@ -84,3 +84,29 @@ def decode(sd: Dict[str, torch.Tensor], cfg: VaeConfig, z: torch.Tensor, trace=N
     """AutoencoderKL.decode: decoder(post_quant_conv(z))  (autoencoder.py:364-367)"""
     z = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
     return decoder_forward(sd, cfg, z, trace=trace)
+
+
+def encoder_forward(sd: Dict[str, torch.Tensor], cfg: VaeConfig, x: torch.Tensor, pre: str = "encoder", trace=None):
+    """Encoder.forward (model.py:852-880); Downsample = F.pad (0,1,0,1) + conv stride 2 padding 0 (model.py:108-112)"""
+    h = F.conv2d(x, sd[pre + ".conv_in.weight"], sd[pre + ".conv_in.bias"], padding=1)
+    nres = len(cfg.ch_mult)
+    for i_level in range(nres):
+        for i_block in range(cfg.num_res_blocks):
+            h = resnet_block(sd, f"{pre}.down.{i_level}.block.{i_block}", h)
+        if i_level != nres - 1:
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[f"{pre}.down.{i_level}.downsample.conv.weight"],
+                         sd[f"{pre}.down.{i_level}.downsample.conv.bias"], stride=2)
+        if trace is not None:
+            trace[f"down.{i_level}"] = h
+    h = resnet_block(sd, pre + ".mid.block_1", h)
+    if cfg.attn_mid:
+        h = attn_block(sd, pre + ".mid.attn_1", h)
+    h = resnet_block(sd, pre + ".mid.block_2", h)
+    h = _swish(_gn(h, sd, pre + ".norm_out"))
+    return F.conv2d(h, sd[pre + ".conv_out.weight"], sd[pre + ".conv_out.bias"], padding=1)
+
+
+def encode_moments(sd: Dict[str, torch.Tensor], cfg: VaeConfig, x: torch.Tensor, trace=None) -> torch.Tensor:
+    """AutoencoderKL.encode up to the posterior parameters: quant_conv(encoder(x))  (autoencoder.py:355-362)"""
+    h = encoder_forward(sd, cfg, x, trace=trace)
+    return F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])

@@ -103,7 +103,8 @@ __device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, con
             ok = (uy >= 0) && (uy < p.Hout) && (ux >= 0) && (ux < p.Wout);
             iy = uy >> 1; ix = ux >> 1;
         } else {
-            iy = s.y * p.stride + ky - 1; ix = s.x * p.stride + kx - 1;
+            const int pad = p.conv_pad_br ? 0 : 1;
+            iy = s.y * p.stride + ky - pad; ix = s.x * p.stride + kx - pad;
             ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
         }
         return ok ? A + s.base + ((int64_t)iy * p.Win + ix) * p.Cin + ci : g_zero_chunk;
@@ -870,6 +871,7 @@ extern "C" int pnc_gemm_f16(const PncGemmParams* pp, void* stream) {
         if (p.Cin % 8 || p.K != 9 * p.Cin || p.Hin <= 0 || p.Win <= 0) return PNC_EINVAL;
         if (p.stride != 1 && p.stride != 2) return PNC_EINVAL;
         if (p.upsample && (p.stride != 1 || p.Hout != 2 * p.Hin || p.Wout != 2 * p.Win)) return PNC_EINVAL;
+        if (p.conv_pad_br && (p.upsample || p.stride != 2)) return PNC_EINVAL;
         if (p.M % (p.Hout * p.Wout)) return PNC_EINVAL;
     } else if (p.a_mode == PNC_A_CONV1D_T) {
         if (p.Cin % 8 || p.K != 3 * p.Cin || p.T <= 0 || p.Npix <= 0) return PNC_EINVAL;

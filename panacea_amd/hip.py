@@ -47,6 +47,7 @@ class GemmParams(C.Structure):
         ("out16t", C.c_void_p), ("ldt", C.c_int32), ("t_rows", C.c_int32), ("t_gstride", C.c_int64),
         ("n_split", C.c_int32), ("act", C.c_int32), ("geglu", C.c_int32),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
+        ("conv_pad_br", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -208,6 +209,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
         p.Cin, p.Hin, p.Win = conv["Cin"], conv["Hin"], conv["Win"]
         p.Hout, p.Wout = conv["Hout"], conv["Wout"]
         p.stride, p.upsample = conv.get("stride", 1), int(conv.get("upsample", 0))
+        p.conv_pad_br = int(conv.get("pad_br", 0))
     if tconv:
         p.Cin, p.T, p.Npix = tconv["C"], tconv["T"], tconv["Npix"]
     p.bias, p.rowbias, p.rb_rows, p.rb_mod = _ptr(bias), _ptr(rowbias), rb_rows, rb_mod

@@ -43,13 +43,17 @@ def _gn_params(gn: nn.GroupNorm):
     return E.pk_f32(gn.weight), E.pk_f32(gn.bias)
 
 
-def _conv3x3(rt: Runtime, x16, F, Hin, Win, Cin, w16, b, Cout, *, upsample=False, res32=None, out16=False) -> Act:
-    Hout, Wout = (2 * Hin, 2 * Win) if upsample else (Hin, Win)
+def _conv3x3(rt: Runtime, x16, F, Hin, Win, Cin, w16, b, Cout, *, upsample=False, down_br=False, res32=None,
+             out16=False) -> Act:
+    if down_br and (Hin % 2 or Win % 2):
+        raise NotImplementedError("the stride-2 Downsample needs even image sizes")
+    Hout, Wout = (2 * Hin, 2 * Win) if upsample else ((Hin // 2, Win // 2) if down_br else (Hin, Win))
     M = F * Hout * Wout
     o32 = rt.empty((M, Cout), torch.float32)
     o16 = rt.empty((M, Cout), torch.float16) if out16 else None
     rt.be.gemm(x16, w16, M=M, N=Cout, K=9 * Cin, a_mode=E._hip.A_CONV3X3,
-               conv=dict(Cin=Cin, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=1, upsample=int(upsample)),
+               conv=dict(Cin=Cin, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=2 if down_br else 1,
+                         upsample=int(upsample), pad_br=int(down_br)),
                bias=b, res1=res32, ldr1=Cout, out32=o32, ldc32=Cout, out16=o16, ldc16=Cout)
     return Act(F, Hout, Wout, Cout, f32=o32, f16=o16)
 
@@ -71,6 +75,29 @@ class Upsample(nn.Module, Packable):
     def _run(self, rt: Runtime, x: Act) -> Act:
         w, b = self.packed()["c"]
         return _conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, w, b, x.C, upsample=True)
+
+    def forward(self, x):
+        rt = Runtime(x.device, x.shape[0], 1)
+        return self._run(rt, act_from_nchw(rt, x)).to_nchw().to(x.dtype)
+
+
+class Downsample(nn.Module, Packable):
+    """model.py:98-113: F.pad(x, (0, 1, 0, 1)) then conv3x3 stride 2 padding 0 (zero padding bottom / right only)."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        self.with_conv = with_conv
+        if not with_conv:
+            raise NotImplementedError("Downsample without conv (avg_pool2d) is not on the path (resamp_with_conv=True)")
+        self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+        self._init_packable()
+
+    def _pack(self):
+        return dict(c=_conv3x3_params(self.conv))
+
+    def _run(self, rt: Runtime, x: Act) -> Act:
+        w, b = self.packed()["c"]
+        return _conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, w, b, x.C, down_br=True)
 
     def forward(self, x):
         rt = Runtime(x.device, x.shape[0], 1)
@@ -272,6 +299,132 @@ class Decoder(nn.Module, Packable):
             if self.tanh_out:
                 out = torch.tanh(out)
         return out.to(z.dtype)
+
+
+class Encoder(nn.Module, Packable):
+    """model.py:763-880.  `forward(x)`: image (F, in_channels, H, W) -> moments (F, 2*z_channels, H/8, W/8)."""
+
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True, use_linear_attn=False,
+                 attn_type="vanilla", **ignore_kwargs):
+        super().__init__()
+        if use_linear_attn:
+            raise NotImplementedError("linear attention is not on the first-stage path")
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.conv_in = torch.nn.Conv2d(in_channels, self.ch, kernel_size=3, stride=1, padding=1)
+        curr_res = resolution
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.in_ch_mult = in_ch_mult
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_in = ch * in_ch_mult[i_level]
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(make_attn(block_in, attn_type=attn_type))
+            down = nn.Module()
+            down.block, down.attn = block, attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+                curr_res = curr_res // 2
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type=attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.norm_out = Normalize(block_in)
+        self.out_channels = 2 * z_channels if double_z else z_channels
+        self.conv_out = torch.nn.Conv2d(block_in, self.out_channels, kernel_size=3, stride=1, padding=1)
+        self._init_packable()
+
+    def _pack(self):
+        ic = (self.in_channels + 7) // 8 * 8
+        return dict(cin=(E.pk_conv3x3(self.conv_in.weight, ic), E.pk_f32(self.conv_in.bias)), ic=ic,
+                    no=_gn_params(self.norm_out), cout=_conv3x3_params(self.conv_out))
+
+    def _run(self, rt: Runtime, x16: torch.Tensor, F: int, H: int, W: int) -> Act:
+        """x16: [F*H*W, ic] fp16 tokens (channels zero-padded to ic).  Returns the moments as an Act (fp32)."""
+        pk = self.packed()
+        h = _conv3x3(rt, x16, F, H, W, pk["ic"], *pk["cin"], self.ch)
+        for i_level in range(self.num_resolutions):
+            down = self.down[i_level]
+            for i_block in range(self.num_res_blocks):
+                h = down.block[i_block]._run(rt, h)
+                if len(down.attn) > 0:
+                    h = down.attn[i_block]._run(rt, h)
+            if i_level != self.num_resolutions - 1:
+                h = down.downsample._run(rt, h)
+        h = self.mid.block_1._run(rt, h)
+        if isinstance(self.mid.attn_1, AttnBlock):
+            h = self.mid.attn_1._run(rt, h)
+        h = self.mid.block_2._run(rt, h)
+        h16 = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, *pk["no"], 1e-6, True)
+        w, b = pk["cout"]
+        return _conv3x3(rt, h16, h.F, h.H, h.W, h.C, w, b, self.out_channels)
+
+    def forward(self, x):
+        with torch.no_grad():
+            if x.dim() == 5:                                   # (b t c h w) video input (model.py:855-856)
+                x = x.reshape(-1, *x.shape[2:])
+            F, C, H, W = x.shape
+            rt = Runtime(x.device, F, 1)
+            ic = self.packed()["ic"]
+            x16 = rt.empty((F * H * W, ic), torch.float16)
+            rt.be.nchw_to_tokens_f16(x.detach().to(torch.float32).contiguous(), C, None, 0, F, H * W, ic, x16)
+            out = self._run(rt, x16, F, H, W).to_nchw()
+        return out.to(x.dtype)
+
+
+class FirstStageEncoder(nn.Module, Packable):
+    """The encode half of `AutoencoderKL` (autoencoder.py:333-362): moments = quant_conv(encoder(x)); the posterior is
+    DiagonalGaussianDistribution(moments): mean, logvar clamped to [-30, 20], sample = mean + exp(logvar / 2) * eps
+    (`AutoencoderKLInferenceWrapper.encode` returns `.sample()`, autoencoder.py:371-373)."""
+
+    def __init__(self, embed_dim: int, ddconfig: dict):
+        super().__init__()
+        assert ddconfig["double_z"]
+        self.encoder = Encoder(**ddconfig)
+        self.quant_conv = torch.nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
+        self.embed_dim = embed_dim
+        self._init_packable()
+
+    def _pack(self):
+        return dict(q=_conv1x1_params(self.quant_conv))
+
+    def moments(self, x: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            if x.dim() == 5:
+                x = x.reshape(-1, *x.shape[2:])
+            enc = self.encoder
+            F, C, H, W = x.shape
+            rt = Runtime(x.device, F, 1)
+            ic = enc.packed()["ic"]
+            x16 = rt.empty((F * H * W, ic), torch.float16)
+            rt.be.nchw_to_tokens_f16(x.detach().to(torch.float32).contiguous(), C, None, 0, F, H * W, ic, x16)
+            h = enc._run(rt, x16, F, H, W)
+            w, b = self.packed()["q"]
+            n = self.quant_conv.out_channels
+            m32 = rt.empty((h.M, n), torch.float32)
+            rt.be.gemm(h.need_f16(rt), w, M=h.M, N=n, K=h.C, lda=h.C, bias=b, out32=m32, ldc32=n)
+            return Act(h.F, h.H, h.W, n, f32=m32).to_nchw().to(x.dtype)
+
+    def encode(self, x: torch.Tensor, generator=None, sample: bool = True) -> torch.Tensor:
+        mom = self.moments(x)
+        mean, logvar = torch.chunk(mom, 2, dim=1)
+        if not sample:
+            return mean
+        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+        eps = torch.randn(mean.shape, generator=generator, device=mean.device, dtype=mean.dtype)
+        return mean + std * eps
+
+    forward = encode
 
 
 class FirstStageDecoder(nn.Module, Packable):

@@ -51,7 +51,10 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
             w = Wm.view(N, Cin // 64, 3, 3, 64).permute(0, 1, 4, 2, 3).reshape(N, Cin, 3, 3)
         else:                 # K order (ky, kx, ci)
             w = Wm.view(N, 3, 3, Cin).permute(0, 3, 1, 2)
-        y = TF.conv2d(x, w, stride=stride, padding=1)
+        if conv.get("pad_br", 0):
+            y = TF.conv2d(TF.pad(x, (0, 1, 0, 1)), w, stride=stride, padding=0)
+        else:
+            y = TF.conv2d(x, w, stride=stride, padding=1)
         assert y.shape[2] == Hout and y.shape[3] == Wout, (y.shape, Hout, Wout)
         acc = y.permute(0, 2, 3, 1).reshape(M, N)
     else:

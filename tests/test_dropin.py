@@ -18,8 +18,9 @@ def test_cabi_library_loads_and_exports_header_symbols():
         assert getattr(lib, s) is not None
     assert lib.pnc_version().decode().startswith("panacea_hip")
     # struct layouts of the two parameter blocks (must match include/panacea_hip.h)
-    assert ctypes.sizeof(hip.GemmParams) == 216 and hip.GemmParams.t_gstride.offset == 176
+    assert ctypes.sizeof(hip.GemmParams) == 224 and hip.GemmParams.t_gstride.offset == 176
     assert hip.GemmParams.ws.offset == 200 and hip.GemmParams.ws_floats.offset == 208
+    assert hip.GemmParams.conv_pad_br.offset == 216
     assert ctypes.sizeof(hip.AttnParams) == 216 and hip.AttnParams.scale.offset == 208
 
 

@@ -59,6 +59,79 @@ def test_mirror_module_tree_and_host_logic_vs_reference():
     assert res.missing_keys == [] and sorted(res.unexpected_keys) == ["encoder.conv_in.weight", "quant_conv.weight"]
 
 
+def _tiny_enc():
+    man = json.loads((GOLDEN / "manifest_vae_enc_tiny.json").read_text())
+    return man, synth.synth_state_dict(man), np.load(GOLDEN / "vae_enc_tiny.npz")
+
+
+def test_encoder_oracle_and_host_logic_vs_reference():
+    man, sd, g = _tiny_enc()
+    x = torch.from_numpy(g["x"])
+    tr = {}
+    mom = vo.encode_moments(sd, vo.VaeConfig(ch=64, ch_mult=[1, 2], num_res_blocks=1), x, trace=tr)
+    assert np.abs(mom.numpy() - g["moments"]).max() < 2e-5
+    assert np.abs(tr["down.0"].reshape(-1)[::7].numpy() - g["down0_s7"]).max() < 2e-5
+    fe = model.FirstStageEncoder(4, TINY)
+    assert {k: list(v.shape) for k, v in fe.state_dict().items()} == man
+    fe.load_state_dict(sd, strict=True)
+    with E.use_backend(emu):
+        got = fe.moments(x)
+        z_mean = fe.encode(x, sample=False)
+        z1 = fe.encode(x, generator=torch.Generator().manual_seed(1))
+    d = np.abs(got.numpy() - g["moments"])
+    assert got.shape == (2, 8, 8, 48) and d.max() < 8e-3 and d.mean() < 1e-3, (d.max(), d.mean())
+    assert torch.equal(z_mean, got[:, :4]) and z1.shape == (2, 4, 8, 48) and not torch.equal(z1, z_mean)
+    with pytest.raises(NotImplementedError):
+        model.Downsample(64, with_conv=False)
+
+
+@pytest.mark.gpu
+def test_encoder_hip_matches_reference_golden_and_roundtrip_shapes():
+    man, sd, g = _tiny_enc()
+    fe = model.FirstStageEncoder(4, TINY)
+    fe.load_state_dict(sd, strict=True)
+    fe = fe.to(DEV)
+    got = fe.moments(torch.from_numpy(g["x"]).to(DEV))
+    torch.cuda.synchronize()
+    d = (got.cpu() - torch.from_numpy(g["moments"])).abs()
+    print("vae encoder tiny vs reference:", d.max().item(), d.mean().item())
+    assert d.max().item() < 8e-3 and d.mean().item() < 1e-3
+    assert torch.equal(got, fe.moments(torch.from_numpy(g["x"]).to(DEV)))
+    # the nuScenes first stage on one 256x768 strip (mid attention over 32x96 tokens), against the oracle
+    fe = model.FirstStageEncoder(4, FULL)
+    fman = {k: list(v.shape) for k, v in fe.state_dict().items()}
+    fsd = synth.synth_state_dict(fman)
+    fe.load_state_dict(fsd, strict=True)
+    x = torch.tanh(torch.randn(1, 3, 128, 384, generator=torch.Generator().manual_seed(8)))
+    ref = vo.encode_moments(fsd, vo.VaeConfig(), x)
+    got = fe.to(DEV).moments(x.to(DEV))
+    d = (got.cpu() - ref).abs()
+    print("vae encoder full-width, 128x384 image vs oracle:", d.max().item(), d.mean().item(), "ref max", ref.abs().max().item())
+    assert got.shape == (1, 8, 16, 48) and d.max().item() < 2e-2 and d.mean().item() < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,Hin,Win,Cin,N", [(2, 8, 24, 64, 64), (1, 16, 48, 128, 128), (1, 6, 10, 8, 32)])
+def test_conv3x3_stride2_bottom_right_padding(F, Hin, Win, Cin, N):
+    from panacea_amd import hip
+    Hout, Wout = Hin // 2, Win // 2
+    M, K = F * Hout * Wout, 9 * Cin
+    g = torch.Generator().manual_seed(Cin + Hin)
+    x = torch.randn(F, Hin, Win, Cin, generator=g).half().to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    conv = dict(Cin=Cin, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=2, upsample=0, pad_br=1)
+    oh, oe = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+    hip.gemm(x, w, M=M, N=N, K=K, a_mode=hip.A_CONV3X3, conv=conv, bias=bias, out32=oh, ldc32=N)
+    emu.gemm(x, w, M=M, N=N, K=K, a_mode=emu.A_CONV3X3, conv=conv, bias=bias, out32=oe, ldc32=N)
+    torch.cuda.synchronize()
+    assert (oh - oe).abs().max().item() < 3e-3
+    # it is NOT the symmetric-padding stride-2 conv
+    conv_sym = dict(conv, pad_br=0)
+    emu.gemm(x, w, M=M, N=N, K=K, a_mode=emu.A_CONV3X3, conv=conv_sym, bias=bias, out32=oe, ldc32=N)
+    assert (oh - oe).abs().max().item() > 1e-1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,lds,scale", [(37, 384, 384, 0.125), (5, 12288, 12288, 512 ** -0.5), (64, 1000, 1024, 1.0),
                                            (3, 16384, 16384, 0.05), (9, 4, 8, 2.0)])

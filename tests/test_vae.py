@@ -192,3 +192,36 @@ def test_decoder_full_size_against_oracle_on_a_crop_and_timing():
     dt = time.perf_counter() - t0
     assert out.shape == (8, 3, 256, 3072) and torch.isfinite(out).all()
     print(f"decode of 8 frames at 256x3072: {dt * 1e3:.1f} ms  (~62 TFLOP => {62.0 / dt:.0f} TFLOP/s)")
+
+
+def _tiny_pipeline(device):
+    from helpers import product_network, step_inputs
+    w, _, kw = product_network("tiny", device)
+    inp = step_inputs("tiny", kw, device)
+    T = kw["num_frames"]
+    c = {"crossattn": inp["crossattn"][1:2], "concat": inp["concat"][T:], "cond_feat": inp["cond_feat"][T:]}
+    uc = {"crossattn": inp["crossattn"][0:1], "concat": inp["concat"][:T], "cond_feat": inp["cond_feat"][:T]}
+    _, sd, _ = _tiny()
+    fs = model.FirstStageDecoder(4, TINY)
+    fs.load_state_dict(sd, strict=True)
+    return w, fs.to(device), c, uc, inp["x"][T:]
+
+
+def test_pipeline_latents_to_frames_composes_on_the_emulated_backend(tmp_path):
+    from panacea_amd import checkpoint as ck, pipeline
+    w, fs, c, uc, noise = _tiny_pipeline("cpu")
+    with E.use_backend(emu):
+        a = pipeline.sample_frames(w, fs, c, uc, noise, num_steps=2, hoist=True)
+        b = pipeline.sample_frames(w, fs, c, uc, noise, num_steps=2, hoist=False)
+    assert a.shape == (noise.shape[0], 3, 8 * 2, 96 * 2) and torch.isfinite(a).all() and torch.equal(a, b)
+    assert len(ck.save_view_frames(a, str(tmp_path), [f"v{i}" for i in range(6)], view_width=a.shape[-1] // 6)) == 6 * a.shape[0]
+
+
+@pytest.mark.gpu
+def test_pipeline_latents_to_frames_on_the_gpu():
+    from panacea_amd import pipeline
+    w, fs, c, uc, noise = _tiny_pipeline(DEV)
+    a = pipeline.sample_frames(w, fs, c, uc, noise, num_steps=3)
+    b = pipeline.sample_frames(w, fs, c, uc, noise, num_steps=3, hoist=False)
+    torch.cuda.synchronize()
+    assert a.shape == (noise.shape[0], 3, 16, 192) and torch.isfinite(a).all() and torch.equal(a, b)

@@ -341,14 +341,23 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(
     const int col = head * 64 + dl * 8;
     const int64_t row_q = ((int64_t)(b * T + tc)) * Npix + pixc;
     const half8v q = *reinterpret_cast<const half8v*>(Q + row_q * ldq + col);
+    // Each lane loads the K and V chunk of ITS OWN (pixel, frame) once and parks them in a wave-private LDS slab; the
+    // T x T products then read the other frames' chunks from LDS (same-address reads broadcast).  Loading every key /
+    // value row once per QUERY frame instead (8x the L1 traffic) held the kernel at 2.4 TB/s of HBM-equivalent.
+    __shared__ __attribute__((aligned(16))) half8v skv[4][2][64];
+    const int wv = threadIdx.x >> 6;
+    skv[wv][0][lane] = *reinterpret_cast<const half8v*>(Kp + row_q * ldk + col);
+    skv[wv][1][lane] = *reinterpret_cast<const half8v*>(Vp + row_q * ldv + col);
+    // (one wave = one LDS slab: wave-level execution order makes the writes visible to the reads below)
+    __builtin_amdgcn_wave_barrier();
     float sc[8];
     float mx = -1e30f;
     const float c = scale * 1.44269504088896340736f;
+    const int lbase = (ps * T) * 8 + dl;          // lane of (this pixel, frame 0, this channel chunk)
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         if (s < T) {
-            const int64_t row_k = ((int64_t)(b * T + s)) * Npix + pixc;
-            const half8v k = *reinterpret_cast<const half8v*>(Kp + row_k * ldk + col);
+            const half8v k = skv[wv][0][ok ? lbase + s * 8 : lane];
             float d = dot8(q, k);
             d += __shfl_xor(d, 1, 64);
             d += __shfl_xor(d, 2, 64);
@@ -367,8 +376,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         if (s < T) {
-            const int64_t row_v = ((int64_t)(b * T + s)) * Npix + pixc;
-            const half8v v = *reinterpret_cast<const half8v*>(Vp + row_v * ldv + col);
+            const half8v v = skv[wv][1][ok ? lbase + s * 8 : lane];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = fmaf(sc[s], (float)v[i], acc[i]);
         }

@@ -134,31 +134,40 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const int p0 = chunk * ppc;
     const int p1 = min(Npix, p0 + ppc);
     const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 2
-    for (int pix = p0 + wave; pix < p1; pix += 4) {
-        const int64_t r = (int64_t)f * Npix + pix;
-        const float* row = x + r * ldx;
-        half_t* yrow = y + r * ldy;
-        f32x4 v[J];
+    // R pixel rows per wave in flight: all their loads are issued before the first use (like layernorm_kernel's LN_R)
+    constexpr int R = J <= 3 ? 4 : (J <= 6 ? 2 : 1);
+    for (int pix0 = p0 + wave; pix0 < p1; pix0 += 4 * R) {
+        f32x4 v[R][J];
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const int cv = lane + j * 64;
-            v[j] = (cv < CV) ? *reinterpret_cast<const f32x4*>(row + cv * 4) : z;
+        for (int rr = 0; rr < R; ++rr) {
+            const int pix = pix0 + 4 * rr;
+            const float* row = x + ((int64_t)f * Npix + pix) * ldx;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int cv = lane + j * 64;
+                v[rr][j] = (cv < CV && pix < p1) ? *reinterpret_cast<const f32x4*>(row + cv * 4) : z;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const int cv = lane + j * 64;
-            if (cv < CV) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(sA + cv * 4);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(sB + cv * 4);
-                half4v h;
+        for (int rr = 0; rr < R; ++rr) {
+            const int pix = pix0 + 4 * rr;
+            if (pix >= p1) break;
+            half_t* yrow = y + ((int64_t)f * Npix + pix) * ldy;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float o = fmaf(v[j][e], a[e], b[e]);
-                    if (silu) o = silu_f(o);
-                    h[e] = (half_t)o;
+            for (int j = 0; j < J; ++j) {
+                const int cv = lane + j * 64;
+                if (cv < CV) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(sA + cv * 4);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(sB + cv * 4);
+                    half4v h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float o = fmaf(v[rr][j][e], a[e], b[e]);
+                        if (silu) o = silu_f(o);
+                        h[e] = (half_t)o;
+                    }
+                    *reinterpret_cast<half4v*>(yrow + cv * 4) = h;
                 }
-                *reinterpret_cast<half4v*>(yrow + cv * 4) = h;
             }
         }
     }

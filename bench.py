@@ -320,6 +320,17 @@ def main():
             kern[fam] = e
         out.setdefault("roofline", {})["kernels"] = kern
         out["roofline"]["kernel_ms_sum"] = round(tot, 2)
+        # the dominant kernel family on its own: algorithmic flops of its launches / HIP-event time of its launches
+        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        if dom[1]["flops"]:
+            tf = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
+            out["roofline"]["dominant_kernel"] = {
+                "family": dom[0], "kernel": "gemm_glds_kernel<PNC_A_PLAIN, ...> (all tile geometries)" if dom[0] == "gemm_plain" else dom[0],
+                "launches_per_step": dom[1]["launches"], "avg_launch_us": round(dom[1]["ms"] * 1e3 / dom[1]["launches"], 1),
+                "algorithmic_TFLOP_per_step": round(dom[1]["flops"] / 1e12, 2), "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                "note": "one-stream instrumented step (HIP events on the launch stream); rocprofv3 --kernel-trace --stats of "
+                        "`bench.py --one-stream` is committed under profiles/ for the same build"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "full":
         del net
         torch.cuda.empty_cache()

@@ -294,18 +294,38 @@ __global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams
     for (int qb = 0; qb < QB; ++qb) {
         const float ltot = lrun[qb] + __shfl_xor(lrun[qb], 32, 64);
         const float inv = ltot > 0.0f ? 1.0f / ltot : 0.0f;
-        if (qok[qb]) {
-            half_t* orow = O + qrow[qb] * p.ldo + hc;
+        // The lane pair (l, l+32) holds channels 8*r4 + {0..3} / {4..7} of the same query.  One xor-32 exchange per pair
+        // of r4 gives each lane 8 CONSECUTIVE channels (r4 even -> lower lane, r4 odd -> upper lane): 4 stores of 16 B
+        // per query block instead of 8 stores of 8 B (32-byte instead of 16-byte contiguous pieces per row).
+        half_t* orow = O + qrow[qb] * p.ldo + hc;
+        const bool vec16 = ((p.ldo & 7) == 0) && (((uintptr_t)p.o & 15) == 0);
 #pragma unroll
-            for (int dh = 0; dh < 2; ++dh)
+        for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    half4v h;
+            for (int rp = 0; rp < 2; ++rp) {
+                half4v he, ho;                                  // this lane's channels of r4 = 2 rp and 2 rp + 1
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) h[q] = (half_t)(oacc[qb][dh][r4 * 4 + q] * inv);
-                    *reinterpret_cast<half4v*>(orow + dh * 32 + 8 * r4 + 4 * grp) = h;
+                for (int q = 0; q < 4; ++q) {
+                    he[q] = (half_t)(oacc[qb][dh][(2 * rp) * 4 + q] * inv);
+                    ho[q] = (half_t)(oacc[qb][dh][(2 * rp + 1) * 4 + q] * inv);
                 }
-        }
+                if (vec16) {
+                    union { half4v h; int2 i; } snd, rcv;
+                    snd.h = grp ? he : ho;                      // what the partner lane stores
+                    rcv.i.x = __shfl_xor(snd.i.x, 32, 64);
+                    rcv.i.y = __shfl_xor(snd.i.y, 32, 64);
+                    half8v o8;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o8[q] = grp ? rcv.h[q] : he[q];
+                        o8[4 + q] = grp ? ho[q] : rcv.h[q];
+                    }
+                    if (qok[qb]) *reinterpret_cast<half8v*>(orow + dh * 32 + 8 * (2 * rp + grp)) = o8;
+                } else if (qok[qb]) {
+                    *reinterpret_cast<half4v*>(orow + dh * 32 + 8 * (2 * rp) + 4 * grp) = he;
+                    *reinterpret_cast<half4v*>(orow + dh * 32 + 8 * (2 * rp + 1) + 4 * grp) = ho;
+                }
+            }
     }
 }
 

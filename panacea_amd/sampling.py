@@ -152,6 +152,16 @@ def hoist_invariants(network, guider, cond: Dict, uc: Dict):
     them.  The concatenated conditioning tensors are built ONCE here and shared by every step (prepare_inputs would
     otherwise re-concatenate them per step, which also changes their identity)."""
     model = network.diffusion_model
+    half = getattr(guider, "half", None)
+    if half is not None:
+        # parallel.ShardedCFG: this rank evaluates ONE CFG half with that half's own tensors (same objects every step)
+        src = dict(uc if half == 0 else cond)
+        src["crossattn"] = src["crossattn"].to(model.controlnet.input_hint_block[0].weight.dtype)
+        inv = model.prepare(src["crossattn"], src["cond_feat"])
+        c2, u2 = dict(cond), dict(uc)
+        (u2 if half == 0 else c2).update(crossattn=src["crossattn"])
+        c2["_invariants"] = u2["_invariants"] = inv
+        return c2, u2
     if guider is None:
         c2 = dict(cond)
         c2["crossattn"] = cond["crossattn"].to(model.controlnet.input_hint_block[0].weight.dtype)

@@ -38,6 +38,9 @@ def _worker(rank, world, port, out_dir):
         denoiser = lambda xi, sigma, cc: den(net, xi, sigma, cc)     # noqa: E731
         smp = S.EulerEDMSampler(3, guider=parallel.ShardedCFG(5.0, groups[rank // 2], rank % 2), device="cpu")
         xs = smp(denoiser, x0.clone(), cond, uc)
+        # hoisted step invariants compose with the sharded guider (each rank prepares its own half): same bits
+        xs_h = smp(denoiser, x0.clone(), cond, uc, network=net)
+        assert torch.equal(xs_h, xs)
         # the same sharding around a closed-form network: must agree with the single-process guider exactly
         def fake_net(a, t, c_):       # per-sample closed form (text statistic of the frame's own sample)
             txt = c_["crossattn"].mean(dim=(1, 2)).repeat_interleave(a.shape[0] // c_["crossattn"].shape[0])

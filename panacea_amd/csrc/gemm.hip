@@ -672,7 +672,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
 // One-time upload of the Phi table (host-computed in double).  Synchronous, hence not legal during stream capture: the
 // first GEGLU GEMM of a process has to run eagerly (every warm-up does).
 static int ensure_phi_table(hipStream_t st) {
-    static bool ready = false;
+    static bool ready_dev[64] = {};                  // the table is a per-device symbol
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& ready = ready_dev[dev & 63];
     if (ready) return PNC_OK;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return PNC_EINVAL;
@@ -766,7 +769,10 @@ int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
     constexpr int threads = 64 * WGM * WGN;
     static_assert(lds + PHI_BYTES <= 160 * 1024, "LDS budget of one CU (operand ring + GEGLU table)");
     static_assert(lds >= WGM * WGN * 32 * 68 * 4, "epilogue staging must fit the operand ring");
-    static bool attr_done = false;   // per-instantiation; idempotent
+    static bool attr_done_dev[64] = {};   // per instantiation and device; idempotent
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& attr_done = attr_done_dev[dev & 63];
     auto kern = gemm_glds_kernel<AMODE, BM, BN, WGM, WGN, STAGES, PIPE>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

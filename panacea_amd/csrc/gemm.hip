@@ -628,26 +628,57 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
                 const int n = nw + j * 32 + col;
                 if (n >= p.N) return;
                 const float bn = p.bias ? p.bias[n] : 0.0f;
+                const int grp = lane >> 5;
+                const bool al16 = ((p.ldt & 7) == 0) && ((p.t_gstride & 7) == 0) && (((uintptr_t)p.out16t & 15) == 0);
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int mb = mw + i * 32 + 8 * r4 + 4 * (lane >> 5);
-                    float v[4];
+                for (int rp = 0; rp < 2; ++rp) {
+                    // rows 8*r4 + {0..3} live in lane l, {4..7} in lane l+32 (same column): one xor-32 exchange per
+                    // pair of r4 gives each lane 8 consecutive rows -> 16-byte stores along the token axis of V^T
+                    half4v he, ho;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = acc[i][j][r4 * 4 + q] + bn;
-                    const int g = mb / p.t_rows, tr = mb - g * p.t_rows;
-                    half_t* dst = out16t + (int64_t)g * p.t_gstride + (int64_t)(n - p.n_split) * p.ldt + tr;
-                    const bool vec = (mb + 3 < p.M) && (tr + 3 < p.t_rows) && ((p.ldt & 3) == 0) &&
-                                     ((p.t_gstride & 3) == 0) && ((tr & 3) == 0);
-                    if (vec) {
-                        half4v h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *reinterpret_cast<half4v*>(dst) = h;
-                    } else {
+                    for (int q = 0; q < 4; ++q) {
+                        he[q] = (half_t)(acc[i][j][(2 * rp) * 4 + q] + bn);
+                        ho[q] = (half_t)(acc[i][j][(2 * rp + 1) * 4 + q] + bn);
+                    }
+                    const int m8a = mw + i * 32 + 8 * (2 * rp), m8b = m8a + 8;       // both 8-row groups of the pair
+                    const int ga = m8a / p.t_rows, ta = m8a - ga * p.t_rows;
+                    const int gb = m8b / p.t_rows, tb = m8b - gb * p.t_rows;
+                    const bool fast = al16 && (m8b + 7 < p.M) && (ta + 7 < p.t_rows) && (tb + 7 < p.t_rows) &&
+                                      ((ta & 7) == 0) && ((tb & 7) == 0);
+                    if (fast) {
+                        union { half4v h; int2 w; } snd, rcv;
+                        snd.h = grp ? he : ho;
+                        rcv.w.x = __shfl_xor(snd.w.x, 32, 64);
+                        rcv.w.y = __shfl_xor(snd.w.y, 32, 64);
+                        half8v o8;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int m = mb + q;
-                            if (m < p.M) {
-                                const int g2 = m / p.t_rows, t2 = m - g2 * p.t_rows;
-                                out16t[(int64_t)g2 * p.t_gstride + (int64_t)(n - p.n_split) * p.ldt + t2] = (half_t)v[q];
+                            o8[q] = grp ? rcv.h[q] : he[q];
+                            o8[4 + q] = grp ? ho[q] : rcv.h[q];
+                        }
+                        half_t* dst = out16t + (int64_t)(grp ? gb : ga) * p.t_gstride + (int64_t)(n - p.n_split) * p.ldt +
+                                      (grp ? tb : ta);
+                        *reinterpret_cast<half8v*>(dst) = o8;
+                    } else {
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            const half4v h = rr ? ho : he;
+                            const int mb = mw + i * 32 + 8 * (2 * rp + rr) + 4 * grp;
+                            const int g = mb / p.t_rows, tr = mb - g * p.t_rows;
+                            half_t* dst = out16t + (int64_t)g * p.t_gstride + (int64_t)(n - p.n_split) * p.ldt + tr;
+                            const bool vec = (mb + 3 < p.M) && (tr + 3 < p.t_rows) && ((p.ldt & 3) == 0) &&
+                                             ((p.t_gstride & 3) == 0) && ((tr & 3) == 0);
+                            if (vec) {
+                                *reinterpret_cast<half4v*>(dst) = h;
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int m = mb + q;
+                                    if (m < p.M) {
+                                        const int g2 = m / p.t_rows, t2 = m - g2 * p.t_rows;
+                                        out16t[(int64_t)g2 * p.t_gstride + (int64_t)(n - p.n_split) * p.ldt + t2] = h[q];
+                                    }
+                                }
                             }
                         }
                     }

@@ -225,3 +225,28 @@ def test_pipeline_latents_to_frames_on_the_gpu():
     b = pipeline.sample_frames(w, fs, c, uc, noise, num_steps=3, hoist=False)
     torch.cuda.synchronize()
     assert a.shape == (noise.shape[0], 3, 16, 192) and torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_full_width_first_stage_host_logic_on_the_emulated_backend():
+    """The nuScenes first-stage architecture (4 levels, 2 res blocks, 128..512 channels, mid attention) on a small image:
+    decoder and encoder mirror modules vs the oracle through the emulated C-ABI (the GPU versions of this test run the
+    same modules through the HIP library)."""
+    torch.manual_seed(0)
+    fd = model.FirstStageDecoder(4, FULL)
+    sd = synth.synth_state_dict({k: list(v.shape) for k, v in fd.state_dict().items()})
+    fd.load_state_dict(sd, strict=True)
+    z = torch.randn(1, 4, 8, 24) * 2.0
+    ref = vo.decode(sd, vo.VaeConfig(), z)
+    with E.use_backend(emu):
+        img = fd.decode(z)
+    d = (img - ref).abs()
+    assert img.shape == (1, 3, 64, 192) and d.max().item() < 2e-2 and d.mean().item() < 2e-3, (d.max().item(), d.mean().item())
+    fe = model.FirstStageEncoder(4, FULL)
+    esd = synth.synth_state_dict({k: list(v.shape) for k, v in fe.state_dict().items()})
+    fe.load_state_dict(esd, strict=True)
+    x = torch.tanh(torch.randn(1, 3, 64, 192))
+    eref = vo.encode_moments(esd, vo.VaeConfig(), x)
+    with E.use_backend(emu):
+        mom = fe.moments(x)
+    d = (mom - eref).abs()
+    assert mom.shape == (1, 8, 8, 24) and d.max().item() < 2e-2 and d.mean().item() < 2e-3, (d.max().item(), d.mean().item())

@@ -288,13 +288,13 @@ def main():
     if args.config == "full":
         ach = ALGO_TFLOP_PER_STEP * (value / world)
         traffic = None
-        pmc = ROOT / "profiles" / "round1" / "pmc_r1j.json"
+        pmc = ROOT / "profiles" / "round1" / "pmc_r1n.json"
         if pmc.exists():       # HBM-side bytes per step from separate rocprofv3 --pmc passes of this same command
             traffic = json.loads(pmc.read_text())["per_step"]["traffic_GB_calibrated"] * 1e9
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic,
                            "traffic_note": "bytes per step at the L2<->fabric boundary (FETCH_SIZE + WRITE_SIZE, separate "
-                                           "--pmc passes, calibrated on a kernel of known byte count): profiles/round1/pmc_r1j.json",
+                                           "--pmc passes, calibrated on a kernel of known byte count): profiles/round1/pmc_r1n.json",
                            "basis": "96.59 algorithmic TFLOP per step (SURVEY.md §8d) / measured step time, per GPU"}
     if parity:
         out["parity"] = parity

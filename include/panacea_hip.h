@@ -29,9 +29,26 @@ extern "C" {
 #define PNC_OK 0
 #define PNC_EINVAL (-1)   /* unsupported shape / argument */
 #define PNC_EALIGN (-2)   /* pointer or leading dimension not 16-byte aligned */
+#define PNC_EABI (-3)     /* parameter struct compiled against another version of this header */
 
 /* library / build identification: returns "panacea_hip <version> gfx950" */
 const char* pnc_version(void);
+/* ABI revision of this header (bumped whenever a parameter struct or a prototype changes): 2 */
+#define PNC_ABI_VERSION 2
+int pnc_abi_version(void);
+
+/* Tuning / test switches (process-global, read with one relaxed atomic load per launch; results never depend on them
+ * beyond what each option states).  Returns the previous value, or PNC_EINVAL for an unknown option. */
+enum {
+    PNC_OPT_GEMM_TAIL_SPLIT = 0,  /* 1 (default): run a sparse last round of output tiles as half / quarter-row workgroups
+                                     (bit-identical to 0: rows of a GEMM are independent) */
+    PNC_OPT_GEMM_TILE = 1,        /* 0 (default): score-based tile choice; 1 = 128x128, 2 = 256x128, 3 = 256x320,
+                                     4 = 256x256 force a geometry where the shape allows it (kernel micro-benchmarks) */
+    PNC_OPT_ATTN_VARIANT = 2,     /* 0 (default): by view size; 41 / 81 / 42 / 82 = (waves, query blocks per wave) */
+    PNC_OPT_ATTN_DMA = 3,         /* 1 (default): LDS-DMA staging of K / V^T tiles where alignment allows; 0 = register staging */
+    PNC_OPT_COUNT = 4
+};
+int pnc_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------- *
  * 1. MFMA GEMM family:  C[M,N] = gatherA[M,K] (fp16) x W[N,K]^T (fp16), fp32 acc
@@ -95,7 +112,19 @@ typedef struct PncGemmParams {
      * only, i.e. F.pad(x, (0,1,0,1)) + Conv2d(padding=0) — the stride-2 Downsample of the first-stage encoder
      * (sgm/modules/diffusionmodules/model.py:108-112) */
     int32_t conv_pad_br;
-    int32_t reserved0;
+    /* sizeof(PncGemmParams) as the CALLER compiled it.  pnc_gemm_f16 / pnc_gemm_workspace_floats return PNC_EABI when
+     * it differs from the library's, instead of reading past a shorter struct (ABI version 2: 240 bytes). */
+    int32_t struct_bytes;
+    /* Precise ("split") activation operands.  An fp16 operand v is carried as two fp16 planes,
+     *     hi = fp16(v),   lo = fp16((v - hi) * 2^11)        (a 22-bit operand; the 2^11 keeps lo out of the subnormals)
+     * A_lo   : lo plane of A (same layout / lda / gather as A), or NULL for a plain fp16 operand.  The kernel runs the
+     *          K loop over the lo plane first, scales the accumulators by 2^-11, then runs the hi plane: twice the MFMA
+     *          work of the call-site, W is read from L2 twice.
+     * out16_lo : lo plane written next to out16 (same ldc16), or NULL.
+     * Used by the call-sites whose operand rounding dominates the eps error: the reference
+     * computes these contractions in fp32 on CPU / fp16 autocast on GPU (wrappers.py:37-70). */
+    const void* A_lo;
+    void* out16_lo;
 } PncGemmParams;
 
 int pnc_gemm_f16(const PncGemmParams* p, void* stream);
@@ -142,7 +171,8 @@ int pnc_attn_temporal_f16(const void* q, int ldq, const void* k, int ldk,
                           int B, int T, int Npix, int heads, float scale, void* stream);
 
 /* ------------------------------------------------------------------------- *
- * 3. Normalisations (fp32 stream in, fp16 operand out)
+ * 3. Normalisations (fp32 stream in, fp16 operand out).  y16_lo (may be NULL) receives the lo plane of a precise
+ *    operand, same layout as y16 (see PncGemmParams.A_lo).
  * ------------------------------------------------------------------------- */
 /* Spatial GroupNorm(32,C) over one frame's (H*W, C/32) slab, two launches.
  *   stats: partial[(f*nchunk + chunk)*32 + g] = {count, mean, M2}
@@ -153,16 +183,16 @@ int pnc_groupnorm_stats(const float* x, int ldx, int F, int Npix, int C,
 int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int C,
                         int pix_per_chunk, const float* partial,
                         const float* gamma, const float* beta, float eps, int silu,
-                        void* y16, int ldy, void* stream);
+                        void* y16, int ldy, void* y16_lo, void* stream);
 /* Temporal GroupNorm(32,C)+SiLU: statistics over the (C/32, T) slab of ONE pixel
  *    -> nn.GroupNorm applied on "(b h w) c t" (openaimodel.py:409-419,509-515) */
 int pnc_groupnorm_temporal_silu(const float* x, int B, int T, int Npix, int C,
                                 const float* gamma, const float* beta, float eps,
-                                void* y16, void* stream);
+                                void* y16, void* y16_lo, void* stream);
 /* LayerNorm over C (eps 1e-5) -> nn.LayerNorm (attention.py:699-701) */
 int pnc_layernorm(const float* x, int ldx, int M, int C,
                   const float* gamma, const float* beta, float eps,
-                  void* y16, int ldy, void* stream);
+                  void* y16, int ldy, void* y16_lo, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * 4. Small helpers
@@ -177,23 +207,24 @@ int pnc_linear_smallm(const float* a, int lda, const void* W, const float* bias,
 int pnc_timestep_embedding(const int64_t* t, int F, int dim, const float* freqs,
                            float* out, void* stream);
 /* NCHW (fp32) -> channels-last fp16 with optional second source (channel concat)
- * and zero padding to Cpad: out[f][p][c] = c<C1 ? a[f][c][p]*sa : c<C1+C2 ? b[f][c-C1][p] : 0
+ * and zero padding to Cpad: out[f][p][c] = c<C1 ? a[f][c][p]*a_scale[f] : c<C1+C2 ? b[f][c-C1][p] : 0
+ * (a_scale NULL = 1: the per-frame c_in of DiscreteDenoiser, denoiser.py:27-28, folded into the conversion)
  *    -> torch.cat in wrappers.py:41 + layout change */
-int pnc_nchw_to_tokens_f16(const float* a, int C1, const float* b, int C2,
-                           int F, int Npix, int Cpad, void* out16, void* stream);
+int pnc_nchw_to_tokens_f16(const float* a, int C1, const float* a_scale, const float* b, int C2,
+                           int F, int Npix, int Cpad, void* out16, void* out16_lo, void* stream);
 /* channels-last fp32 [F*Npix][ld] -> NCHW fp32 (first C columns) */
 int pnc_tokens_to_nchw_f32(const float* x, int ld, int F, int Npix, int C,
                            float* out, void* stream);
 /* out32[m][0:C1] = a[m][:], out32[m][C1:C1+C2] = s[m][:] + c[m][:]; optional fp16 copy
  *    -> th.cat([h, hs.pop() + control.pop()], dim=1)  (controlmodel.py:193-195) */
 int pnc_concat_add(const float* a, int C1, const float* s, const float* c, int C2,
-                   int64_t M, float* out32, void* out16, void* stream);
+                   int64_t M, float* out32, void* out16, void* out16_lo, void* stream);
 /* y = x + a (fp32, may be in place); optional fp16 copy of y
  *    -> h += guided_hint / h += control.pop()  (controlmodel.py:127,192) */
-int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16,
+int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16, void* y16_lo,
                 void* stream);
 /* fp32 -> fp16 */
-int pnc_cast_f16(const float* x, int64_t n, void* y16, void* stream);
+int pnc_cast_f16(const float* x, int64_t n, void* y16, void* y16_lo, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * 5. First-stage decoder: row softmax of a materialised score

@@ -19,8 +19,8 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libpanacea_hip.so"
-SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "misc.hip"]
-HEADERS = [CSRC / "common.h", ROOT / "include" / "panacea_hip.h"]
+SOURCES = ["gemm.hip", "gemm_plain.hip", "gemm_conv3x3.hip", "gemm_conv1d.hip", "attn.hip", "norm.hip", "misc.hip"]
+HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", ROOT / "include" / "panacea_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", str(ROOT / "include"), "-I", str(CSRC)]
 

@@ -434,12 +434,11 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     // variants: (waves, query blocks per wave) -> queries per workgroup.  Large views: 8 waves x 2 blocks (512 queries
     // share a K/V tile and every fragment read feeds two MFMAs: 600-670 TFLOP/s at level 0 vs 470-500 for 4 x 1);
     // mid-size: 8 x 1 (256); small views: 4 x 1 (128).  Measured in profiles/round1/kbench_attn_variants.log.
-    const char* fenv = getenv("PNC_ATTN_VARIANT");      // tests / kbench: force one variant
-    const int force = fenv ? atoi(fenv) : 0;
+    const int force = pnc_get_option(PNC_OPT_ATTN_VARIANT);      // tests / kbench: force one variant
     const int variant = force ? force : (Nq >= 512 ? 82 : (Nq >= 256 ? 81 : 41));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool dma = ((kvWv & 7) == 0) && ((p.kvW & 7) == 0) && ((p.ldvt & 7) == 0) && ((p.vt_gstride & 7) == 0) &&
-                     !getenv("PNC_ATTN_NODMA");
+                     pnc_get_option(PNC_OPT_ATTN_DMA) != 0;
     int wv_shift = -1;
     if (kvWv > 0 && (kvWv & (kvWv - 1)) == 0) { wv_shift = 0; while ((1 << wv_shift) < kvWv) ++wv_shift; }
 #define PNC_ATTN_LAUNCH(NW_, QB_, QTILE_)                                                                         \

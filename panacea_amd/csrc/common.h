@@ -35,6 +35,16 @@ __device__ __forceinline__ void glds16(const half_t* src, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Precise ("split") fp16 operands (include/panacea_hip.h, PncGemmParams.A_lo): v ~ hi + lo * 2^-11 with
+// hi = fp16(v), lo = fp16((v - hi) * 2^11).
+constexpr float PNC_LO_SCALE = 2048.0f;
+__device__ __forceinline__ half4v lo_plane4(const float (&v)[4], half4v hi) {
+    half4v l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) l[e] = (half_t)((v[e] - (float)hi[e]) * PNC_LO_SCALE);
+    return l;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -48,6 +58,8 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+
+int pnc_get_option(int option);          // misc.hip (process-global tuning / test switches, see pnc_set_option)
 
 static inline int pnc_launch_status() {
     hipError_t e = hipGetLastError();

@@ -1,0 +1,779 @@
+// gemm_kernel.h — MFMA (v_mfma_f32_32x32x16_f16) GEMM family for gfx950: kernel template + launcher.
+//
+//   C[M,N] = gatherA[M,K] x W[N,K]^T   fp16 operands, fp32 accumulate, fused epilogue.
+//
+// One kernel template covers every dense contraction of the Panacea denoising path (include/panacea_hip.h §1):
+//   PNC_A_PLAIN     Linear / 1x1 conv on channels-last tokens            (gemm_plain.hip)
+//   PNC_A_CONV3X3   implicit-GEMM 3x3 conv over an NHWC image            (gemm_conv3x3.hip)
+//   PNC_A_CONV1D_T  temporal k=3 conv over the frames of one pixel       (gemm_conv1d.hip)
+//
+// Tile: BM x BN block, BK = 64, WGM x WGN waves, each wave owns MI x NI blocks of 32x32.  Operands go HBM -> LDS
+// directly (global_load_lds_dwordx4), 16-B chunks in XOR-swizzled 128-B rows; the LDS image of the DMA is lane-linear,
+// so the swizzle is applied to the per-lane SOURCE address and again on the ds_read side.  Out-of-range chunks (conv
+// padding, K/M/N tails) are sourced from a 16-byte zero block.
+//
+// The EPILOGUE is a compile-time parameter (EPI bit set): which fp32 streams are added (res1, res2, row bias), which
+// outputs are written (fp32, fp16, channel-major fp16 "V^T"), GEGLU.  The fast variants assume the vector contract
+// checked by epi_fast_ok() on the host (N % 8 == 0, 16-byte aligned pointers and leading dimensions), so they contain
+// no per-element predicates: every global access is a 16-byte vector on 8 consecutive columns of one row, staged
+// through a wave-private LDS region.  Anything else runs E_GENERIC (scalar, predicated, slow, any shape).
+// Round 1 carried every option as a run-time branch inside fully unrolled loops: 190 KB of code and 78 spilled VGPRs in
+// the 256x320 kernel; the specialised variants are 10-25 KB with no scratch
+// (profiles/round2/gemm_codeobj_r2.txt).
+//
+// "Precise" operands (A_lo != NULL): A = A_hi + 2^-11 * A_lo with both planes fp16.  The K loop first runs over the lo
+// plane, scales the accumulators by 2^-11 (exact), then runs over the hi plane: a 22-bit activation operand at twice
+// the MFMA work, same tile machinery.
+#pragma once
+#include "common.h"
+#include <atomic>
+#include <utility>
+
+namespace pnc_gemm {
+
+constexpr int BK = 64;          // fp16 elements per K tile = 128 B per LDS row
+
+enum : unsigned {
+    E_R1 = 1,        // += res1 (fp32 stream, may alias out32)
+    E_R2 = 2,        // += res2
+    E_RB = 4,        // += rowbias[(m / rb_rows) % rb_mod]
+    E_O32 = 8,       // fp32 output
+    E_O16 = 16,      // fp16 output (+ optional lo plane)
+    E_VT = 32,       // column blocks >= n_split go channel-major (V^T)
+    E_GEGLU = 64,    // value * gelu(gate) on interleaved 32-column blocks, fp16 output
+    E_GENERIC = 128  // run-time flags, scalar predicated accesses: ragged N, unaligned pointers / leading dimensions
+};
+
+constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;   // lo plane = (v - hi) * 2^11
+
+// compile-time loop: the index reaches the body as a constant, so accumulator arrays are always indexed statically
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+struct RowState {               // per staged A row, fixed over the K loop
+    int64_t base;               // element offset of the row origin
+    int y, x;                   // conv3x3: output pixel; conv1d: t in .y
+    bool valid;
+};
+
+template <int AMODE>
+__device__ __forceinline__ RowState make_row(const PncGemmParams& p, int m) {
+    RowState s;
+    s.valid = m < p.M;
+    const int mm = s.valid ? m : 0;
+    if (AMODE == PNC_A_PLAIN) {
+        s.base = (int64_t)mm * p.lda; s.y = 0; s.x = 0;
+    } else if (AMODE == PNC_A_CONV3X3) {
+        const int hw = p.Hout * p.Wout;
+        const int f = mm / hw, pix = mm - f * hw;
+        s.y = pix / p.Wout; s.x = pix - s.y * p.Wout;
+        s.base = (int64_t)f * p.Hin * p.Win * p.Cin;
+    } else {
+        const int f = mm / p.Npix;
+        s.y = f % p.T; s.x = 0;
+        s.base = (int64_t)mm * p.Cin;
+    }
+    return s;
+}
+
+static __device__ __attribute__((aligned(16))) half_t g_zero_chunk[8];   // zero-initialised: source of padded chunks
+
+// GEGLU gate: Phi(g) = (1 + erf(g / sqrt 2)) / 2 tabulated on [-8, 8) in steps of 1/128 as {Phi(x_i), Phi(x_{i+1}) - Phi(x_i)}
+// (16 KB, copied into LDS by the GEGLU GEMMs).  Linear interpolation error <= h^2/8 max|Phi''| = 1.8e-6 — 250x below
+// the fp16 rounding of the product it feeds — for 9 VALU + one ds_read_b64 per gate instead of ~14 VALU incl. exp + rcp.
+constexpr int PHI_N = 2048;
+constexpr float PHI_SCALE = 128.0f, PHI_X0 = -8.0f;
+constexpr int PHI_BYTES = PHI_N * 8;
+
+__device__ __forceinline__ float gelu_tab_f(float g, const float* tab) {
+    float t = fmaf(g, PHI_SCALE, -PHI_X0 * PHI_SCALE);
+    t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)PHI_N - 0.001f);
+    const int i = (int)t;
+    const float f = t - (float)i;
+    const float2 e = *reinterpret_cast<const float2*>(tab + 2 * i);
+    return g * fmaf(f, e.y, e.x);
+}
+
+// global source of the 16-byte chunk (row state s, k index kc) of plane A, or the zero block
+template <int AMODE>
+__device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, const half_t* __restrict__ A,
+                                                     const RowState& s, int kc) {
+    if (!s.valid || kc >= p.K) return g_zero_chunk;
+    if (AMODE == PNC_A_PLAIN) {
+        return A + s.base + kc;
+    } else if (AMODE == PNC_A_CONV3X3) {
+        // K order: (ky,kx,ci) for narrow inputs; (ci/64, ky, kx, ci%64) when Cin % 64 == 0, so that the nine tap
+        // reads of one 64-channel slice of a pixel neighbourhood are consecutive K tiles and hit L1/L2
+        int tap, ci;
+        if ((p.Cin & 63) == 0) {
+            const int cc = kc / 576, r = kc - cc * 576;
+            tap = r >> 6; ci = (cc << 6) + (r & 63);
+        } else {
+            tap = kc / p.Cin; ci = kc - tap * p.Cin;
+        }
+        const int ky = tap / 3, kx = tap - ky * 3;
+        int iy, ix; bool ok;
+        if (p.upsample) {
+            const int uy = s.y + ky - 1, ux = s.x + kx - 1;
+            ok = (uy >= 0) && (uy < p.Hout) && (ux >= 0) && (ux < p.Wout);
+            iy = uy >> 1; ix = ux >> 1;
+        } else {
+            const int pad = p.conv_pad_br ? 0 : 1;
+            iy = s.y * p.stride + ky - pad; ix = s.x * p.stride + kx - pad;
+            ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+        }
+        return ok ? A + s.base + ((int64_t)iy * p.Win + ix) * p.Cin + ci : g_zero_chunk;
+    } else {
+        const int tap = kc / p.Cin, ci = kc - tap * p.Cin;
+        const int tt = s.y + tap - 1;
+        return (tt < 0 || tt >= p.T) ? g_zero_chunk : A + s.base + (int64_t)(tap - 1) * p.Npix * p.Cin + ci;
+    }
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// fp16 store of 8 consecutive columns, plus the lo plane of a precise operand when the caller asked for one
+__device__ __forceinline__ void store_h8(half_t* out16, half_t* out16_lo, int64_t off, const float (&v)[8]) {
+    half8v o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+    *reinterpret_cast<half8v*>(out16 + off) = o;
+    if (out16_lo) {
+        half8v l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[e] = (half_t)((v[e] - (float)o[e]) * LO_SCALE);
+        *reinterpret_cast<half8v*>(out16_lo + off) = l;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast row-major epilogue of one wave tile (MI x NI blocks of 32x32), compile-time option set.
+//
+// Each 32-row x (32|64)-column slab goes through a wave-private LDS region so that a lane ends up with 8 CONSECUTIVE
+// columns of one row: 16-byte fp16 stores, two 16-byte fp32 loads/stores.  A 64-column slab uses 8 lanes per row
+// (4 passes of 8 rows), the odd 32-column slab of NI = 5 uses 4 lanes per row (2 passes of 16 rows): no idle lanes.
+// LDS operations of one wave execute in order, so only lgkmcnt waits separate the phases — no workgroup barrier.
+//
+// Added fp32 streams (X = res1 | rowbias, Y = res2 | rowbias next to res1) are prefetched ROLLING: as soon as pass ps of
+// slab s has consumed its values, the same registers receive the loads of pass ps of slab s+1 — issued before the
+// stores of pass ps, so they travel with those stores and under the LDS staging of slab s+1.  In place (res1 == out32)
+// a load may not move above an earlier store; rows/columns of different slabs are disjoint, so this order is safe.
+// The loads of slab 0 go out after its accumulators have been staged (32 registers free again): with two streams in
+// flight the live set stays below 256 VGPRs next to the 160 accumulator registers of the 256x320 tile.
+template <int MI, int NI, unsigned EPI>
+__device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[MI][NI], float* ep, int lane,
+                                         int mw, int nw, int ncols) {
+    constexpr bool R1 = (EPI & E_R1) != 0, R2 = (EPI & E_R2) != 0, RB = (EPI & E_RB) != 0;
+    constexpr bool O32 = (EPI & E_O32) != 0, O16 = (EPI & E_O16) != 0;
+    constexpr bool HAS_X = R1 || RB, HAS_Y = R1 && (R2 || RB);
+    static_assert(!(R2 && !R1), "a single residual is passed as res1");
+    static_assert(!(R1 && R2 && RB), "three added streams run the generic epilogue");
+    constexpr int ENI = NI < 2 ? NI : 2;
+    constexpr int EPITCH = ENI * 32 + 4;
+    constexpr int NJ = (NI + ENI - 1) / ENI, NS = NJ * MI;
+    constexpr int NPMAX = ENI == 2 ? 4 : 2;
+    half_t* out16 = reinterpret_cast<half_t*>(p.out16);
+    half_t* out16_lo = reinterpret_cast<half_t*>(p.out16_lo);
+    const bool silu = (!HAS_X) && (p.act == PNC_ACT_SILU);
+    const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 x0[NPMAX], x1[NPMAX], y0[NPMAX], y1[NPMAX];
+
+    // slab s -> (row block i, first column block jc, width cw in blocks, lanes per row, rows per pass, passes)
+    auto load_xy = [&](auto s_, auto ps_) {
+        constexpr int s = decltype(s_)::value, ps = decltype(ps_)::value;
+        constexpr int jc = (s / MI) * ENI, i = s % MI, cw = (NI - jc) < ENI ? (NI - jc) : ENI;
+        constexpr int CPL = cw * 4, RPP = 64 / CPL;
+        const int cl = lane % CPL, rl = lane / CPL;
+        const int ncol = nw + jc * 32 + cl * 8;
+        const int m = mw + i * 32 + ps * RPP + rl;
+        const bool on = (m < p.M) && (ncol < ncols);
+        if constexpr (HAS_X) {
+            x0[ps] = z4; x1[ps] = z4;
+            if (on) {
+                const float* xp = R1 ? p.res1 + (int64_t)m * p.ldr1 + ncol
+                                     : p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
+                x0[ps] = ld4(xp); x1[ps] = ld4(xp + 4);
+            }
+        }
+        if constexpr (HAS_Y) {
+            y0[ps] = z4; y1[ps] = z4;
+            if (on) {
+                const float* yp = R2 ? p.res2 + (int64_t)m * p.ldr2 + ncol
+                                     : p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
+                y0[ps] = ld4(yp); y1[ps] = ld4(yp + 4);
+            }
+        }
+    };
+
+    static_for<NS>([&](auto s_) {
+        constexpr int s = decltype(s_)::value, jc = (s / MI) * ENI, i = s % MI;
+        constexpr int cw = (NI - jc) < ENI ? (NI - jc) : ENI;
+        constexpr int CPL = cw * 4, RPP = 64 / CPL, NP = 32 / RPP;
+        const int cl = lane % CPL, rl = lane / CPL;
+        const int ncol = nw + jc * 32 + cl * 8;
+        const bool col_on = ncol < ncols;
+        f32x4 b0 = z4, b1 = z4;
+        if (p.bias && col_on) { b0 = ld4(p.bias + ncol); b1 = ld4(p.bias + ncol + 4); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // previous slab fully read back from LDS
+        static_for<cw>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][jc + j][r];
+        });
+        if constexpr (s == 0 && (HAS_X || HAS_Y)) {
+            static_for<NP>([&](auto ps_) { load_xy(std::integral_constant<int, 0>{}, ps_); });
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<NP>([&](auto ps_) {
+            constexpr int ps = decltype(ps_)::value;
+            const float* src = ep + (ps * RPP + rl) * EPITCH + cl * 8;
+            const f32x4 a0 = ld4(src), a1 = ld4(src + 4);
+            const int m = mw + i * 32 + ps * RPP + rl;
+            const bool on = col_on && m < p.M;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a0[e] + b0[e]; v[e + 4] = a1[e] + b1[e]; }
+            if constexpr (RB && HAS_Y) {            // rowbias next to res1: bias + rowbias first (header order)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += y0[ps][e]; v[e + 4] += y1[ps][e]; }
+            }
+            if constexpr (HAS_X) {                  // res1, or rowbias when it is the only stream
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += x0[ps][e]; v[e + 4] += x1[ps][e]; }
+            } else {
+                if (silu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                }
+            }
+            if constexpr (R2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += y0[ps][e]; v[e + 4] += y1[ps][e]; }
+            }
+            // rolling prefetch: these registers are free now; the loads go out before this pass's stores
+            if constexpr ((HAS_X || HAS_Y) && s + 1 < NS) {
+                constexpr int jn = ((s + 1) / MI) * ENI, cwn = (NI - jn) < ENI ? (NI - jn) : ENI;
+                constexpr int NPn = 32 / (64 / (cwn * 4));
+                if constexpr (ps < NPn) load_xy(std::integral_constant<int, s + 1>{}, ps_);
+                // (a narrower next slab has fewer passes; a wider one cannot follow a narrower one: the odd block is last)
+            }
+            if (!on) return;
+            if constexpr (O32) {
+                float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
+                const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                *reinterpret_cast<f32x4*>(op) = o0;
+                *reinterpret_cast<f32x4*>(op + 4) = o1;
+            }
+            if constexpr (O16) store_h8(out16, out16_lo, (int64_t)m * p.ldc16 + ncol, v);
+        });
+    });
+}
+
+// GEGLU epilogue: the two column blocks of a staged chunk are a value block and its gate block (engine.pk_geglu);
+// 4 lanes per row own 8 of the 32 output columns each.
+template <int MI, int NI>
+__device__ __forceinline__ void epi_geglu(const PncGemmParams& p, f32x16 (&acc)[MI][NI], float* ep, int lane,
+                                          int mw, int nw, const float* phi_tab) {
+    static_assert(NI % 2 == 0, "GEGLU pairs value / gate column blocks inside a wave");
+    constexpr int EPITCH = 2 * 32 + 4;
+    constexpr int CPL = 4, RPP = 16, NP = 2;
+    const int cl = lane % CPL, rl = lane / CPL;
+    const int Nout = p.N >> 1;
+    half_t* out16 = reinterpret_cast<half_t*>(p.out16);
+    half_t* out16_lo = reinterpret_cast<half_t*>(p.out16_lo);
+    const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    static_for<NI / 2>([&](auto jc_) {
+        constexpr int jc = decltype(jc_)::value * 2;
+        const int nin = nw + jc * 32 + cl * 8;                          // first input column (N space of W / bias)
+        const int ncol = ((nw + jc * 32) >> 1) + cl * 8;                // first output column of this lane
+        const bool col_on = ncol < Nout;
+        f32x4 b0 = z4, b1 = z4, g0b = z4, g1b = z4;
+        if (p.bias && col_on) {
+            b0 = ld4(p.bias + nin); b1 = ld4(p.bias + nin + 4);
+            g0b = ld4(p.bias + nin + 32); g1b = ld4(p.bias + nin + 36);
+        }
+        static_for<MI>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // previous slab fully read
+            static_for<2>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][jc + j][r];
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f32x4 a0[NP], a1[NP], g0[NP], g1[NP];
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const float* src = ep + (ps * RPP + rl) * EPITCH + cl * 8;
+                a0[ps] = ld4(src); a1[ps] = ld4(src + 4);
+                g0[ps] = ld4(src + 32); g1[ps] = ld4(src + 36);
+            }
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const int m = mw + i * 32 + ps * RPP + rl;
+                if (!col_on || m >= p.M) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (a0[ps][e] + b0[e]) * gelu_tab_f(g0[ps][e] + g0b[e], phi_tab);
+                    v[e + 4] = (a1[ps][e] + b1[e]) * gelu_tab_f(g1[ps][e] + g1b[e], phi_tab);
+                }
+                store_h8(out16, out16_lo, (int64_t)m * p.ldc16 + ncol, v);
+            }
+        });
+    });
+}
+
+// channel-major ("V^T") output of one wave tile: a lane already holds 4 consecutive rows of one column; rows
+// 8*r4 + {0..3} live in lane l, {4..7} in lane l+32 (same column): one xor-32 exchange per pair of r4 gives each lane 8
+// consecutive rows -> 16-byte stores along the token axis.  Vector contract: M % 8 == 0, t_rows % 8 == 0.
+template <int MI, int NI>
+__device__ __forceinline__ void epi_vt(const PncGemmParams& p, f32x16 (&acc)[MI][NI], int lane, int mw, int nw) {
+    half_t* out16t = reinterpret_cast<half_t*>(p.out16t);
+    const int col = lane & 31, grp = lane >> 5;
+    static_for<MI * NI>([&](auto ij_) {
+        constexpr int i = decltype(ij_)::value / NI, j = decltype(ij_)::value % NI;
+        const int n = nw + j * 32 + col;
+        const bool col_on = n < p.N;
+        const float bn = (p.bias && col_on) ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            half4v he, ho;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                he[q] = (half_t)(acc[i][j][(2 * rp) * 4 + q] + bn);
+                ho[q] = (half_t)(acc[i][j][(2 * rp + 1) * 4 + q] + bn);
+            }
+            union { half4v h; int2 w; } snd, rcv;
+            snd.h = grp ? he : ho;
+            rcv.w.x = __shfl_xor(snd.w.x, 32, 64);
+            rcv.w.y = __shfl_xor(snd.w.y, 32, 64);
+            half8v o8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o8[q] = grp ? rcv.h[q] : he[q];
+                o8[4 + q] = grp ? ho[q] : rcv.h[q];
+            }
+            const int m8 = mw + i * 32 + 8 * (2 * rp + grp);            // this lane's 8-row group
+            if (col_on && m8 < p.M) {
+                const int g = m8 / p.t_rows, t0 = m8 - g * p.t_rows;
+                *reinterpret_cast<half8v*>(out16t + (int64_t)g * p.t_gstride + (int64_t)(n - p.n_split) * p.ldt + t0) = o8;
+            }
+        }
+    });
+}
+
+// Generic epilogue: every option is a run-time flag, every access scalar and predicated.  Correct for any N, leading
+// dimension and alignment; used by the few ragged launches of the path (the 4-channel output head) and by callers
+// outside the vector contract.  No prefetch arrays: it must not need scratch either.
+template <int MI, int NI>
+__device__ __forceinline__ void epi_generic(const PncGemmParams& p, f32x16 (&acc)[MI][NI], int lane, int mw, int nw) {
+    half_t* out16 = reinterpret_cast<half_t*>(p.out16);
+    half_t* out16_lo = reinterpret_cast<half_t*>(p.out16_lo);
+    half_t* out16t = reinterpret_cast<half_t*>(p.out16t);
+    const int col = lane & 31;
+    static_for<MI * NI>([&](auto ij_) {
+        constexpr int i = decltype(ij_)::value / NI, j = decltype(ij_)::value % NI;
+        const int n = nw + j * 32 + col;
+        if (n >= p.N) return;
+        const float bn = p.bias ? p.bias[n] : 0.0f;
+        const bool to_t = out16t && n >= p.n_split;
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int m = mw + i * 32 + mfma32_row(r, lane);
+            if (m >= p.M) continue;
+            float v = acc[i][j][r] + bn;
+            if (p.rowbias) v += p.rowbias[(int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + n];
+            if (p.act == PNC_ACT_SILU) v = silu_f(v);
+            if (p.res1) v += p.res1[(int64_t)m * p.ldr1 + n];
+            if (p.res2) v += p.res2[(int64_t)m * p.ldr2 + n];
+            if (to_t) {
+                const int g = m / p.t_rows, t = m - g * p.t_rows;
+                out16t[(int64_t)g * p.t_gstride + (int64_t)(n - p.n_split) * p.ldt + t] = (half_t)v;
+                continue;
+            }
+            if (p.out32) p.out32[(int64_t)m * p.ldc32 + n] = v;
+            if (out16) {
+                const half_t h = (half_t)v;
+                out16[(int64_t)m * p.ldc16 + n] = h;
+                if (out16_lo) out16_lo[(int64_t)m * p.ldc16 + n] = (half_t)((v - (float)h) * LO_SCALE);
+            }
+        }
+    });
+}
+
+template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE, unsigned EPI>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams pin, const int ksplit,
+                                                                   const int nfull, const int tail_f,
+                                                                   const float* __restrict__ phi_g) {
+    PncGemmParams p = pin;
+    constexpr int NW = WGM * WGN;                          // waves per workgroup
+    constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
+    constexpr int RPI = NW * 8;                            // rows staged per DMA iteration (8 rows per wave)
+    constexpr int A_IT = BM / RPI, B_IT = BN / RPI;
+    constexpr int LOADS = A_IT + B_IT;                     // DMA instructions per thread per K tile
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must be a multiple of the DMA row group");
+    constexpr int ENI = NI < 2 ? NI : 2;                   // column blocks staged per epilogue pass
+    constexpr int EPITCH = ENI * 32 + 4;                   // floats per staged epilogue row
+    constexpr bool GEGLU = (EPI & E_GEGLU) != 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const half_t* __restrict__ A = reinterpret_cast<const half_t*>(p.A);
+    const half_t* __restrict__ A_lo = reinterpret_cast<const half_t*>(p.A_lo);
+    const half_t* __restrict__ Wt = reinterpret_cast<const half_t*>(p.W);
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    // split K (ksplit > 1): block b = (slice, tile); slice s runs K tiles [s*nt/S, (s+1)*nt/S) and writes its raw fp32
+    // accumulators to ws[s][M][N] (the host launches the E_O32 variant with the epilogue options cleared);
+    // splitk_reduce_kernel sums the slices in order and applies the epilogue.
+    // Tail split (tail_f = 2 or 4): the last (ntile_mn - nfull) output tiles - the partial round that would leave most
+    // CUs idle - are each run by tail_f workgroups that own BM / tail_f rows of the tile: the waves of the other row
+    // groups skip their MFMAs and epilogue (their A rows are DMA'd as zero chunks), all waves still stage W.  Rows are
+    // independent in a GEMM, so the result does not depend on the split.
+    const int ntile_mn = tiles_m * tiles_n;
+    int kslice = 0, tile, part = 0;
+    if (ksplit > 1) {
+        const int blk = xcd_remap(blockIdx.x, ntile_mn * ksplit);
+        kslice = blk / ntile_mn; tile = blk - kslice * ntile_mn;
+    } else if ((int)blockIdx.x < nfull) {
+        tile = xcd_remap(blockIdx.x, nfull);
+    } else {
+        const int j = (int)blockIdx.x - nfull;
+        tile = nfull + j / tail_f; part = j - (j / tail_f) * tail_f;
+    }
+    const bool split_rows = (ksplit == 1) && ((int)blockIdx.x >= nfull) && (tail_f > 1);
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int ntiles_all = (p.K + BK - 1) / BK;
+    const int kt_begin = (int)((int64_t)kslice * ntiles_all / ksplit);
+    const int ntiles = (int)((int64_t)(kslice + 1) * ntiles_all / ksplit) - kt_begin;
+    if (ksplit > 1) p.out32 = p.ws + (int64_t)kslice * p.M * p.N;
+    // precise operand: the lo plane's K tiles run first, then the accumulators are scaled by 2^-11
+    const int nt_lo = A_lo ? ntiles : 0;
+    const int ntot = ntiles + nt_lo;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // DMA assignment: lane l of wave w fills slot (l&7) of row i*32 + w*8 + (l>>3); the slot holds the
+    // chunk slot ^ ((row>>1)&7), and (row>>1)&7 does not depend on i
+    const int srow = wave * 8 + (lane >> 3);
+    const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
+    const int rows_lo = split_rows ? part * (BM / tail_f) : 0;                 // tile-local row range of this workgroup
+    const int rows_hi = split_rows ? rows_lo + BM / tail_f : BM;
+    const bool wave_on = (wm * (MI * 32) >= rows_lo) && (wm * (MI * 32) < rows_hi);
+    RowState rows[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int r = i * RPI + srow;
+        rows[i] = make_row<AMODE>(p, m0 + r);
+        rows[i].valid = rows[i].valid && (r >= rows_lo) && (r < rows_hi);
+    }
+    const half_t* wrow[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int n = n0 + i * RPI + srow;
+        wrow[i] = (n < p.N) ? Wt + (int64_t)n * p.K : nullptr;
+    }
+    auto issue_tile = [&](int kt_local, int stage) {
+        const bool lo = kt_local < nt_lo;
+        const int kt = kt_begin + (lo ? kt_local : kt_local - nt_lo);
+        const half_t* Ap = lo ? A_lo : A;
+        const int kc = kt * BK + schunk * 8;
+        char* sa = smem + stage * STAGE + wave * 1024;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) glds16(a_chunk_ptr<AMODE>(p, Ap, rows[i], kc), sa + i * (RPI * 128));
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            glds16((wrow[i] && kc < p.K) ? wrow[i] + kc : g_zero_chunk, sb + i * (RPI * 128));
+    };
+
+    // GEGLU: the Phi table rides into LDS (behind the operand ring) with the first K tile
+    constexpr int RING_BYTES = STAGES * STAGE;
+    if constexpr (GEGLU) {
+        const char* tab = reinterpret_cast<const char*>(phi_g);
+#pragma unroll
+        for (int c = wave; c < PHI_BYTES / 1024; c += NW)
+            glds16(reinterpret_cast<const half_t*>(tab + c * 1024 + lane * 16), smem + RING_BYTES + c * 1024);
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int frow = lane & 31, fk = lane >> 5;
+    auto compute = [&](int stage, int mid_issue = -1) {
+        const char* sa = smem + stage * STAGE;
+        const char* sb = sa + A_BYTES;
+        if (PIPE) {
+            // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (register double buffer)
+            half8v af[2][MI], bf[2][NI];
+            auto frags = [&](int ks, int b) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[b][i] = *reinterpret_cast<const half8v*>(
+                        sa + lds_off128(wm * (MI * 32) + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    bf[b][j] = *reinterpret_cast<const half8v*>(
+                        sb + lds_off128(wn * (NI * 32) + j * 32 + frow, ks * 2 + fk));
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                if (ks + 1 < BK / 16) frags(ks + 1, (ks + 1) & 1);
+                // keep the reads of k-step ks+1 AHEAD of the MFMAs of k-step ks (hipcc otherwise sinks them behind the
+                // MFMAs and then waits lgkmcnt(0) right after issuing them, exposing the LDS latency every k-step)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 1 && mid_issue >= 0) { issue_tile(mid_issue, mid_issue & 1); __builtin_amdgcn_sched_barrier(0); }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                half8v af[MI], bf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[i] = *reinterpret_cast<const half8v*>(
+                        sa + lds_off128(wm * (MI * 32) + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    bf[j] = *reinterpret_cast<const half8v*>(
+                        sb + lds_off128(wn * (NI * 32) + j * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                if (ks == 1 && mid_issue >= 0) issue_tile(mid_issue, mid_issue & 1);
+            }
+        }
+    };
+    auto scale_lo = [&]() {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= LO_INV;
+    };
+
+    if (STAGES == 2) {
+        // one tile in flight: the plain barrier carries the vmcnt(0) that lands the DMA
+        issue_tile(0, 0);
+        __syncthreads();
+        // The second-dispatched half of the waves (4-7: one per SIMD, the arbitration losers) issues its share of the
+        // next tile's DMA in the MIDDLE of its MFMA stream instead of together with waves 0-3 right after the barrier
+        // (s_memtime timeline: 1870 vs 690 cycles per tile in the issue segment, with waves 0-3 then idling ~1400
+        // cycles at the barrier): each SIMD then has one wave issuing DMA while the other runs MFMAs.
+        const bool late = NW == 8 && wave >= 4 && wave_on && ntot >= 8;   // 2-5 % at long K
+        for (int kt = 0; kt < ntot; ++kt) {
+            const bool nxt = kt + 1 < ntot;
+            if (nxt && !late) issue_tile(kt + 1, (kt + 1) & 1);
+            if (wave_on) {
+                compute(kt & 1, (nxt && late) ? kt + 1 : -1);
+                if (kt + 1 == nt_lo) scale_lo();
+            }
+            __syncthreads();
+        }
+    } else {
+        // ring of three stages, TWO tiles in flight.  Counted waits: after issuing tile kt+2 only its LOADS
+        // DMA instructions may stay outstanding, i.e. tile kt+1 has landed; the raw s_barrier (no compiler
+        // vmcnt(0)) then publishes every wave's part of it and retires all reads of the stage being recycled.
+        issue_tile(0, 0);
+        if (ntot > 1) {
+            issue_tile(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        int st = 0;
+        for (int kt = 0; kt < ntot; ++kt) {
+            const bool ahead = (kt + 2) < ntot;
+            if (ahead) issue_tile(kt + 2, st == 0 ? 2 : st - 1);      // (kt + 2) % 3
+            if (wave_on) {
+                compute(st);
+                if (kt + 1 == nt_lo) scale_lo();
+            }
+            if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            st = (st == 2) ? 0 : st + 1;
+        }
+    }
+
+    // ------------------------------ epilogue ------------------------------
+    if (!wave_on) return;                       // row group of another workgroup (tail split)
+    const int mw = m0 + wm * (MI * 32), nw = n0 + wn * (NI * 32);
+    if constexpr ((EPI & E_GENERIC) != 0) {
+        epi_generic<MI, NI>(p, acc, lane, mw, nw);
+    } else {
+        if constexpr ((EPI & E_VT) != 0) {
+            if (n0 >= p.n_split) { epi_vt<MI, NI>(p, acc, lane, mw, nw); return; }
+        }
+        float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EPITCH);
+        __syncthreads();                        // every wave is done reading operand tiles from LDS
+        if constexpr (GEGLU) {
+            epi_geglu<MI, NI>(p, acc, ep, lane, mw, nw, reinterpret_cast<const float*>(smem + RING_BYTES));
+        } else {
+            epi_fast<MI, NI, (EPI & ~E_VT)>(p, acc, ep, lane, mw, nw, (EPI & E_VT) ? p.n_split : p.N);
+        }
+    }
+}
+
+// Workgroups of one geometry that are resident at once on the 256 CUs (LDS-limited: 160 KB per CU)
+template <int LDS_BYTES>
+constexpr int resident_slots() { return 256 * ((160 * 1024) / LDS_BYTES < 1 ? 1 : (160 * 1024) / LDS_BYTES > 2 ? 2 : (160 * 1024) / LDS_BYTES); }
+
+// Tail split decision: tiles = q * slots + r.  When the last, partial round holds r <= slots/2 (or /4) tiles, run each of
+// them as 2 (4) workgroups of BM/2 (BM/4) rows so that the round fills the chip: e.g. M = 49152, N = 640 with 256x320
+// tiles is 384 tiles = 1.5 rounds -> 256 full tiles + 128 tiles x 2 halves.
+template <int BM, int WGM, int LDS_BYTES>
+static inline void tail_split(int tiles, int& nfull, int& tail_f) {
+    constexpr int slots = resident_slots<LDS_BYTES>();
+    const int r = tiles % slots;
+    nfull = tiles; tail_f = 1;
+    if (r == 0 || !pnc_get_option(PNC_OPT_GEMM_TAIL_SPLIT)) return;
+    if (WGM >= 4 && r * 4 <= slots) tail_f = 4;
+    else if (WGM >= 2 && r * 2 <= slots) tail_f = 2;
+    if (tail_f > 1) nfull = tiles - r;
+}
+
+// gemm.hip
+int launch_splitk_reduce(const PncGemmParams& p, int ksplit, hipStream_t st);
+const float* phi_table_device(hipStream_t st, int* rc);
+
+template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE, unsigned EPI>
+int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
+    constexpr int lds = STAGES * (BM + BN) * 128;
+    constexpr int threads = 64 * WGM * WGN;
+    constexpr bool GEGLU = (EPI & E_GEGLU) != 0;
+    static_assert(lds + (GEGLU ? PHI_BYTES : 0) <= 160 * 1024, "LDS budget of one CU (operand ring + GEGLU table)");
+    static_assert(lds >= WGM * WGN * 32 * 68 * 4, "epilogue staging must fit the operand ring");
+    static std::atomic<unsigned char> attr_done[64];      // per instantiation and device; the call is idempotent
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto kern = gemm_glds_kernel<AMODE, BM, BN, WGM, WGN, STAGES, PIPE, EPI>;
+    if (!attr_done[dev & 63].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds + (GEGLU ? PHI_BYTES : 0));
+        attr_done[dev & 63].store(1, std::memory_order_release);
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    int nfull = tiles, tail_f = 1;
+    if (ksplit == 1) tail_split<BM, WGM, lds>(tiles, nfull, tail_f);
+    const int blocks = ksplit > 1 ? tiles * ksplit : nfull + (tiles - nfull) * tail_f;
+    PncGemmParams q = p;
+    const float* phi = nullptr;
+    if constexpr (GEGLU) {
+        int rc = PNC_OK;
+        phi = phi_table_device(st, &rc);
+        if (rc != PNC_OK) return rc;
+    }
+    if (ksplit > 1) {            // raw partial sums; the reduce launch owns bias / residuals / outputs
+        q.ldc32 = p.N;
+        q.bias = nullptr; q.rowbias = nullptr; q.res1 = nullptr; q.res2 = nullptr;
+        q.out16 = nullptr; q.out16_lo = nullptr; q.out16t = nullptr; q.n_split = p.N; q.act = PNC_ACT_NONE;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds + (GEGLU ? PHI_BYTES : 0), st, q, ksplit, nfull, tail_f, phi);
+    if (ksplit > 1) return launch_splitk_reduce(p, ksplit, st);
+    return pnc_launch_status();
+}
+
+// expected relative throughput of a geometry on `slots` concurrently resident workgroups
+static inline double tile_score(long tiles, int slots, double eff) {
+    if (tiles <= 0) return 0.0;
+    // a partial last round costs a full round, unless tail_split() can run it as half / quarter tiles (the row-split
+    // workgroups still stage the whole W tile: ~0.65 / 0.45 of a full tile's time)
+    const long q = tiles / slots, r = tiles % slots;
+    const double tail = r == 0 ? 0.0 : (r * 4 <= slots ? 0.45 : (r * 2 <= slots ? 0.65 : 1.0));
+    return eff * ((double)tiles / slots) / ((double)q + tail);
+}
+
+// Split K when one K loop per output tile would leave most CUs idle (the M = 3072 level: 60 tiles of 256x256).
+// Returns the number of K slices (1 = do not split) for the 256x256 tile.  The slice count is a function of K ALONE
+// and only the on/off decision looks at M, so that a batch and its halves (CFG sharding, tests) run the same K
+// partition and stay bit-identical as long as both are in the split regime.
+static inline int splitk_slices(const PncGemmParams& p) {
+    if (p.geglu || p.out16t || (p.N % 256) || (p.N % 8)) return 1;
+    if ((p.out32 && (p.ldc32 % 4)) || (p.out16 && (p.ldc16 % 8))) return 1;
+    const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
+    const int ktiles = (p.K + BK - 1) / BK;
+    if (tiles > 96 || ktiles < 48) return 1;
+    return ktiles >= 320 ? 8 : (ktiles >= 160 ? 4 : 2);
+}
+
+// Tile geometries.  Every channel width of the network is a multiple of 320, so the preferred tile is 256x320 (8 waves
+// as 4x2, wave tile 64x160, 2 stages = 144 KB): no column waste at N = 320, A is read once per 320 output columns, 9 DMA
+// instructions per 40 MFMAs.  256x256 serves GEGLU (value / gate blocks pair inside a wave) and N % 256 == 0; 256x128
+// (3-stage ring) and 128x128 the small grids; 128x32 the narrow-N convs (hint stem, output head).
+enum { T_128x128 = 1, T_256x128 = 2, T_256x320 = 3, T_256x256 = 4, T_128x32 = 5 };
+
+struct TileChoice { int tile; int ksplit; };
+
+static inline TileChoice choose_tile(const PncGemmParams& p) {
+    if (p.N <= 32 && !p.geglu) return {T_128x32, 1};
+    const int ks = splitk_slices(p);
+    if (ks > 1 && p.ws && p.ws_floats >= (int64_t)ks * p.M * p.N && !pnc_get_option(PNC_OPT_GEMM_TILE))
+        return {T_256x256, ks};
+    const long mt256 = (p.M + 255) / 256, mt128 = (p.M + 127) / 128;
+    const bool w320_ok = !p.geglu && (p.N % 320 == 0) && (!p.out16t || p.n_split % 320 == 0);
+    const bool w256_ok = (p.N % 256 == 0) && (!p.out16t || p.n_split % 256 == 0);
+    // a precise operand doubles the K loop: the long-K efficiencies apply from half the K
+    const int keff = p.A_lo ? 2 * p.K : p.K;
+    // measured main-loop efficiencies (relative): wide wave tiles win whenever they still fill ~3/4 of the CUs
+    const double s320 = w320_ok ? tile_score(mt256 * (p.N / 320), 256, keff >= 2048 ? 1.08 : (keff >= 1024 ? 1.0 : 0.92)) : 0.0;
+    const double s256 = w256_ok ? tile_score(mt256 * (p.N / 256), 256, 0.97) : 0.0;
+    const double s2x1 = tile_score(mt256 * ((p.N + 127) / 128), 256, 0.80);
+    const double s1x1 = tile_score(mt128 * ((p.N + 127) / 128), 512, 0.70);
+    int pick = T_128x128;
+    double best = s1x1;
+    if (s2x1 > best) { best = s2x1; pick = T_256x128; }
+    if (s256 > best) { best = s256; pick = T_256x256; }
+    if (s320 > best) { best = s320; pick = T_256x320; }
+    const int force = pnc_get_option(PNC_OPT_GEMM_TILE);
+    if (force == T_128x128 || force == T_256x128) pick = force;
+    if ((force == T_256x320 && w320_ok) || (force == T_256x256 && w256_ok)) pick = force;
+    return {pick, 1};
+}
+
+// launch the variant EPI of AMODE on the chosen tile
+template <int AMODE, unsigned EPI>
+int launch_tile(const PncGemmParams& p, hipStream_t st, TileChoice tc) {
+    constexpr bool GEGLU = (EPI & E_GEGLU) != 0;
+    switch (tc.tile) {
+        case T_128x32:
+            if constexpr (!GEGLU && !(EPI & E_VT)) return launch<AMODE, 128, 32, 4, 1, 2, true, EPI>(p, st);
+            return PNC_EINVAL;
+        case T_256x320:
+            if constexpr (!GEGLU) return launch<AMODE, 256, 320, 4, 2, 2, false, EPI>(p, st);
+            return PNC_EINVAL;
+        case T_256x256:
+            if (tc.ksplit > 1) return launch<AMODE, 256, 256, 4, 2, 2, true, E_O32>(p, st, tc.ksplit);   // raw partials
+            return launch<AMODE, 256, 256, 4, 2, 2, true, EPI>(p, st);
+        case T_256x128: return launch<AMODE, 256, 128, 4, 2, 3, true, EPI>(p, st);
+        default: return launch<AMODE, 128, 128, 2, 2, 2, true, EPI>(p, st);
+    }
+}
+
+}  // namespace pnc_gemm

@@ -1,0 +1,25 @@
+// gemm_plain.hip — PNC_A_PLAIN instantiations (nn.Linear / 1x1 conv call-sites, include/panacea_hip.h §1) of the GEMM
+// kernel template, one per (tile geometry, epilogue variant) the denoising path uses; everything else runs E_GENERIC.
+#include "gemm_kernel.h"
+
+namespace pnc_gemm {
+
+int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st) {
+    constexpr int AM = PNC_A_PLAIN;
+    const TileChoice tc = choose_tile(p);
+    if (tc.tile == T_128x32 && epi != E_O16 && epi != E_O32) epi = E_GENERIC;     // narrow-N: two fast variants
+    switch (epi) {
+        case E_O16: return launch_tile<AM, E_O16>(p, st, tc);                       // q (text), qkv (temporal), text K
+        case E_O16 | E_VT: return launch_tile<AM, E_O16 | E_VT>(p, st, tc);         // qkv of the view attention, text V^T
+        case E_O32: return launch_tile<AM, E_O32>(p, st, tc);                       // proj_in, skip 1x1, zero convs
+        case E_O32 | E_O16: return launch_tile<AM, E_O32 | E_O16>(p, st, tc);
+        case E_R1 | E_O32: return launch_tile<AM, E_R1 | E_O32>(p, st, tc);         // to_out, ff2, proj_out (+ residual, in place)
+        case E_R1 | E_O32 | E_O16: return launch_tile<AM, E_R1 | E_O32 | E_O16>(p, st, tc);
+        case E_R1 | E_O16: return launch_tile<AM, E_R1 | E_O16>(p, st, tc);         // ff2 of the last block: fp16 for proj_out
+        case E_RB | E_O32: return launch_tile<AM, E_RB | E_O32>(p, st, tc);         // proj_in_temporal + position table
+        case E_GEGLU | E_O16: return launch_tile<AM, E_GEGLU | E_O16>(p, st, tc);   // ff1
+        default: return launch_tile<AM, E_GENERIC>(p, st, tc);
+    }
+}
+
+}  // namespace pnc_gemm

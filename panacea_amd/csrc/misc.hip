@@ -1,6 +1,7 @@
 // misc.hip — small HBM-bound helpers of the denoising path: time-embedding MLP (small-M fp32
 // linear), sinusoidal embedding, NCHW <-> channels-last conversion, skip/control concat-add.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -65,23 +66,28 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int F, 
 
 // thread per (f, pixel): gather channels (stride Npix), write Cpad fp16 contiguous
 __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __restrict__ a, int C1,
+                                                             const float* __restrict__ a_scale,
                                                              const float* __restrict__ b, int C2, int F,
-                                                             int Npix, int Cpad, half_t* __restrict__ out) {
+                                                             int Npix, int Cpad, half_t* __restrict__ out,
+                                                             half_t* __restrict__ out_lo) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)F * Npix) return;
     const int64_t f = i / Npix, pix = i - f * Npix;
+    const float sa = a_scale ? a_scale[f] : 1.0f;
     half_t* o = out + i * Cpad;
     for (int c0 = 0; c0 < Cpad; c0 += 8) {
-        half8v h;
+        half8v h, l;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e;
             float v = 0.0f;
-            if (c < C1) v = a[(f * C1 + c) * Npix + pix];
+            if (c < C1) v = a[(f * C1 + c) * Npix + pix] * sa;
             else if (c < C1 + C2) v = b[(f * C2 + (c - C1)) * Npix + pix];
             h[e] = (half_t)v;
+            l[e] = (half_t)((v - (float)h[e]) * PNC_LO_SCALE);
         }
         *reinterpret_cast<half8v*>(o + c0) = h;
+        if (out_lo) *reinterpret_cast<half8v*>(out_lo + i * Cpad + c0) = l;
     }
 }
 
@@ -97,7 +103,8 @@ __global__ __launch_bounds__(256) void tokens_to_nchw_kernel(const float* __rest
 __global__ __launch_bounds__(256) void concat_add_kernel(const float* __restrict__ a, int C1,
                                                          const float* __restrict__ s,
                                                          const float* __restrict__ c, int C2, int64_t M,
-                                                         float* __restrict__ out32, half_t* __restrict__ out16) {
+                                                         float* __restrict__ out32, half_t* __restrict__ out16,
+                                                         half_t* __restrict__ out16_lo) {
     const int CT = C1 + C2, V = CT >> 2;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M * V) return;
@@ -118,11 +125,16 @@ __global__ __launch_bounds__(256) void concat_add_kernel(const float* __restrict
     if (out16) {
         half4v h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         *reinterpret_cast<half4v*>(out16 + m * CT + ch) = h;
+        if (out16_lo) {
+            const float o[4] = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<half4v*>(out16_lo + m * CT + ch) = lo_plane4(o, h);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, const float* __restrict__ a,
-                                                  int64_t n4, float* __restrict__ y32, half_t* __restrict__ y16) {
+                                                  int64_t n4, float* __restrict__ y32, half_t* __restrict__ y16,
+                                                  half_t* __restrict__ y16_lo) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
@@ -131,12 +143,25 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, c
     if (y16) {
         half4v h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         *reinterpret_cast<half4v*>(y16 + i * 4) = h;
+        if (y16_lo) {
+            const float o[4] = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<half4v*>(y16_lo + i * 4) = lo_plane4(o, h);
+        }
     }
 }
 
 }  // namespace
 
-extern "C" const char* pnc_version(void) { return "panacea_hip 0.1.0 gfx950"; }
+extern "C" const char* pnc_version(void) { return "panacea_hip 0.2.0 gfx950"; }
+
+static std::atomic<int> g_options[PNC_OPT_COUNT] = {{1}, {0}, {0}, {1}};
+
+int pnc_get_option(int option) { return g_options[option].load(std::memory_order_relaxed); }
+
+extern "C" int pnc_set_option(int option, int value) {
+    if (option < 0 || option >= PNC_OPT_COUNT) return PNC_EINVAL;
+    return g_options[option].exchange(value, std::memory_order_relaxed);
+}
 
 extern "C" int pnc_linear_smallm(const float* a, int lda, const void* W, const float* bias,
                                  float* out, int ldo, int M, int N, int K, int silu_in, int silu_out,
@@ -159,15 +184,15 @@ extern "C" int pnc_timestep_embedding(const int64_t* t, int F, int dim, const fl
     return pnc_launch_status();
 }
 
-extern "C" int pnc_nchw_to_tokens_f16(const float* a, int C1, const float* b, int C2,
-                                      int F, int Npix, int Cpad, void* out16, void* stream) {
+extern "C" int pnc_nchw_to_tokens_f16(const float* a, int C1, const float* a_scale, const float* b, int C2,
+                                      int F, int Npix, int Cpad, void* out16, void* out16_lo, void* stream) {
     if (!a || !out16 || F < 1 || Npix < 1 || C1 < 1 || C2 < 0 || (C2 > 0 && !b)) return PNC_EINVAL;
     if (Cpad % 8 || Cpad < C1 + C2) return PNC_EINVAL;
-    if ((uintptr_t)out16 & 15) return PNC_EALIGN;
+    if (((uintptr_t)out16 | (uintptr_t)out16_lo) & 15) return PNC_EALIGN;
     const int64_t n = (int64_t)F * Npix;
     hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), a, C1, b, C2, F, Npix, Cpad,
-                       reinterpret_cast<half_t*>(out16));
+                       reinterpret_cast<hipStream_t>(stream), a, C1, a_scale, b, C2, F, Npix, Cpad,
+                       reinterpret_cast<half_t*>(out16), reinterpret_cast<half_t*>(out16_lo));
     return pnc_launch_status();
 }
 
@@ -181,21 +206,23 @@ extern "C" int pnc_tokens_to_nchw_f32(const float* x, int ld, int F, int Npix, i
 }
 
 extern "C" int pnc_concat_add(const float* a, int C1, const float* s, const float* c, int C2,
-                              int64_t M, float* out32, void* out16, void* stream) {
+                              int64_t M, float* out32, void* out16, void* out16_lo, void* stream) {
     if (!a || !s || M < 1 || C1 % 4 || C2 % 4 || C1 < 4 || C2 < 4) return PNC_EINVAL;
-    if (!out32 && !out16) return PNC_EINVAL;
+    if ((!out32 && !out16) || (out16_lo && !out16)) return PNC_EINVAL;
     const int64_t n = M * ((C1 + C2) / 4);
     hipLaunchKernelGGL(concat_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a, C1, s, c, C2, M, out32,
-                       reinterpret_cast<half_t*>(out16));
+                       reinterpret_cast<half_t*>(out16), reinterpret_cast<half_t*>(out16_lo));
     return pnc_launch_status();
 }
 
-extern "C" int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16, void* stream) {
-    if (!x || n < 4 || n % 4 || (!y32 && !y16)) return PNC_EINVAL;
+extern "C" int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16, void* y16_lo,
+                           void* stream) {
+    if (!x || n < 4 || n % 4 || (!y32 && !y16) || (y16_lo && !y16)) return PNC_EINVAL;
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), x, a, n4, y32, reinterpret_cast<half_t*>(y16));
+                       reinterpret_cast<hipStream_t>(stream), x, a, n4, y32, reinterpret_cast<half_t*>(y16),
+                       reinterpret_cast<half_t*>(y16_lo));
     return pnc_launch_status();
 }
 
@@ -259,6 +286,6 @@ extern "C" int pnc_softmax_rows_f16(const float* s, int64_t lds, int M, int N, f
     return pnc_launch_status();
 }
 
-extern "C" int pnc_cast_f16(const float* x, int64_t n, void* y16, void* stream) {
-    return pnc_add_f32(x, nullptr, n, nullptr, y16, stream);
+extern "C" int pnc_cast_f16(const float* x, int64_t n, void* y16, void* y16_lo, void* stream) {
+    return pnc_add_f32(x, nullptr, n, nullptr, y16, y16_lo, stream);
 }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        int ppc, const float* __restrict__ partial,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu,
-                                                       half_t* __restrict__ y, int ldy) {
+                                                       half_t* __restrict__ y, int ldy, half_t* __restrict__ ylo) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // A[C], B[C], then mean[32], rstd[32]
     const int tabw = 2 * C > 24 * GROUPS ? 2 * C : 24 * GROUPS;
     float* sA = sm;
@@ -160,13 +160,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                     const f32x4 a = *reinterpret_cast<const f32x4*>(sA + cv * 4);
                     const f32x4 b = *reinterpret_cast<const f32x4*>(sB + cv * 4);
                     half4v h;
+                    float o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float o = fmaf(v[rr][j][e], a[e], b[e]);
-                        if (silu) o = silu_f(o);
-                        h[e] = (half_t)o;
+                        o[e] = fmaf(v[rr][j][e], a[e], b[e]);
+                        if (silu) o[e] = silu_f(o[e]);
+                        h[e] = (half_t)o[e];
                     }
                     *reinterpret_cast<half4v*>(yrow + cv * 4) = h;
+                    if (ylo) *reinterpret_cast<half4v*>(ylo + ((int64_t)f * Npix + pix) * ldy + cv * 4) = lo_plane4(o, h);
                 }
             }
         }
@@ -182,7 +184,7 @@ template <int T>
 __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restrict__ x, int B, int Npix, int C,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
-                                                          half_t* __restrict__ y, int PB) {
+                                                          half_t* __restrict__ y, half_t* __restrict__ ylo, int PB) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [PB][C/2][2] sums, then [PB][32][2] stats
     const int CP = C >> 1, C4 = C >> 2, cpg2 = (C / GROUPS) >> 1;
     float* s_part = sm;                           // PB*CP*2
@@ -244,12 +246,11 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restric
         const float g0 = gm[0] * ra, g1 = gm[1] * ra, g2 = gm[2] * rb, g3 = gm[3] * rb;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            half4v h;
-            h[0] = (half_t)silu_f(fmaf(v[it][t][0] - ma, g0, bt[0]));
-            h[1] = (half_t)silu_f(fmaf(v[it][t][1] - ma, g1, bt[1]));
-            h[2] = (half_t)silu_f(fmaf(v[it][t][2] - mb, g2, bt[2]));
-            h[3] = (half_t)silu_f(fmaf(v[it][t][3] - mb, g3, bt[3]));
+            const float o[4] = {silu_f(fmaf(v[it][t][0] - ma, g0, bt[0])), silu_f(fmaf(v[it][t][1] - ma, g1, bt[1])),
+                                silu_f(fmaf(v[it][t][2] - mb, g2, bt[2])), silu_f(fmaf(v[it][t][3] - mb, g3, bt[3]))};
+            const half4v h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
             *reinterpret_cast<half4v*>(y + off[it] + (int64_t)t * Npix * C) = h;
+            if (ylo) *reinterpret_cast<half4v*>(ylo + off[it] + (int64_t)t * Npix * C) = lo_plane4(o, h);
         }
     }
 }
@@ -261,7 +262,7 @@ template <int J>     // J = float4 vectors per lane = ceil(C / 256)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, int M, int C,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        half_t* __restrict__ y, int ldy) {
+                                                        half_t* __restrict__ y, int ldy, half_t* __restrict__ ylo) {
     const int lane = threadIdx.x & 63;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_R;
     if (row0 >= M) return;
@@ -326,9 +327,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const int cv = lane + j * 64;
             if (cv < CV) {
                 half4v h;
+                float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (half_t)fmaf((v[r][j][e] - mean[r]) * rs, g[j][e], b[j][e]);
+                for (int e = 0; e < 4; ++e) { o[e] = fmaf((v[r][j][e] - mean[r]) * rs, g[j][e], b[j][e]); h[e] = (half_t)o[e]; }
                 *reinterpret_cast<half4v*>(yr + cv * 4) = h;
+                if (ylo) *reinterpret_cast<half4v*>(ylo + (row0 + r) * ldy + cv * 4) = lo_plane4(o, h);
             }
         }
     }
@@ -364,26 +367,26 @@ extern "C" int pnc_groupnorm_stats(const float* x, int ldx, int F, int Npix, int
 extern "C" int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int C,
                                    int pix_per_chunk, const float* partial,
                                    const float* gamma, const float* beta, float eps, int silu,
-                                   void* y16, int ldy, void* stream) {
+                                   void* y16, int ldy, void* y16_lo, void* stream) {
     if (!x || !partial || !gamma || !beta || !y16 || F < 1 || Npix < 1 || pix_per_chunk < 1) return PNC_EINVAL;
     if (C % 64 || C > GN_MAXC || ldx % 4 || ldy % 4) return PNC_EINVAL;
-    if (((uintptr_t)x & 15) || ((uintptr_t)y16 & 7)) return PNC_EALIGN;
+    if (((uintptr_t)x & 15) || (((uintptr_t)y16 | (uintptr_t)y16_lo) & 7)) return PNC_EALIGN;
     const int nchunk = (Npix + pix_per_chunk - 1) / pix_per_chunk;
     const size_t lds = ((size_t)(2 * C > 24 * GROUPS ? 2 * C : 24 * GROUPS) + 2 * GROUPS) * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     half_t* y = reinterpret_cast<half_t*>(y16);
     PNC_GN_DISPATCH(gn_apply_kernel, dim3(nchunk, F), dim3(256), lds, st, x, ldx, Npix, C, pix_per_chunk, partial,
-                    gamma, beta, eps, silu, y, ldy);
+                    gamma, beta, eps, silu, y, ldy, reinterpret_cast<half_t*>(y16_lo));
     return pnc_launch_status();
 }
 
 extern "C" int pnc_groupnorm_temporal_silu(const float* x, int B, int T, int Npix, int C,
                                            const float* gamma, const float* beta, float eps,
-                                           void* y16, void* stream) {
+                                           void* y16, void* y16_lo, void* stream) {
     if (!x || !gamma || !beta || !y16 || B < 1 || Npix < 1) return PNC_EINVAL;
     if (C % 64 || C > 2048 || T < 1 || T > 8) return PNC_EINVAL;     // <= 512 four-channel items per pixel
     if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) return PNC_EALIGN;
-    if ((uintptr_t)y16 & 7) return PNC_EALIGN;
+    if (((uintptr_t)y16 | (uintptr_t)y16_lo) & 7) return PNC_EALIGN;
     const int CP = C / 2;
     int PB = 512 / (C / 4); if (PB < 1) PB = 1; if (PB > 16) PB = 16;       // <= 512 work items of 4 channels per block
     const int64_t total = (int64_t)B * Npix;
@@ -392,7 +395,7 @@ extern "C" int pnc_groupnorm_temporal_silu(const float* x, int B, int T, int Npi
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     half_t* y = reinterpret_cast<half_t*>(y16);
 #define PNC_GNT(TT) case TT: hipLaunchKernelGGL(gn_temporal_kernel<TT>, dim3(blocks), dim3(256), lds, st, \
-                                               x, B, Npix, C, gamma, beta, eps, y, PB); break;
+                                               x, B, Npix, C, gamma, beta, eps, y, reinterpret_cast<half_t*>(y16_lo), PB); break;
     switch (T) {
         PNC_GNT(1) PNC_GNT(2) PNC_GNT(3) PNC_GNT(4) PNC_GNT(5) PNC_GNT(6) PNC_GNT(7) PNC_GNT(8)
     }
@@ -402,16 +405,16 @@ extern "C" int pnc_groupnorm_temporal_silu(const float* x, int B, int T, int Npi
 
 extern "C" int pnc_layernorm(const float* x, int ldx, int M, int C,
                              const float* gamma, const float* beta, float eps,
-                             void* y16, int ldy, void* stream) {
+                             void* y16, int ldy, void* y16_lo, void* stream) {
     if (!x || !gamma || !beta || !y16 || M < 1) return PNC_EINVAL;
     if (C % 4 || C > 4 * 64 * 12 || C < 4 || ldx % 4 || ldy % 4) return PNC_EINVAL;
     if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) return PNC_EALIGN;
-    if ((uintptr_t)y16 & 7) return PNC_EALIGN;
+    if (((uintptr_t)y16 | (uintptr_t)y16_lo) & 7) return PNC_EALIGN;
     const unsigned blocks = (unsigned)(((int64_t)M + 4 * LN_R - 1) / (4 * LN_R));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     half_t* y = reinterpret_cast<half_t*>(y16);
     const int J = (C / 4 + 63) / 64;
-#define PNC_LN(JJ) hipLaunchKernelGGL(layernorm_kernel<JJ>, dim3(blocks), dim3(256), 0, st, x, ldx, M, C, gamma, beta, eps, y, ldy)
+#define PNC_LN(JJ) hipLaunchKernelGGL(layernorm_kernel<JJ>, dim3(blocks), dim3(256), 0, st, x, ldx, M, C, gamma, beta, eps, y, ldy, reinterpret_cast<half_t*>(y16_lo))
     if (J <= 1) PNC_LN(1); else if (J == 2) PNC_LN(2); else if (J == 3) PNC_LN(3); else if (J <= 5) PNC_LN(5);
     else if (J <= 8) PNC_LN(8); else PNC_LN(12);
 #undef PNC_LN

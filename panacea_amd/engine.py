@@ -45,6 +45,52 @@ def use_backend(be):
 TEXT_PAD = 80          # 77 text tokens padded to a multiple of 8 rows (zero rows, masked in the kernel)
 
 
+@dataclass(frozen=True)
+class Precision:
+    """Which fp16 operand classes are carried as PRECISE (split) pairs hi + lo * 2^-11 (include/panacea_hip.h,
+    PncGemmParams.A_lo): the consumer GEMM then runs its K loop twice.  The classes are those of the measured error
+    budget (tools/exp/error_budget.py) — share of the eps error variance at full width in brackets:
+
+      stream   [47 %] fp16 copies of the un-normalised fp32 stream: inputs of skip 1x1 convs, zero convs, Down/Upsample
+                      convs, the STT / ResBlock outputs handed to them, the skip concat
+      gn_stt   [11 %] GroupNorm output feeding proj_in / proj_in_temporal / proj_in_crossview
+      ff_out   [10 %] last transformer block's output feeding proj_out*
+      stem     [ 8 %] network input tokens (latent | concat) feeding the stem convs
+      gn_head  [ 8 %] GroupNorm+SiLU feeding the 4-channel output conv
+      gn_res   [ 5 %] GroupNorm+SiLU feeding the ResBlock3D 3x3 convs (the expensive one: doubles the conv3x3 family)
+      gnt      [ 3 %] temporal GroupNorm+SiLU feeding the temporal conv1d
+      conv_mid [ 2 %] fp16 activations between the layers of the ControlNet hint stem
+    LayerNorm outputs, q/k/v, the GEGLU hidden state and the attention output together are < 4 %: never split."""
+    stream: bool = False
+    gn_stt: bool = False
+    ff_out: bool = False
+    stem: bool = False
+    gn_head: bool = False
+    gn_res: bool = False
+    gnt: bool = False
+    conv_mid: bool = False
+
+    @property
+    def name(self) -> str:
+        on = [k for k, v in self.__dict__.items() if v]
+        return "fp16" if not on else "split(" + ",".join(on) + ")"
+
+
+FAST = Precision()
+# eps max-abs < 1e-3 at BASELINE config 3 (DESIGN.md §6): every class except the ResBlock conv inputs
+PRECISE = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True, gnt=True, conv_mid=True)
+PRECISE_ALL = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True, gn_res=True, gnt=True, conv_mid=True)
+PRECISIONS = {"fast": FAST, "precise": PRECISE, "precise-all": PRECISE_ALL}
+
+
+def precision(p) -> Precision:
+    if isinstance(p, Precision):
+        return p
+    if p not in PRECISIONS:
+        raise ValueError(f"unknown precision {p!r}: choose one of {sorted(PRECISIONS)} or pass an engine.Precision")
+    return PRECISIONS[p]
+
+
 @dataclass
 class Act:
     """A feature map in the resident layout: [F*H*W, C] tokens, fp32 stream and/or fp16 operand."""
@@ -54,6 +100,7 @@ class Act:
     C: int
     f32: Optional[torch.Tensor] = None
     f16: Optional[torch.Tensor] = None
+    f16_lo: Optional[torch.Tensor] = None      # lo plane when f16 is a precise (split) operand
 
     @property
     def N(self) -> int:
@@ -64,9 +111,11 @@ class Act:
         return self.F * self.H * self.W
 
     def need_f16(self, rt: "Runtime") -> torch.Tensor:
+        """fp16 operand copy of the stream (operand class `stream`: the lo plane lands in `f16_lo`)"""
         if self.f16 is None:
             self.f16 = rt.empty((self.M, self.C), torch.float16)
-            rt.be.cast_f16(self.f32, self.M * self.C, self.f16)
+            self.f16_lo = rt.empty((self.M, self.C), torch.float16) if rt.prec.stream else None
+            rt.be.cast_f16(self.f32, self.M * self.C, self.f16, self.f16_lo)
         return self.f16
 
     def to_nchw(self) -> torch.Tensor:
@@ -81,6 +130,7 @@ class Runtime:
         self.be = backend()
         self.device = device
         self.B, self.T, self.F = B, T, B * T
+        self.prec: Precision = FAST                    # operand precision policy of this evaluation
         self.ctx16: Optional[torch.Tensor] = None      # [B*TEXT_PAD, context_dim] fp16, zero padded
         self.n_text = 77
         self.trace: Optional[Dict[str, torch.Tensor]] = None
@@ -197,22 +247,27 @@ def _ppc(npix: int) -> int:
     return max(16, min(128, npix // 48), -(-npix // 256))
 
 
-def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, beta, eps: float, silu: bool) -> torch.Tensor:
+def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, beta, eps: float, silu: bool,
+               split: bool = False):
+    """-> (y16, y16_lo): y16_lo is None unless `split` (precise operand for the consumer GEMM)."""
     if C % 64:
         raise ValueError(f"GroupNorm(32) kernels need C % 64 == 0, got {C}")
     ppc = _ppc(N)
     nchunk = (N + ppc - 1) // ppc
     part = rt.empty((F * nchunk * 32 * 3,), torch.float32)
     y = rt.empty((F * N, C), torch.float16)
+    ylo = rt.empty((F * N, C), torch.float16) if split else None
     rt.be.groupnorm_stats(x32, C, F, N, C, ppc, part)
-    rt.be.groupnorm_apply(x32, C, F, N, C, ppc, part, gamma, beta, eps, silu, y, C)
-    return y
+    rt.be.groupnorm_apply(x32, C, F, N, C, ppc, part, gamma, beta, eps, silu, y, C, ylo)
+    return y, ylo
 
 
-def gn_temporal(rt: Runtime, x32: torch.Tensor, N: int, C: int, gamma, beta, eps: float) -> torch.Tensor:
+def gn_temporal(rt: Runtime, x32: torch.Tensor, N: int, C: int, gamma, beta, eps: float):
+    """-> (y16, y16_lo) (operand class `gnt`)"""
     y = rt.empty((rt.F * N, C), torch.float16)
-    rt.be.groupnorm_temporal_silu(x32, rt.B, rt.T, N, C, gamma, beta, eps, y)
-    return y
+    ylo = rt.empty((rt.F * N, C), torch.float16) if rt.prec.gnt else None
+    rt.be.groupnorm_temporal_silu(x32, rt.B, rt.T, N, C, gamma, beta, eps, y, ylo)
+    return y, ylo
 
 
 def layer_norm(rt: Runtime, x32: torch.Tensor, M: int, C: int, gamma, beta) -> torch.Tensor:

@@ -20,6 +20,7 @@ HEADER = PKG.parent / "include" / "panacea_hip.h"
 
 A_PLAIN, A_CONV3X3, A_CONV1D_T = 0, 1, 2
 ACT_NONE, ACT_SILU = 0, 1
+ABI_VERSION = 2          # PNC_ABI_VERSION of include/panacea_hip.h this binding was written against
 
 
 class HipLibraryError(RuntimeError):
@@ -47,7 +48,8 @@ class GemmParams(C.Structure):
         ("out16t", C.c_void_p), ("ldt", C.c_int32), ("t_rows", C.c_int32), ("t_gstride", C.c_int64),
         ("n_split", C.c_int32), ("act", C.c_int32), ("geglu", C.c_int32),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
-        ("conv_pad_br", C.c_int32), ("reserved0", C.c_int32),
+        ("conv_pad_br", C.c_int32), ("struct_bytes", C.c_int32),
+        ("A_lo", C.c_void_p), ("out16_lo", C.c_void_p),
     ]
 
 
@@ -69,22 +71,24 @@ class AttnParams(C.Structure):
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGNATURES = {
     "pnc_version": (C.c_char_p, []),
+    "pnc_abi_version": (_I, []),
+    "pnc_set_option": (_I, [_I, _I]),
     "pnc_gemm_f16": (_I, [C.POINTER(GemmParams), _P]),
     "pnc_gemm_workspace_floats": (_L, [C.POINTER(GemmParams)]),
     "pnc_attn_views_f16": (_I, [C.POINTER(AttnParams), _P]),
     "pnc_softmax_rows_f16": (_I, [_P, _L, _I, _I, _F, _P, _L, _P]),
     "pnc_attn_temporal_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "pnc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
-    "pnc_groupnorm_apply": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P]),
-    "pnc_groupnorm_temporal_silu": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P]),
-    "pnc_layernorm": (_I, [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P]),
+    "pnc_groupnorm_apply": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P, _P]),
+    "pnc_groupnorm_temporal_silu": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P]),
+    "pnc_layernorm": (_I, [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P]),
     "pnc_linear_smallm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "pnc_timestep_embedding": (_I, [_P, _I, _I, _P, _P, _P]),
-    "pnc_nchw_to_tokens_f16": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "pnc_nchw_to_tokens_f16": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "pnc_tokens_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    "pnc_concat_add": (_I, [_P, _I, _P, _P, _I, _L, _P, _P, _P]),
-    "pnc_add_f32": (_I, [_P, _P, _L, _P, _P, _P]),
-    "pnc_cast_f16": (_I, [_P, _L, _P, _P]),
+    "pnc_concat_add": (_I, [_P, _I, _P, _P, _I, _L, _P, _P, _P, _P]),
+    "pnc_add_f32": (_I, [_P, _P, _L, _P, _P, _P, _P]),
+    "pnc_cast_f16": (_I, [_P, _L, _P, _P, _P]),
 }
 
 _lib = None
@@ -121,8 +125,22 @@ def load():
             raise HipLibraryError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
         fn.restype = res
         fn.argtypes = args
+    if lib.pnc_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"{LIB_PATH} implements C-ABI version {lib.pnc_abi_version()}, this binding needs "
+                              f"{ABI_VERSION}; rebuild the extension (`python -m panacea_amd.build --force`)")
     _lib = lib
     return lib
+
+
+OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA = 0, 1, 2, 3
+
+
+def set_option(option: int, value: int) -> int:
+    """pnc_set_option: process-global tuning / test switch of the library; returns the previous value."""
+    prev = load().pnc_set_option(option, value)
+    if prev == -1:
+        raise PncError(f"unknown library option {option}")
+    return prev
 
 
 class Profiler:
@@ -165,7 +183,8 @@ def _timed(family: str, flops: float, nbytes: float, fn, *args):
 
 def _check(rc: int, what: str):
     if rc != 0:
-        kind = {-1: "PNC_EINVAL (unsupported shape/argument)", -2: "PNC_EALIGN (alignment)"}.get(rc, f"hipError {rc}")
+        kind = {-1: "PNC_EINVAL (unsupported shape/argument)", -2: "PNC_EALIGN (alignment)",
+                -3: "PNC_EABI (parameter struct of another header version)"}.get(rc, f"hipError {rc}")
         raise PncError(f"{what} failed: {kind}")
 
 
@@ -201,9 +220,13 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
          out32: Optional[torch.Tensor] = None, ldc32: int = 0,
          out16: Optional[torch.Tensor] = None, ldc16: int = 0,
          out16t: Optional[torch.Tensor] = None, ldt: int = 0, t_rows: int = 0, t_gstride: int = 0,
-         n_split: int = 0, act: int = ACT_NONE, geglu: bool = False):
+         n_split: int = 0, act: int = ACT_NONE, geglu: bool = False,
+         a16_lo: Optional[torch.Tensor] = None, out16_lo: Optional[torch.Tensor] = None):
+    """`a16_lo` / `out16_lo`: lo planes of precise (split) operands, see PncGemmParams.A_lo in the header."""
     p = GemmParams()
+    p.struct_bytes = C.sizeof(GemmParams)
     p.A, p.W = _ptr(a16), _ptr(w16)
+    p.A_lo, p.out16_lo = _ptr(a16_lo), _ptr(out16_lo)
     p.M, p.N, p.K, p.lda, p.a_mode = M, N, K, lda, a_mode
     if conv:
         p.Cin, p.Hin, p.Win = conv["Cin"], conv["Hin"], conv["Win"]
@@ -225,7 +248,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
         ws = torch.empty(nws, device=a16.device, dtype=torch.float32)
         p.ws, p.ws_floats = _ptr(ws), nws
     fam = ("gemm_plain", "gemm_conv3x3", "gemm_conv1d_t")[a_mode]
-    _check(_timed(fam, 2.0 * M * N * K, 0.0, load().pnc_gemm_f16, C.byref(p), _stream()), "pnc_gemm_f16")
+    _check(_timed(fam, 2.0 * M * N * K, 0.0, lib.pnc_gemm_f16, C.byref(p), _stream()), "pnc_gemm_f16")
 
 
 def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H, W, views,
@@ -263,21 +286,24 @@ def groupnorm_stats(x32, ldx, F, Npix, Cch, ppc, partial):
                   ppc, _ptr(partial), _stream()), "pnc_groupnorm_stats")
 
 
-def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy):
-    _check(_timed("groupnorm", 0.0, 6.0 * F * Npix * Cch, load().pnc_groupnorm_apply, _ptr(x32), ldx, F, Npix, Cch,
-                  ppc, _ptr(partial), _ptr(gamma), _ptr(beta), eps, int(silu), _ptr(y16), ldy, _stream()),
+def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy, y16_lo=None):
+    nb = (8.0 if y16_lo is not None else 6.0) * F * Npix * Cch
+    _check(_timed("groupnorm", 0.0, nb, load().pnc_groupnorm_apply, _ptr(x32), ldx, F, Npix, Cch,
+                  ppc, _ptr(partial), _ptr(gamma), _ptr(beta), eps, int(silu), _ptr(y16), ldy, _ptr(y16_lo), _stream()),
            "pnc_groupnorm_apply")
 
 
-def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16):
-    _check(_timed("groupnorm_temporal", 0.0, 6.0 * B * T * Npix * Cch, load().pnc_groupnorm_temporal_silu,
-                  _ptr(x32), B, T, Npix, Cch, _ptr(gamma), _ptr(beta), eps, _ptr(y16), _stream()),
+def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16, y16_lo=None):
+    nb = (8.0 if y16_lo is not None else 6.0) * B * T * Npix * Cch
+    _check(_timed("groupnorm_temporal", 0.0, nb, load().pnc_groupnorm_temporal_silu,
+                  _ptr(x32), B, T, Npix, Cch, _ptr(gamma), _ptr(beta), eps, _ptr(y16), _ptr(y16_lo), _stream()),
            "pnc_groupnorm_temporal_silu")
 
 
-def layernorm(x32, ldx, M, Cch, gamma, beta, eps, y16, ldy):
-    _check(_timed("layernorm", 0.0, 6.0 * M * Cch, load().pnc_layernorm, _ptr(x32), ldx, M, Cch, _ptr(gamma),
-                  _ptr(beta), eps, _ptr(y16), ldy, _stream()), "pnc_layernorm")
+def layernorm(x32, ldx, M, Cch, gamma, beta, eps, y16, ldy, y16_lo=None):
+    nb = (8.0 if y16_lo is not None else 6.0) * M * Cch
+    _check(_timed("layernorm", 0.0, nb, load().pnc_layernorm, _ptr(x32), ldx, M, Cch, _ptr(gamma),
+                  _ptr(beta), eps, _ptr(y16), ldy, _ptr(y16_lo), _stream()), "pnc_layernorm")
 
 
 def linear_smallm(a32, lda, w16, bias, out32, ldo, M, N, K, silu_in=False, silu_out=False):
@@ -290,9 +316,10 @@ def timestep_embedding(t_i64, F, dim, freqs, out32):
            "pnc_timestep_embedding")
 
 
-def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16):
+def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16, out16_lo=None, a_scale=None):
     _check(_timed("layout", 0.0, F * Npix * (4.0 * (C1 + C2) + 2.0 * Cpad), load().pnc_nchw_to_tokens_f16, _ptr(a32),
-                  C1, _ptr(b32), C2, F, Npix, Cpad, _ptr(out16), _stream()), "pnc_nchw_to_tokens_f16")
+                  C1, _ptr(a_scale), _ptr(b32), C2, F, Npix, Cpad, _ptr(out16), _ptr(out16_lo), _stream()),
+           "pnc_nchw_to_tokens_f16")
 
 
 def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):
@@ -300,16 +327,16 @@ def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):
            "pnc_tokens_to_nchw_f32")
 
 
-def concat_add(a32, C1, s32, c32, C2, M, out32, out16):
-    nb = M * (4.0 * C1 + (8.0 if c32 is not None else 4.0) * C2 + 6.0 * (C1 + C2))
+def concat_add(a32, C1, s32, c32, C2, M, out32, out16, out16_lo=None):
+    nb = M * (4.0 * C1 + (8.0 if c32 is not None else 4.0) * C2 + (8.0 if out16_lo is not None else 6.0) * (C1 + C2))
     _check(_timed("elementwise", 0.0, nb, load().pnc_concat_add, _ptr(a32), C1, _ptr(s32), _ptr(c32), C2, M,
-                  _ptr(out32), _ptr(out16), _stream()), "pnc_concat_add")
+                  _ptr(out32), _ptr(out16), _ptr(out16_lo), _stream()), "pnc_concat_add")
 
 
-def add_f32(x32, a32, n, y32, y16):
+def add_f32(x32, a32, n, y32, y16, y16_lo=None):
     _check(_timed("elementwise", 0.0, 12.0 * n, load().pnc_add_f32, _ptr(x32), _ptr(a32), n, _ptr(y32), _ptr(y16),
-                  _stream()), "pnc_add_f32")
+                  _ptr(y16_lo), _stream()), "pnc_add_f32")
 
 
-def cast_f16(x32, n, y16):
-    _check(load().pnc_cast_f16(_ptr(x32), n, _ptr(y16), _stream()), "pnc_cast_f16")
+def cast_f16(x32, n, y16, y16_lo=None):
+    _check(load().pnc_cast_f16(_ptr(x32), n, _ptr(y16), _ptr(y16_lo), _stream()), "pnc_cast_f16")

@@ -80,15 +80,15 @@ class FeedForward(nn.Module, Packable):
         w1, b1 = E.pk_geglu(self.net[0].proj.weight, self.net[0].proj.bias)
         return dict(w1=w1, b1=b1, w2=E.pk_linear(self.net[2].weight), b2=E.pk_f32(self.net[2].bias))
 
-    def _run(self, rt: Runtime, x16, M, res32, out32=None, out16=None):
-        """out = FF(x16) + res32 -> out32 (may alias res32) and/or out16."""
+    def _run(self, rt: Runtime, x16, M, res32, out32=None, out16=None, out16_lo=None):
+        """out = FF(x16) + res32 -> out32 (may alias res32) and/or out16 (+ lo plane of a precise operand)."""
         pk = self.packed()
         hid = rt.empty((M, self.inner_dim), torch.float16)
         rt.be.gemm(x16, pk["w1"], M=M, N=2 * self.inner_dim, K=self.dim, lda=self.dim, bias=pk["b1"],
                    geglu=True, out16=hid, ldc16=self.inner_dim)
         rt.be.gemm(hid, pk["w2"], M=M, N=self.dim_out, K=self.inner_dim, lda=self.inner_dim, bias=pk["b2"],
                    res1=res32, ldr1=self.dim_out, out32=out32, ldc32=self.dim_out, out16=out16,
-                   ldc16=self.dim_out)
+                   ldc16=self.dim_out, out16_lo=out16_lo)
 
 
 class _AttentionBase(nn.Module, Packable):
@@ -244,7 +244,8 @@ class BasicTransformerBlock(nn.Module, Packable):
                 for n in ("norm1", "norm2", "norm3") for s in ("w", "b")}
 
     def _run(self, rt: Runtime, t32, F, H, W, branch: str, last: bool):
-        """t32 [M, dim] fp32 stream, updated in place; returns the fp16 copy of the final x when `last`."""
+        """t32 [M, dim] fp32 stream, updated in place; returns the fp16 copy (hi, lo) of the final x when `last`
+        (operand class `ff_out`)."""
         pk = self.packed()
         C, N = self.dim, H * W
         M = F * N
@@ -264,8 +265,9 @@ class BasicTransformerBlock(nn.Module, Packable):
         x16 = E.layer_norm(rt, t32, M, C, pk["norm3w"], pk["norm3b"])
         if last:
             out16 = rt.empty((M, C), torch.float16)
-            self.ff._run(rt, x16, M, t32, out32=None, out16=out16)
-            return out16
+            out16lo = rt.empty((M, C), torch.float16) if rt.prec.ff_out else None
+            self.ff._run(rt, x16, M, t32, out32=None, out16=out16, out16_lo=out16lo)
+            return out16, out16lo
         self.ff._run(rt, x16, M, t32, out32=t32)
         return None
 
@@ -335,23 +337,27 @@ class SpatialTemporalTransformer(nn.Module, Packable):
         pk["pos"] = E.temporal_pos_table(self.num_frames, self.inner_dim).to(self.proj_in.weight.device)
         return pk
 
-    def _branch(self, rt: Runtime, x: Act, sfx: str, blocks, branch: str, out16=None):
+    def _branch(self, rt: Runtime, x: Act, sfx: str, blocks, branch: str, out16=None, out16_lo=None):
         pk = self.packed()
         C, M = x.C, x.M
-        n16 = E.gn_spatial(rt, x.f32, x.F, x.N, C, pk["g" + sfx], pk["b" + sfx], 1e-6, False)
+        n16, n16lo = E.gn_spatial(rt, x.f32, x.F, x.N, C, pk["g" + sfx], pk["b" + sfx], 1e-6, False,
+                                  split=rt.prec.gn_stt)
         t32 = rt.empty((M, C), torch.float32)
         if branch == "temporal":
             # + position table indexed by t = frame % T (attention.py:1117-1118)
             rt.be.gemm(n16, pk["wi" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bi" + sfx], rowbias=pk["pos"],
-                       rb_rows=x.N, rb_mod=rt.T, out32=t32, ldc32=C)
+                       rb_rows=x.N, rb_mod=rt.T, out32=t32, ldc32=C, a16_lo=n16lo)
         else:
-            rt.be.gemm(n16, pk["wi" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bi" + sfx], out32=t32, ldc32=C)
-        p16 = None
+            rt.be.gemm(n16, pk["wi" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bi" + sfx], out32=t32, ldc32=C,
+                       a16_lo=n16lo)
+        p16 = p16lo = None
         for i, blk in enumerate(blocks):
-            p16 = blk._run(rt, t32, x.F, x.H, x.W, branch, last=(i == len(blocks) - 1))
+            r = blk._run(rt, t32, x.F, x.H, x.W, branch, last=(i == len(blocks) - 1))
+            if r is not None:
+                p16, p16lo = r
         # x = proj_out(t) + x_in, in place on the stream
         rt.be.gemm(p16, pk["wo" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bo" + sfx], res1=x.f32, ldr1=C,
-                   out32=x.f32, ldc32=C, out16=out16, ldc16=C)
+                   out32=x.f32, ldc32=C, out16=out16, ldc16=C, a16_lo=p16lo, out16_lo=out16_lo)
 
     def _run(self, rt: Runtime, x: Act, want_f16: bool = False) -> Act:
         if rt.T != self.num_frames:
@@ -360,8 +366,9 @@ class SpatialTemporalTransformer(nn.Module, Packable):
         if self.insert_crossview:
             self._branch(rt, x, "_crossview", self.transformer_blocks_crossview, "crossview")
         out16 = rt.empty((x.M, x.C), torch.float16) if want_f16 else None
-        self._branch(rt, x, "_temporal", self.transformer_blocks_temporal, "temporal", out16=out16)
-        return Act(x.F, x.H, x.W, x.C, f32=x.f32, f16=out16)
+        out16lo = rt.empty((x.M, x.C), torch.float16) if (want_f16 and rt.prec.stream) else None
+        self._branch(rt, x, "_temporal", self.transformer_blocks_temporal, "temporal", out16=out16, out16_lo=out16lo)
+        return Act(x.F, x.H, x.W, x.C, f32=x.f32, f16=out16, f16_lo=out16lo)
 
     def forward(self, x, context=None):
         """Reference-compatible entry: x (B*T, C, h, w) NCHW, context (B*T, n, D) already tiled over T."""

@@ -84,12 +84,13 @@ class ControlNet3D(UNetModel3D):
         F, C, H, W = hint.shape
         cp = (C + 7) // 8 * 8
         t16 = rt.empty((F * H * W, cp), torch.float16)
-        rt.be.nchw_to_tokens_f16(hint.detach().to(torch.float32).contiguous(), C, None, 0, F, H * W, cp, t16)
-        a = Act(F, H, W, cp, f16=t16)
+        t16lo = rt.empty((F * H * W, cp), torch.float16) if rt.prec.conv_mid else None
+        rt.be.nchw_to_tokens_f16(hint.detach().to(torch.float32).contiguous(), C, None, 0, F, H * W, cp, t16, t16lo)
+        a = Act(F, H, W, cp, f16=t16, f16_lo=t16lo)
         for i, ((w, b), s) in enumerate(zip(pk["hint"], HINT_STRIDES)):
             last = i == len(HINT_STRIDES) - 1
             a = run_conv3x3(rt, a.f16, a.F, a.H, a.W, a.C, w, b, w.shape[0], stride=s, act_silu=not last,
-                            out32=last, out16=not last)
+                            out32=last, out16=not last, x16_lo=a.f16_lo, split_out=rt.prec.conv_mid)
         return a
 
     def _run_control(self, rt: Runtime, x16: Act, hint: torch.Tensor, emb32: torch.Tensor) -> List[Act]:
@@ -106,7 +107,8 @@ class ControlNet3D(UNetModel3D):
                     raise ValueError(f"hint stem output {guided.H}x{guided.W}x{guided.C} does not match the latent "
                                      f"{h.H}x{h.W}x{h.C} (the hint must be 8x the latent resolution)")
                 h.f16 = rt.empty((h.M, h.C), torch.float16)
-                rt.be.add_f32(h.f32, guided.f32, h.M * h.C, h.f32, h.f16)             # h += guided_hint
+                h.f16_lo = rt.empty((h.M, h.C), torch.float16) if rt.prec.stream else None
+                rt.be.add_f32(h.f32, guided.f32, h.M * h.C, h.f32, h.f16, h.f16_lo)   # h += guided_hint
             outs.append(self._zero_conv(rt, h, zw, zb))
         h = self.middle_block._run(rt, h, emb32, want_f16=True)
         if rt.trace is not None:
@@ -118,7 +120,7 @@ class ControlNet3D(UNetModel3D):
     @staticmethod
     def _zero_conv(rt: Runtime, h: Act, w16, b) -> Act:
         o = rt.empty((h.M, h.C), torch.float32)
-        rt.be.gemm(h.need_f16(rt), w16, M=h.M, N=h.C, K=h.C, lda=h.C, bias=b, out32=o, ldc32=h.C)
+        rt.be.gemm(h.need_f16(rt), w16, M=h.M, N=h.C, K=h.C, lda=h.C, bias=b, out32=o, ldc32=h.C, a16_lo=h.f16_lo)
         return Act(h.F, h.H, h.W, h.C, f32=o)
 
     def forward(self, x, hint, timesteps=None, context=None, y=None, **kwargs):
@@ -127,6 +129,7 @@ class ControlNet3D(UNetModel3D):
             "must specify y if and only if the model is class-conditional"
         with torch.no_grad():
             rt = runtime_for(x, self.num_frames)
+            rt.prec = E.precision(self.precision)
             rt.set_context(context)
             emb = self._time_embedding(rt, timesteps)
             outs = self._run_control(rt, self._stem_tokens(rt, x), hint, emb)
@@ -151,6 +154,7 @@ class ControlledUNetModel3D(UNetModel3D):
             "must specify y if and only if the model is class-conditional"
         with torch.no_grad():
             rt = runtime_for(x, self.num_frames)
+            rt.prec = E.precision(self.precision)
             rt.set_context(context)
             emb = self._time_embedding(rt, timesteps)
             acts = None
@@ -168,11 +172,12 @@ class ControlledUNetModel3D(UNetModel3D):
         with torch.no_grad():
             F = hint.shape[0]
             rt = Runtime(hint.device, F // self.num_frames, self.num_frames)
+            rt.prec = E.precision(self.precision)
             rt.set_context(context)
             self._project_text(rt)
             self.controlnet._project_text(rt)
             guided = self.controlnet._hint_stem(rt, hint.detach().to(torch.float32).contiguous())
-        return StepInvariants(rt.ctx16, rt.n_text, dict(rt.text_kv), guided, (context, hint))
+        return StepInvariants(rt.ctx16, rt.n_text, dict(rt.text_kv), guided, (context, hint), rt.prec)
 
     two_stream = True      # run the ControlNet branch on a second HIP stream, concurrently with the UNet encoder
     split_samples = False  # additionally run every sample of the batch (CFG half) as its own stream pair
@@ -207,6 +212,7 @@ class ControlledUNetModel3D(UNetModel3D):
     def _denoise_one(self, x, timesteps, context, hint, trace, side_idx, inv=None) -> torch.Tensor:
         with torch.no_grad():
             rt = runtime_for(x, self.num_frames)
+            rt.prec = E.precision(self.precision)
             rt.trace = trace
             if inv is not None:
                 inv.check(rt, context, hint)
@@ -244,8 +250,8 @@ class ControlledUNetModel3D(UNetModel3D):
 class StepInvariants:
     """Result of ControlledUNetModel3D.prepare(): tensors that are constant over the sampler steps of one sample."""
 
-    def __init__(self, ctx16, n_text, text_kv, guided, sources):
-        self.ctx16, self.n_text, self.text_kv, self.guided = ctx16, n_text, text_kv, guided
+    def __init__(self, ctx16, n_text, text_kv, guided, sources, prec=E.FAST):
+        self.ctx16, self.n_text, self.text_kv, self.guided, self.prec = ctx16, n_text, text_kv, guided, prec
         self._src = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in sources)
 
     def check(self, rt: Runtime, context, hint):
@@ -253,6 +259,8 @@ class StepInvariants:
         now = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in (context, hint))
         if now != self._src:
             raise ValueError("StepInvariants were prepared for different (or since modified) context / hint tensors")
+        if self.prec != rt.prec:
+            raise ValueError(f"StepInvariants were prepared with precision {self.prec.name}, the network runs {rt.prec.name}")
         if self.guided.F != rt.F:
             raise ValueError(f"StepInvariants hold {self.guided.F} frames, the batch has {rt.F}")
 

@@ -139,9 +139,9 @@ class ResnetBlock(nn.Module, Packable):
     def _run(self, rt: Runtime, x: Act) -> Act:
         pk = self.packed()
         Ci, Co = self.in_channels, self.out_channels
-        h16 = E.gn_spatial(rt, x.f32, x.F, x.N, Ci, *pk["n1"], 1e-6, True)
+        h16, _ = E.gn_spatial(rt, x.f32, x.F, x.N, Ci, *pk["n1"], 1e-6, True)
         h = _conv3x3(rt, h16, x.F, x.H, x.W, Ci, *pk["c1"], Co)
-        h16 = E.gn_spatial(rt, h.f32, x.F, x.N, Co, *pk["n2"], 1e-6, True)
+        h16, _ = E.gn_spatial(rt, h.f32, x.F, x.N, Co, *pk["n2"], 1e-6, True)
         skip = x.f32
         if Ci != Co:
             w, b = pk["sc"]
@@ -182,7 +182,7 @@ class AttnBlock(nn.Module, Packable):
         C, N, M, F = self.in_channels, x.N, x.M, x.F
         if N > 16384 or N % 8:
             raise NotImplementedError(f"AttnBlock over {N} tokens per frame (supported: multiples of 8 up to 16384)")
-        h16 = E.gn_spatial(rt, x.f32, F, N, C, *pk["n"], 1e-6, False)
+        h16, _ = E.gn_spatial(rt, x.f32, F, N, C, *pk["n"], 1e-6, False)
         q16, k16 = rt.empty((M, C), torch.float16), rt.empty((M, C), torch.float16)
         vt16 = rt.empty((F, C, N), torch.float16)                       # channel-major V^T per frame
         rt.be.gemm(h16, pk["q"][0], M=M, N=C, K=C, lda=C, bias=pk["q"][1], out16=q16, ldc16=C)
@@ -284,7 +284,7 @@ class Decoder(nn.Module, Packable):
                 h = up.upsample._run(rt, h)
         if self.give_pre_end:
             return h
-        h16 = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, *pk["no"], 1e-6, True)
+        h16, _ = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, *pk["no"], 1e-6, True)
         w, b = pk["cout"]
         return _conv3x3(rt, h16, h.F, h.H, h.W, h.C, w, b, self.out_ch)
 
@@ -365,7 +365,7 @@ class Encoder(nn.Module, Packable):
         if isinstance(self.mid.attn_1, AttnBlock):
             h = self.mid.attn_1._run(rt, h)
         h = self.mid.block_2._run(rt, h)
-        h16 = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, *pk["no"], 1e-6, True)
+        h16, _ = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, *pk["no"], 1e-6, True)
         w, b = pk["cout"]
         return _conv3x3(rt, h16, h.F, h.H, h.W, h.C, w, b, self.out_channels)
 

@@ -46,8 +46,9 @@ def conv_params(conv: nn.Conv2d):
 
 def run_conv3x3(rt: Runtime, x16: torch.Tensor, F: int, Hin: int, Win: int, Cin_pad: int, w16, bias, Cout: int,
                 stride: int = 1, upsample: bool = False, act_silu: bool = False, out32: bool = True,
-                out16: bool = False):
-    """3x3 conv (pad 1) as implicit GEMM over the channels-last fp16 image x16 [F*Hin*Win, Cin_pad]."""
+                out16: bool = False, x16_lo: Optional[torch.Tensor] = None, split_out: bool = False):
+    """3x3 conv (pad 1) as implicit GEMM over the channels-last fp16 image x16 [F*Hin*Win, Cin_pad] (+ lo plane of a
+    precise operand); `split_out`: the fp16 output is written as a precise pair."""
     if upsample:
         Hout, Wout = 2 * Hin, 2 * Win
     else:
@@ -55,11 +56,12 @@ def run_conv3x3(rt: Runtime, x16: torch.Tensor, F: int, Hin: int, Win: int, Cin_
     M = F * Hout * Wout
     o32 = rt.empty((M, Cout), torch.float32) if out32 else None
     o16 = rt.empty((M, Cout), torch.float16) if out16 else None
+    o16lo = rt.empty((M, Cout), torch.float16) if (out16 and split_out) else None
     rt.be.gemm(x16, w16, M=M, N=Cout, K=9 * Cin_pad, a_mode=E._hip.A_CONV3X3,
                conv=dict(Cin=Cin_pad, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride, upsample=int(upsample)),
                bias=bias, act=E._hip.ACT_SILU if act_silu else E._hip.ACT_NONE,
-               out32=o32, ldc32=Cout, out16=o16, ldc16=Cout)
-    return Act(F, Hout, Wout, Cout, f32=o32, f16=o16)
+               out32=o32, ldc32=Cout, out16=o16, ldc16=Cout, a16_lo=x16_lo, out16_lo=o16lo)
+    return Act(F, Hout, Wout, Cout, f32=o32, f16=o16, f16_lo=o16lo)
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock, Packable):
@@ -87,13 +89,15 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock, Packable):
                 w16, b = self.packed()[i]
                 if layer.kernel_size[0] == 3:
                     x = run_conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, w16, b, layer.out_channels,
-                                    stride=layer.stride[0], out16=wf)
+                                    stride=layer.stride[0], out16=wf, x16_lo=x.f16_lo, split_out=rt.prec.stream)
                 else:
                     o32 = rt.empty((x.M, layer.out_channels), torch.float32)
                     o16 = rt.empty((x.M, layer.out_channels), torch.float16) if wf else None
+                    o16lo = rt.empty((x.M, layer.out_channels), torch.float16) if (wf and rt.prec.stream) else None
                     rt.be.gemm(x.need_f16(rt), w16, M=x.M, N=layer.out_channels, K=x.C, lda=x.C, bias=b,
-                               out32=o32, ldc32=layer.out_channels, out16=o16, ldc16=layer.out_channels)
-                    x = Act(x.F, x.H, x.W, layer.out_channels, f32=o32, f16=o16)
+                               out32=o32, ldc32=layer.out_channels, out16=o16, ldc16=layer.out_channels,
+                               a16_lo=x.f16_lo, out16_lo=o16lo)
+                    x = Act(x.F, x.H, x.W, layer.out_channels, f32=o32, f16=o16, f16_lo=o16lo)
             else:
                 raise NotImplementedError(f"{type(layer).__name__} inside TimestepEmbedSequential")
         return x
@@ -117,7 +121,7 @@ class Upsample(nn.Module, Packable):
     def _run(self, rt: Runtime, x: Act, want_f16=False) -> Act:
         pk = self.packed()
         return run_conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, pk["w"], pk["b"], self.out_channels,
-                           upsample=True, out16=want_f16)
+                           upsample=True, out16=want_f16, x16_lo=x.f16_lo, split_out=rt.prec.stream)
 
 
 class Downsample(nn.Module, Packable):
@@ -138,7 +142,7 @@ class Downsample(nn.Module, Packable):
     def _run(self, rt: Runtime, x: Act, want_f16=False) -> Act:
         pk = self.packed()
         return run_conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, pk["w"], pk["b"], self.out_channels,
-                           stride=2, out16=want_f16)
+                           stride=2, out16=want_f16, x16_lo=x.f16_lo, split_out=rt.prec.stream)
 
 
 class ResBlock3D(TimestepBlock, Packable):
@@ -198,30 +202,33 @@ class ResBlock3D(TimestepBlock, Packable):
         hip = E._hip
         tconv = dict(C=Co, T=rt.T, Npix=N)
         # in_layers: GN + SiLU + conv3x3
-        a16 = E.gn_spatial(rt, x.f32, F, N, Cin, pk["g1"], pk["b1"], 1e-5, True)
-        h = run_conv3x3(rt, a16, F, H, W, Cin, pk["w1"], pk["c1"], Co).f32
+        a16, a16lo = E.gn_spatial(rt, x.f32, F, N, Cin, pk["g1"], pk["b1"], 1e-5, True, split=rt.prec.gn_res)
+        h = run_conv3x3(rt, a16, F, H, W, Cin, pk["w1"], pk["c1"], Co, x16_lo=a16lo).f32
         # h = h + conv1d_t(SiLU(GN_t(h))) + emb_layers(emb)[frame]      (:505-531)
-        t16 = E.gn_temporal(rt, h, N, Co, pk["gt1"], pk["bt1"], 1e-5)
+        t16, t16lo = E.gn_temporal(rt, h, N, Co, pk["gt1"], pk["bt1"], 1e-5)
         # emb32 arrives as SiLU(emb): the activation of `emb_layers` is applied ONCE per network evaluation by
         # _time_embedding (32 ResBlocks x 16 x 1280 identical SiLUs otherwise), the Linear runs here
         emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
         rt.be.gemm(t16, pk["wt1"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct1"],
-                   rowbias=emb_out, rb_rows=N, rb_mod=F, res1=h, ldr1=Co, out32=h, ldc32=Co)
+                   rowbias=emb_out, rb_rows=N, rb_mod=F, res1=h, ldr1=Co, out32=h, ldc32=Co, a16_lo=t16lo)
         # out_layers: GN + SiLU + conv3x3
-        a16 = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True)
-        g = run_conv3x3(rt, a16, F, H, W, Co, pk["w2"], pk["c2"], Co).f32
-        t16 = E.gn_temporal(rt, g, N, Co, pk["gt2"], pk["bt2"], 1e-5)
+        a16, a16lo = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True, split=rt.prec.gn_res)
+        g = run_conv3x3(rt, a16, F, H, W, Co, pk["w2"], pk["c2"], Co, x16_lo=a16lo).f32
+        t16, t16lo = E.gn_temporal(rt, g, N, Co, pk["gt2"], pk["bt2"], 1e-5)
         # skip path
         if "ws" in pk:
             s = rt.empty((M, Co), torch.float32)
-            rt.be.gemm(x.need_f16(rt), pk["ws"], M=M, N=Co, K=Cin, lda=Cin, bias=pk["bs"], out32=s, ldc32=Co)
+            rt.be.gemm(x.need_f16(rt), pk["ws"], M=M, N=Co, K=Cin, lda=Cin, bias=pk["bs"], out32=s, ldc32=Co,
+                       a16_lo=x.f16_lo)
         else:
             s = x.f32
         # return skip(x) + (g + conv1d_t(SiLU(GN_t(g))))                 (:533-542)
         o16 = rt.empty((M, Co), torch.float16) if want_f16 else None
+        o16lo = rt.empty((M, Co), torch.float16) if (want_f16 and rt.prec.stream) else None
         rt.be.gemm(t16, pk["wt2"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct2"],
-                   res1=g, ldr1=Co, res2=s, ldr2=Co, out32=g, ldc32=Co, out16=o16, ldc16=Co)
-        return Act(F, H, W, Co, f32=g, f16=o16)
+                   res1=g, ldr1=Co, res2=s, ldr2=Co, out32=g, ldc32=Co, out16=o16, ldc16=Co, a16_lo=t16lo,
+                   out16_lo=o16lo)
+        return Act(F, H, W, Co, f32=g, f16=o16, f16_lo=o16lo)
 
     def forward(self, x, emb):
         from .util import act_from_nchw, runtime_for
@@ -338,6 +345,21 @@ class UNetModel3D(nn.Module, Packable):
         super().invalidate_packed()
         self.__dict__.pop("_text_proj", None)
 
+    # Operand precision policy (engine.Precision or "fast" | "precise" | "precise-all").  "precise" carries the operand
+    # classes that dominate the eps error as split fp16 pairs and meets the 1e-3 max-abs contract of the boundary
+    # (wrappers.py:37-70); "fast" is plain fp16 operands everywhere (2.3e-3 at BASELINE config 3).
+    @property
+    def precision(self):
+        return self.__dict__.get("_precision", "precise")
+
+    @precision.setter
+    def precision(self, value):
+        E.precision(value)                                   # validates
+        self.__dict__["_precision"] = value
+        cn = self._modules.get("controlnet") if hasattr(self, "_modules") else None
+        if cn is not None:
+            cn.precision = value
+
     def _project_text(self, rt: Runtime):
         """Text K/V of every cross-attention site of this network, batched (attention.TextKVProjector)."""
         from .attention import TextKVProjector
@@ -373,8 +395,8 @@ class UNetModel3D(nn.Module, Packable):
     def _head(self, rt: Runtime, h: Act) -> torch.Tensor:
         """self.out: GN + SiLU + conv3x3 -> NCHW fp32 (:1245-1253, controlmodel.py:197-202)."""
         pk = self.packed()
-        a16 = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, pk["og"], pk["ob"], 1e-5, True)
-        o = run_conv3x3(rt, a16, h.F, h.H, h.W, h.C, pk["ow"], pk["oc"], self.out_channels)
+        a16, a16lo = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, pk["og"], pk["ob"], 1e-5, True, split=rt.prec.gn_head)
+        o = run_conv3x3(rt, a16, h.F, h.H, h.W, h.C, pk["ow"], pk["oc"], self.out_channels, x16_lo=a16lo)
         out = rt.empty((h.F, self.out_channels, h.H, h.W), torch.float32)
         rt.be.tokens_to_nchw_f32(o.f32, self.out_channels, h.F, h.N, self.out_channels, out)
         return out
@@ -385,8 +407,9 @@ class UNetModel3D(nn.Module, Packable):
         cp = (C + 7) // 8 * 8
         x32 = x.detach().to(torch.float32).contiguous()
         t16 = rt.empty((F * H * W, cp), torch.float16)
-        rt.be.nchw_to_tokens_f16(x32, C, None, 0, F, H * W, cp, t16)
-        return Act(F, H, W, cp, f16=t16)
+        t16lo = rt.empty((F * H * W, cp), torch.float16) if rt.prec.stem else None
+        rt.be.nchw_to_tokens_f16(x32, C, None, 0, F, H * W, cp, t16, t16lo)
+        return Act(F, H, W, cp, f16=t16, f16_lo=t16lo)
 
     def _own_blocks(self):
         for name in ("input_blocks", "middle_block", "output_blocks"):
@@ -421,9 +444,10 @@ class UNetModel3D(nn.Module, Packable):
             ct = h.C + s.C
             cat32 = rt.empty((h.M, ct), torch.float32)
             cat16 = rt.empty((h.M, ct), torch.float16)
-            # th.cat([h, hs.pop() + control.pop()], dim=1): one pass, fp32 stream + fp16 operand
-            rt.be.concat_add(h.f32, h.C, s.f32, None if c is None else c.f32, s.C, h.M, cat32, cat16)
-            h = module._run(rt, Act(h.F, h.H, h.W, ct, f32=cat32, f16=cat16), emb32)
+            cat16lo = rt.empty((h.M, ct), torch.float16) if rt.prec.stream else None
+            # th.cat([h, hs.pop() + control.pop()], dim=1): one pass, fp32 stream + fp16 operand (of the skip 1x1 conv)
+            rt.be.concat_add(h.f32, h.C, s.f32, None if c is None else c.f32, s.C, h.M, cat32, cat16, cat16lo)
+            h = module._run(rt, Act(h.F, h.H, h.W, ct, f32=cat32, f16=cat16, f16_lo=cat16lo), emb32)
             if rt.trace is not None:
                 rt.trace[f"output_blocks.{i}"] = h.to_nchw()
         return self._head(rt, h)
@@ -435,6 +459,7 @@ class UNetModel3D(nn.Module, Packable):
         from .util import runtime_for
         with torch.no_grad():
             rt = runtime_for(x, self.num_frames)
+            rt.prec = E.precision(self.precision)
             rt.set_context(context)
             emb = self._time_embedding(rt, timesteps)
             out = self._run_unet(rt, self._stem_tokens(rt, x), emb, None)

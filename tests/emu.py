@@ -22,6 +22,26 @@ class PncError(RuntimeError):
     pass
 
 
+def _r16_default(v: torch.Tensor, site: str) -> torch.Tensor:
+    return v.half()
+
+
+# every fp16 rounding of an activation goes through this hook: r16(value_fp32, producing_entry_point).  The default is
+# the kernels' rounding; tools/exp/error_budget.py swaps it to measure what each operand class contributes.
+r16 = _r16_default
+STRICT_DTYPES = True
+LO_SCALE = 2048.0
+
+
+def _lo(v: torch.Tensor, hi: torch.Tensor) -> torch.Tensor:
+    """lo plane of a precise (split) operand: fp16((v - hi) * 2^11), exactly like the kernels"""
+    return ((v.float() - hi.float()) * LO_SCALE).half()
+
+
+def _join(hi: torch.Tensor, lo) -> torch.Tensor:
+    return hi.float() if lo is None else hi.float() + lo.float() / LO_SCALE
+
+
 def _mat(t: torch.Tensor, rows: int, cols: int, ld: int) -> torch.Tensor:
     """[rows, cols] strided view (row stride ld) of the flat storage of t."""
     return torch.as_strided(t.reshape(-1), (rows, cols), (ld, 1))
@@ -33,10 +53,13 @@ def load():
 
 def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bias=None, rowbias=None,
          rb_rows=0, rb_mod=0, res1=None, ldr1=0, res2=None, ldr2=0, out32=None, ldc32=0, out16=None,
-         ldc16=0, out16t=None, ldt=0, t_rows=0, t_gstride=0, n_split=0, act=ACT_NONE, geglu=False):
-    assert a16.dtype == torch.float16 and w16.dtype == torch.float16
+         ldc16=0, out16t=None, ldt=0, t_rows=0, t_gstride=0, n_split=0, act=ACT_NONE, geglu=False,
+         a16_lo=None, out16_lo=None):
+    assert (not STRICT_DTYPES) or (a16.dtype == torch.float16 and w16.dtype == torch.float16)
     assert K % 8 == 0
     Wm = w16.reshape(-1)[: N * K].view(N, K).float()
+    if a16_lo is not None:       # precise operand: A = hi + lo * 2^-11 (the kernel sums the two planes' products in fp32)
+        a16 = _join(a16.reshape(-1), a16_lo.reshape(-1)[: a16.numel()])
     if a_mode == A_PLAIN:
         A = _mat(a16, M, K, lda).float()
         acc = A @ Wm.t()
@@ -74,7 +97,10 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
         if out32 is not None:
             _mat(out32, M, N // 2, ldc32).copy_(v)
         if out16 is not None:
-            _mat(out16, M, N // 2, ldc16).copy_(v.half())
+            h = r16(v, 'gemm.geglu')
+            _mat(out16, M, N // 2, ldc16).copy_(h)
+            if out16_lo is not None:
+                _mat(out16_lo, M, N // 2, ldc16).copy_(_lo(v, h))
         return
     if rowbias is not None:
         idx = (torch.arange(M, device=v.device) // rb_rows) % rb_mod
@@ -89,12 +115,15 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
     if out32 is not None:
         _mat(out32, M, ns, ldc32).copy_(v[:, :ns])
     if out16 is not None:
-        _mat(out16, M, ns, ldc16).copy_(v[:, :ns].half())
+        h = r16(v[:, :ns], 'gemm.out16')
+        _mat(out16, M, ns, ldc16).copy_(h)
+        if out16_lo is not None:
+            _mat(out16_lo, M, ns, ldc16).copy_(_lo(v[:, :ns], h))
     if out16t is not None:
         G = M // t_rows
         assert G * t_rows == M
         dst = torch.as_strided(out16t.reshape(-1), (G, N - ns, t_rows), (t_gstride, ldt, 1))
-        dst.copy_(v[:, ns:].half().view(G, t_rows, N - ns).permute(0, 2, 1))
+        dst.copy_(r16(v[:, ns:], 'gemm.out16t').view(G, t_rows, N - ns).permute(0, 2, 1))
 
 
 def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H, W, views, kvH, kvW,
@@ -123,12 +152,12 @@ def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H
         pr = torch.softmax(s, dim=-1)
         ov = torch.einsum("ghqk,ghkd->ghqd", pr, vc)   # [g, heads, q, 64]
         ov = ov.permute(0, 2, 1, 3).reshape(groups, H, Wv, Cc)
-        O[:, :, v * Wv:(v + 1) * Wv] = ov.half()
+        O[:, :, v * Wv:(v + 1) * Wv] = r16(ov, 'attn_views')
 
 
 def softmax_rows(s32, lds, M, N, scale, p16, ldp):
     pr = torch.softmax(_mat(s32, M, N, lds).float() * scale, dim=-1)
-    _mat(p16, M, N, ldp).copy_(pr.half())
+    _mat(p16, M, N, ldp).copy_(r16(pr, 'softmax_rows'))
 
 
 def attn_temporal(q, ldq, k, ldk, v, ldv, o, ldo, *, B, T, Npix, heads, scale):
@@ -140,7 +169,7 @@ def attn_temporal(q, ldq, k, ldk, v, ldv, o, ldo, *, B, T, Npix, heads, scale):
     s = torch.einsum("bphtd,bphsd->bphts", g(q, ldq), g(k, ldk)) * scale
     pr = torch.softmax(s, dim=-1)
     ov = torch.einsum("bphts,bphsd->bphtd", pr, g(v, ldv))
-    _mat(o, M, Cc, ldo).copy_(ov.permute(0, 3, 1, 2, 4).reshape(M, Cc).half())
+    _mat(o, M, Cc, ldo).copy_(r16(ov.permute(0, 3, 1, 2, 4).reshape(M, Cc), 'attn_temporal'))
 
 
 def groupnorm_stats(x32, ldx, F, Npix, Cch, ppc, partial):
@@ -156,7 +185,7 @@ def groupnorm_stats(x32, ldx, F, Npix, Cch, ppc, partial):
         P[:, c, :, 2] = ((xs - mean[..., None]) ** 2).sum(-1)
 
 
-def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy):
+def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy, y16_lo=None):
     nchunk = (Npix + ppc - 1) // ppc
     P = partial.reshape(-1)[: F * nchunk * 32 * 3].view(F, nchunk, 32, 3).double()
     n = P[..., 0].sum(1)
@@ -168,20 +197,29 @@ def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu
     y = y.reshape(F * Npix, Cch) * gamma.reshape(-1)[:Cch] + beta.reshape(-1)[:Cch]
     if silu:
         y = TF.silu(y)
-    _mat(y16, F * Npix, Cch, ldy).copy_(y.half())
+    h = r16(y, 'groupnorm_apply')
+    _mat(y16, F * Npix, Cch, ldy).copy_(h)
+    if y16_lo is not None:
+        _mat(y16_lo, F * Npix, Cch, ldy).copy_(_lo(y, h))
 
 
-def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16):
+def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16, y16_lo=None):
     X = x32.reshape(-1)[: B * T * Npix * Cch].view(B, T, Npix, Cch).permute(0, 2, 3, 1).reshape(B * Npix, Cch, T)
     y = TF.silu(TF.group_norm(X, 32, gamma.reshape(-1)[:Cch], beta.reshape(-1)[:Cch], eps))
     y = y.view(B, Npix, Cch, T).permute(0, 3, 1, 2).reshape(-1)
-    y16.reshape(-1)[: y.numel()].copy_(y.half())
+    h = r16(y, 'groupnorm_temporal')
+    y16.reshape(-1)[: y.numel()].copy_(h)
+    if y16_lo is not None:
+        y16_lo.reshape(-1)[: y.numel()].copy_(_lo(y, h))
 
 
-def layernorm(x32, ldx, M, Cch, gamma, beta, eps, y16, ldy):
+def layernorm(x32, ldx, M, Cch, gamma, beta, eps, y16, ldy, y16_lo=None):
     X = _mat(x32, M, Cch, ldx)
     y = TF.layer_norm(X, (Cch,), gamma.reshape(-1)[:Cch], beta.reshape(-1)[:Cch], eps)
-    _mat(y16, M, Cch, ldy).copy_(y.half())
+    h = r16(y, 'layernorm')
+    _mat(y16, M, Cch, ldy).copy_(h)
+    if y16_lo is not None:
+        _mat(y16_lo, M, Cch, ldy).copy_(_lo(y, h))
 
 
 def linear_smallm(a32, lda, w16, bias, out32, ldo, M, N, K, silu_in=False, silu_out=False):
@@ -202,12 +240,18 @@ def timestep_embedding(t_i64, F, dim, freqs, out32):
     out32.reshape(-1)[: F * dim].view(F, dim)[:, : 2 * (dim // 2)].copy_(emb)
 
 
-def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16):
-    o = out16.reshape(-1)[: F * Npix * Cpad].view(F, Npix, Cpad)
-    o.zero_()
-    o[:, :, :C1] = a32.reshape(F, C1, Npix).permute(0, 2, 1).half()
+def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16, out16_lo=None, a_scale=None):
+    v = torch.zeros((F, Npix, Cpad), dtype=torch.float32, device=a32.device)
+    a = a32.reshape(F, C1, Npix).float()
+    if a_scale is not None:
+        a = a * a_scale.reshape(F, 1, 1).float()
+    v[:, :, :C1] = a.permute(0, 2, 1)
     if C2:
-        o[:, :, C1:C1 + C2] = b32.reshape(F, C2, Npix).permute(0, 2, 1).half()
+        v[:, :, C1:C1 + C2] = b32.reshape(F, C2, Npix).permute(0, 2, 1)
+    h = r16(v, 'nchw_to_tokens')
+    out16.reshape(-1)[: F * Npix * Cpad].view(F, Npix, Cpad).copy_(h)
+    if out16_lo is not None:
+        out16_lo.reshape(-1)[: F * Npix * Cpad].view(F, Npix, Cpad).copy_(_lo(v, h))
 
 
 def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):
@@ -215,7 +259,7 @@ def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):
     out32.reshape(-1)[: F * Cch * Npix].view(F, Cch, Npix).copy_(X.permute(0, 2, 1))
 
 
-def concat_add(a32, C1, s32, c32, C2, M, out32, out16):
+def concat_add(a32, C1, s32, c32, C2, M, out32, out16, out16_lo=None):
     a = a32.reshape(-1)[: M * C1].view(M, C1)
     s = s32.reshape(-1)[: M * C2].view(M, C2)
     if c32 is not None:
@@ -224,18 +268,24 @@ def concat_add(a32, C1, s32, c32, C2, M, out32, out16):
     if out32 is not None:
         out32.reshape(-1)[: y.numel()].copy_(y.reshape(-1))
     if out16 is not None:
-        out16.reshape(-1)[: y.numel()].copy_(y.reshape(-1).half())
+        h = r16(y.reshape(-1), 'concat_add')
+        out16.reshape(-1)[: y.numel()].copy_(h)
+        if out16_lo is not None:
+            out16_lo.reshape(-1)[: y.numel()].copy_(_lo(y.reshape(-1), h))
 
 
-def add_f32(x32, a32, n, y32, y16):
+def add_f32(x32, a32, n, y32, y16, y16_lo=None):
     y = x32.reshape(-1)[:n]
     if a32 is not None:
         y = y + a32.reshape(-1)[:n]
     if y16 is not None:
-        y16.reshape(-1)[:n].copy_(y.half())
+        h = r16(y, 'add_f32')
+        y16.reshape(-1)[:n].copy_(h)
+        if y16_lo is not None:
+            y16_lo.reshape(-1)[:n].copy_(_lo(y, h))
     if y32 is not None and (a32 is not None or y32.data_ptr() != x32.data_ptr()):
         y32.reshape(-1)[:n].copy_(y)
 
 
-def cast_f16(x32, n, y16):
-    add_f32(x32, None, n, None, y16)
+def cast_f16(x32, n, y16, y16_lo=None):
+    add_f32(x32, None, n, None, y16, y16_lo)

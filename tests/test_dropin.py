@@ -17,17 +17,39 @@ def test_cabi_library_loads_and_exports_header_symbols():
     for s in syms:
         assert getattr(lib, s) is not None
     assert lib.pnc_version().decode().startswith("panacea_hip")
-    # struct layouts of the two parameter blocks (must match include/panacea_hip.h)
-    assert ctypes.sizeof(hip.GemmParams) == 224 and hip.GemmParams.t_gstride.offset == 176
-    assert hip.GemmParams.ws.offset == 200 and hip.GemmParams.ws_floats.offset == 208
-    assert hip.GemmParams.conv_pad_br.offset == 216
-    assert ctypes.sizeof(hip.AttnParams) == 216 and hip.AttnParams.scale.offset == 208
+    assert lib.pnc_abi_version() == hip.ABI_VERSION
+
+
+def test_ctypes_structs_match_the_header_as_gcc_lays_it_out(tmp_path):
+    """Every field offset and the size of both parameter blocks, as a C compiler sees include/panacea_hip.h, against
+    the ctypes mirrors (a reference-side binding is written against the header, not against hip.py)."""
+    import subprocess
+    fields = {"PncGemmParams": [f[0] for f in hip.GemmParams._fields_], "PncAttnParams": [f[0] for f in hip.AttnParams._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hip.HEADER}"', 'int main(void) {']
+    for st, fs in fields.items():
+        src.append(f'printf("{st} %zu\\n", sizeof({st}));')
+        src += [f'printf("{st}.{f} %zu\\n", offsetof({st}, {f}));' for f in fs]
+    src.append('printf("abi %d\\n", PNC_ABI_VERSION); return 0; }')
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", str(c), "-o", str(exe)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for st, cls in (("PncGemmParams", hip.GemmParams), ("PncAttnParams", hip.AttnParams)):
+        assert int(got[st]) == ctypes.sizeof(cls), st
+        for f in fields[st]:
+            assert int(got[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
+    assert int(got["abi"]) == hip.ABI_VERSION
+    assert ctypes.sizeof(hip.GemmParams) == 240
 
 
 def test_argument_validation_without_gpu():
     """Entry points validate before launching: bad arguments return PNC_E* codes even with no device."""
     lib = hip.load()
     p = hip.GemmParams()
+    assert lib.pnc_gemm_f16(ctypes.byref(p), None) == -3                  # PNC_EABI: struct_bytes not set (short / old struct)
+    assert lib.pnc_gemm_workspace_floats(ctypes.byref(p)) == 0
+    p.struct_bytes = ctypes.sizeof(hip.GemmParams)
     assert lib.pnc_gemm_f16(ctypes.byref(p), None) == -1                  # PNC_EINVAL: null operands
     # split-K is offered only to small-M / long-K problems (the 4x48 level), never to GEGLU or V^T outputs
     p.M, p.N, p.K = 3072, 1280, 11520
@@ -37,7 +59,7 @@ def test_argument_validation_without_gpu():
     p.geglu, p.M = 0, 12288
     assert lib.pnc_gemm_workspace_floats(ctypes.byref(p)) == 0
     assert lib.pnc_attn_temporal_f16(None, 0, None, 0, None, 0, None, 0, 1, 9, 1, 1, 0.125, None) == -1
-    assert lib.pnc_layernorm(None, 0, 0, 0, None, None, 1e-5, None, 0, None) == -1
+    assert lib.pnc_layernorm(None, 0, 0, 0, None, None, 1e-5, None, 0, None, None) == -1
 
 
 def test_product_refuses_to_run_without_gpu_tensors():

@@ -13,21 +13,24 @@ import emu
 from helpers import cond, err_stats, golden, manifest, product_network, step_inputs
 from panacea_amd import build_network, configs, engine as E
 
-# |eps| max ~2.7, rms 0.59.  plain1 runs T=1: its temporal GroupNorm normalises C/32 x T = 2 values per
-# group, which amplifies operand rounding, hence the wider band for that degenerate configuration.
-TOL = {"tiny": (4e-3, 8e-4), "plain1": (1.2e-2, 2e-3)}
+# |eps| max ~2.7, rms 0.59.  (network, operand precision) -> (max-abs, mean-abs); the default "precise" policy meets the
+# 1e-3 of BASELINE.json's north_star.  plain1 runs T=1 at 64 channels: its temporal GroupNorm normalises C/32 x T = 2
+# values per group, which amplifies the rounding of the conv output feeding it, hence "precise-all" and a wider band.
+TOL = {("tiny", "precise"): (1e-3, 2e-4), ("tiny", "fast"): (3e-3, 5e-4),
+       ("plain1", "precise-all"): (1.4e-3, 2.2e-4), ("plain1", "fast"): (8e-3, 1.2e-3)}
 
 
-@pytest.mark.parametrize("name", ["tiny", "plain1"])
-def test_engine_matches_reference_golden(name):
+@pytest.mark.parametrize("name,prec", list(TOL))
+def test_engine_matches_reference_golden(name, prec):
     w, _, kw = product_network(name)
+    w.diffusion_model.precision = prec
     inp = step_inputs(name, kw)
     gold = golden(name)
     trace = {}
     with E.use_backend(emu):
         eps = w(inp["x"], inp["t"], cond(inp), trace=trace)
     st = err_stats(eps, gold["eps"])
-    assert st["max_abs"] <= TOL[name][0] and st["mean_abs"] <= TOL[name][1], st
+    assert st["max_abs"] <= TOL[(name, prec)][0] and st["mean_abs"] <= TOL[(name, prec)][1], st
     assert eps.dtype == torch.float32 and eps.shape == inp["x"].shape
     checked = 0
     for k in gold.files:

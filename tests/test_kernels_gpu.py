@@ -162,7 +162,7 @@ def test_gemm_conv1d_temporal(B, T, Npix, C):
 
 @pytest.mark.parametrize("M,N,K,geglu", [(1000, 320, 640, False), (49152, 640, 640, False), (700, 1280, 320, True),
                                          (12288, 1280, 192, False)])
-def test_gemm_tail_row_split_is_bit_identical(monkeypatch, M, N, K, geglu):
+def test_gemm_tail_row_split_is_bit_identical(M, N, K, geglu):
     # the partial last round of tiles is run as half / quarter tiles (BM/2, BM/4 rows per workgroup): same bits
     a = rnd(M, K, dtype=torch.float16)
     w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
@@ -179,8 +179,11 @@ def test_gemm_tail_row_split_is_bit_identical(monkeypatch, M, N, K, geglu):
         torch.cuda.synchronize()
         return o32, o16
     s32, s16 = run()
-    monkeypatch.setenv("PNC_GEMM_NOTAIL", "1")
-    f32, f16 = run()
+    prev = hip.set_option(hip.OPT_GEMM_TAIL_SPLIT, 0)
+    try:
+        f32, f16 = run()
+    finally:
+        hip.set_option(hip.OPT_GEMM_TAIL_SPLIT, prev)
     assert torch.equal(s16, f16) and (geglu or torch.equal(s32, f32))
     e16 = torch.zeros(M, No, device=DEV, dtype=torch.float16)
     kw = dict(a16=a, w16=w, M=M, N=N, K=K, lda=K, bias=bias, out16=e16, ldc16=No, geglu=geglu)
@@ -191,11 +194,198 @@ def test_gemm_tail_row_split_is_bit_identical(monkeypatch, M, N, K, geglu):
     check("tail split vs emu", s16, e16, 6e-3)
 
 
+
+# ---------------------------------------------------------- specialised epilogue variants x tile geometries
+TILES = {"128x128": 1, "256x128": 2, "256x320": 3, "256x256": 4}
+
+
+def _epi_case(name, M, N, K, seed=0):
+    """kwargs factory of one fast-epilogue variant (16-byte aligned everything: the vector contract)"""
+    a = rnd(M, K, dtype=torch.float16, seed=seed + 1)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=seed + 2)
+    bias, res, res2, rowb = rnd(N, seed=seed + 3), rnd(M, N, seed=seed + 4), rnd(M, N, seed=seed + 5), rnd(4, N, seed=seed + 6)
+    base = dict(a16=a, w16=w, M=M, N=N, K=K, lda=K, bias=bias)
+
+    def outs():
+        return dict(o32=res.clone(), o16=torch.zeros(M, N, device=DEV, dtype=torch.float16),
+                    o16lo=torch.zeros(M, N, device=DEV, dtype=torch.float16))
+    kws = {
+        "o16": lambda o: dict(base, out16=o["o16"], ldc16=N),
+        "o16+lo": lambda o: dict(base, out16=o["o16"], ldc16=N, out16_lo=o["o16lo"]),
+        "o32": lambda o: dict(base, out32=o["o32"], ldc32=N),
+        "o32+o16": lambda o: dict(base, out32=o["o32"], ldc32=N, out16=o["o16"], ldc16=N),
+        "r1+o32": lambda o: dict(base, res1=o["o32"], ldr1=N, out32=o["o32"], ldc32=N),
+        "r1+o32+o16+lo": lambda o: dict(base, res1=o["o32"], ldr1=N, out32=o["o32"], ldc32=N, out16=o["o16"], ldc16=N,
+                                        out16_lo=o["o16lo"]),
+        "r1+o16": lambda o: dict(base, res1=res2, ldr1=N, out16=o["o16"], ldc16=N),
+        "rb+o32": lambda o: dict(base, rowbias=rowb, rb_rows=50, rb_mod=4, out32=o["o32"], ldc32=N),
+        "r2only+o32": lambda o: dict(base, res2=res2, ldr2=N, out32=o["o32"], ldc32=N),
+    }
+    return outs, kws[name]
+
+
+@pytest.mark.parametrize("tile", list(TILES))
+@pytest.mark.parametrize("name", ["o16", "o16+lo", "o32", "o32+o16", "r1+o32", "r1+o32+o16+lo", "r1+o16", "rb+o32",
+                                  "r2only+o32"])
+def test_gemm_fast_epilogue_variants(name, tile):
+    # N = 1280 admits every geometry (1280 = 4 x 320 = 5 x 256); ragged M exercises the row predicate
+    M, N, K = 1000, 1280, 128
+    outs, kw = _epi_case(name, M, N, K)
+    prev = hip.set_option(hip.OPT_GEMM_TILE, TILES[tile])
+    try:
+        h, e = _run_both("gemm", outs, kw)
+    finally:
+        hip.set_option(hip.OPT_GEMM_TILE, prev)
+    check("out32", h["o32"], e["o32"], 2e-3)
+    check("out16", h["o16"], e["o16"], 4e-3)
+    # the lo plane carries (v - hi) * 2^11: compare the RECONSTRUCTED value with the fp32 output where both exist
+    if "lo" in name:
+        rec = h["o16"].float() + h["o16lo"].float() / 2048.0
+        ref = e["o16"].float() + e["o16lo"].float() / 2048.0
+        check("hi+lo", rec, ref, 2e-3, 2e-3)
+        if "o32" in name:
+            assert (rec - h["o32"]).abs().max().item() <= 2.0 ** -20 * max(1.0, h["o32"].abs().max().item())
+
+
+@pytest.mark.parametrize("tile", list(TILES))
+@pytest.mark.parametrize("mode", ["conv1d+rb", "conv1d+r2", "conv1d+r2+o16", "conv3x3+o32", "conv3x3+silu16"])
+def test_gemm_fast_epilogue_variants_conv(mode, tile):
+    prev = hip.set_option(hip.OPT_GEMM_TILE, TILES[tile])
+    try:
+        if mode.startswith("conv1d"):
+            B, T, Npix, C = 1, 4, 150, 1280
+            M, N, K = B * T * Npix, C, 3 * C
+            x = rnd(M, C, dtype=torch.float16, seed=1)
+            w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=2)
+            bias, emb, res, res2 = rnd(N, seed=3), rnd(B * T, N, seed=4), rnd(M, N, seed=5), rnd(M, N, seed=6)
+            base = dict(a16=x, w16=w, M=M, N=N, K=K, a_mode=hip.A_CONV1D_T, tconv=dict(C=C, T=T, Npix=Npix), bias=bias)
+
+            def outs():
+                return dict(o32=res.clone(), o16=torch.zeros(M, N, device=DEV, dtype=torch.float16))
+            if mode == "conv1d+rb":
+                kw = lambda o: dict(base, rowbias=emb, rb_rows=Npix, rb_mod=B * T, res1=o["o32"], ldr1=N, out32=o["o32"], ldc32=N)
+            elif mode == "conv1d+r2":
+                kw = lambda o: dict(base, res1=o["o32"], ldr1=N, res2=res2, ldr2=N, out32=o["o32"], ldc32=N)
+            else:
+                kw = lambda o: dict(base, res1=o["o32"], ldr1=N, res2=res2, ldr2=N, out32=o["o32"], ldc32=N,
+                                    out16=o["o16"], ldc16=N)
+        else:
+            F, H, W, Cin, N = 2, 10, 24, 64, 1280
+            M, K = F * H * W, 9 * Cin
+            x = rnd(F, H, W, Cin, dtype=torch.float16, seed=1)
+            w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=2)
+            conv = dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0)
+            base = dict(a16=x, w16=w, M=M, N=N, K=K, a_mode=hip.A_CONV3X3, conv=conv, bias=rnd(N, seed=3))
+
+            def outs():
+                return dict(o32=torch.zeros(M, N, device=DEV), o16=torch.zeros(M, N, device=DEV, dtype=torch.float16))
+            if mode == "conv3x3+o32":
+                kw = lambda o: dict(base, out32=o["o32"], ldc32=N)
+            else:
+                kw = lambda o: dict(base, act=hip.ACT_SILU, out16=o["o16"], ldc16=N)
+        h, e = _run_both("gemm", outs, kw)
+    finally:
+        hip.set_option(hip.OPT_GEMM_TILE, prev)
+    check("out32", h["o32"], e["o32"], 2e-3)
+    check("out16", h["o16"], e["o16"], 4e-3)
+
+
+def _split(v):
+    hi = v.half()
+    return hi, ((v - hi.float()) * 2048.0).half()
+
+
+@pytest.mark.parametrize("tile", list(TILES))
+@pytest.mark.parametrize("M,N,K", [(1000, 1280, 320), (700, 1280, 1344)])
+def test_gemm_precise_operand_plain(M, N, K, tile):
+    """A = hi + lo * 2^-11: the result must track the fp64 product of the UNSPLIT fp32 activations ~2^-11 closer than
+    the plain fp16 operand does (what the precise mode is for), on every tile geometry."""
+    a32 = rnd(M, K, seed=7) * 3.0
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=8)
+    hi, lo = _split(a32)
+    ref = (a32.double() @ w.double().t()).float()
+    o_p, o_h = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+    prev = hip.set_option(hip.OPT_GEMM_TILE, TILES[tile])
+    try:
+        hip.gemm(hi, w, M=M, N=N, K=K, lda=K, out32=o_p, ldc32=N, a16_lo=lo)
+        hip.gemm(hi, w, M=M, N=N, K=K, lda=K, out32=o_h, ldc32=N)
+    finally:
+        hip.set_option(hip.OPT_GEMM_TILE, prev)
+    torch.cuda.synchronize()
+    err_p, err_h = (o_p - ref).abs().max().item(), (o_h - ref).abs().max().item()
+    print(f"precise {err_p:.3e}  fp16 {err_h:.3e}")
+    assert err_h > 1e-4 and err_p < 2e-5 and err_p < err_h / 50
+    e_p = torch.zeros(M, N, device=DEV)
+    emu.gemm(hi, w, M=M, N=N, K=K, lda=K, out32=e_p, ldc32=N, a16_lo=lo)
+    check("precise vs emu", o_p, e_p, 2e-5, 1e-5)
+
+
+def test_gemm_precise_operand_conv_and_splitk():
+    # conv3x3 (both K orders), conv1d and the split-K path with a lo plane
+    for Cin in (24, 64):
+        F, H, W, N = 2, 9, 12, 320
+        M, K = F * H * W, 9 * Cin
+        x32 = rnd(F, H, W, Cin, seed=3) * 2.0
+        hi, lo = _split(x32)
+        w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=4)
+        conv = dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0)
+        h, e = _run_both("gemm", lambda: dict(o=torch.zeros(M, N, device=DEV)), lambda o: dict(
+            a16=hi, w16=w, M=M, N=N, K=K, a_mode=hip.A_CONV3X3, conv=conv, out32=o["o"], ldc32=N, a16_lo=lo))
+        check("conv3x3 precise", h["o"], e["o"], 2e-5, 1e-5)
+    B, T, Npix, C = 1, 8, 40, 1280                # K = 3840: split-K regime
+    M, N, K = B * T * Npix, C, 3 * C
+    assert _splits(M=M, N=N, K=K, a_mode=hip.A_CONV1D_T) >= 2
+    x32 = rnd(M, C, seed=5)
+    hi, lo = _split(x32)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=6)
+    res = rnd(M, N, seed=7)
+    h, e = _run_both("gemm", lambda: dict(o=res.clone()), lambda o: dict(
+        a16=hi, w16=w, M=M, N=N, K=K, a_mode=hip.A_CONV1D_T, tconv=dict(C=C, T=T, Npix=Npix), bias=rnd(N, seed=8),
+        res1=o["o"], ldr1=N, out32=o["o"], ldc32=N, a16_lo=lo))
+    check("conv1d_t split-K precise", h["o"], e["o"], 3e-5, 1e-5)
+
+
+def test_gemm_generic_epilogue_ragged_everything():
+    # N % 8 != 0, odd leading dimensions, three added streams + V^T with ragged groups: the scalar fallback
+    M, N, K = 333, 100, 72
+    a, w = rnd(M, K, dtype=torch.float16), rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    bias, rowb, r1, r2 = rnd(N), rnd(3, N), rnd(M, N + 1), rnd(M, N + 3)
+
+    def outs():
+        return dict(o32=torch.zeros(M, N + 5, device=DEV), o16=torch.zeros(M, N + 2, device=DEV, dtype=torch.float16),
+                    lo=torch.zeros(M, N + 2, device=DEV, dtype=torch.float16))
+    h, e = _run_both("gemm", outs, lambda o: dict(
+        a16=a, w16=w, M=M, N=N, K=K, lda=K, bias=bias, rowbias=rowb, rb_rows=40, rb_mod=3, res1=r1, ldr1=N + 1,
+        res2=r2, ldr2=N + 3, act=hip.ACT_SILU, out32=o["o32"], ldc32=N + 5, out16=o["o16"], ldc16=N + 2, out16_lo=o["lo"]))
+    check("generic out32", h["o32"], e["o32"], 2e-3)
+    check("generic out16", h["o16"], e["o16"], 6e-3)
+    G, t_rows, C = 3, 75, 64                         # t_rows % 8 != 0 -> generic V^T
+    M, N, K = G * t_rows, 3 * C, C
+    a, w = rnd(M, K, dtype=torch.float16), rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+
+    def outs2():
+        return dict(qk=torch.zeros(M, 2 * C, device=DEV, dtype=torch.float16),
+                    vt=torch.zeros(G, C, t_rows + 3, device=DEV, dtype=torch.float16))
+    h, e = _run_both("gemm", outs2, lambda o: dict(
+        a16=a, w16=w, M=M, N=N, K=K, lda=K, out16=o["qk"], ldc16=2 * C, out16t=o["vt"], ldt=t_rows + 3,
+        t_rows=t_rows, t_gstride=C * (t_rows + 3), n_split=2 * C))
+    check("generic qk", h["qk"], e["qk"], 4e-3)
+    check("generic vt", h["vt"], e["vt"], 4e-3)
+
+
+def test_gemm_rejects_a_struct_of_another_abi():
+    import ctypes
+    p = hip.GemmParams()
+    assert hip.load().pnc_gemm_f16(ctypes.byref(p), None) == -3           # PNC_EABI
+    p.struct_bytes = 224                                                   # round-1 layout
+    assert hip.load().pnc_gemm_f16(ctypes.byref(p), None) == -3
+
 # ---------------------------------------------------------------------------------------- split K
 def _splits(**kw):
     """K slices the library would run for this problem (0 workspace -> 1 slice)."""
     import ctypes
     p = hip.GemmParams()
+    p.struct_bytes = ctypes.sizeof(hip.GemmParams)
     for k, v in kw.items():
         setattr(p, k, v)
     return hip.load().pnc_gemm_workspace_floats(ctypes.byref(p)) // (kw["M"] * kw["N"])
@@ -281,10 +471,13 @@ def test_attn_views_self(G, H, W, heads, segs):
 
 @pytest.mark.parametrize("variant", ["41", "81", "42", "82"])
 @pytest.mark.parametrize("G,H,W,heads,segs", [(1, 24, 150, 1, CROSS), (2, 8, 96, 2, CROSS), (1, 3, 36, 1, INTRA)])
-def test_attn_views_every_variant(monkeypatch, variant, G, H, W, heads, segs):
+def test_attn_views_every_variant(variant, G, H, W, heads, segs):
     # (waves, query blocks per wave) variants of the kernel, forced regardless of the size heuristic
-    monkeypatch.setenv("PNC_ATTN_VARIANT", variant)
-    test_attn_views_self(G, H, W, heads, segs)
+    prev = hip.set_option(hip.OPT_ATTN_VARIANT, int(variant))
+    try:
+        test_attn_views_self(G, H, W, heads, segs)
+    finally:
+        hip.set_option(hip.OPT_ATTN_VARIANT, prev)
 
 
 def test_attn_views_sharp_softmax():
@@ -460,3 +653,63 @@ def test_rejects_cpu_tensors_and_bad_shapes():
     a = rnd(64, 60, dtype=torch.float16)
     with pytest.raises(hip.PncError):     # K not a multiple of 8
         hip.gemm(a, a, M=64, N=64, K=60, lda=60, out32=torch.zeros(64, 64, device=DEV), ldc32=64)
+
+
+def test_lo_planes_of_norms_and_helpers():
+    """every producer of a precise operand: hi is bit-identical to the plain fp16 output, hi + lo * 2^-11 reproduces the
+    fp32 value to ~2^-22 relative"""
+    def rec(hi, lo):
+        return hi.float() + lo.float() / 2048.0
+    F, Npix, C, ppc = 2, 300, 320, 128
+    x = rnd(F * Npix, C) * 1.7 + 0.9
+    gamma, beta = rnd(C) * 0.5 + 1, rnd(C) * 0.3
+    nchunk = (Npix + ppc - 1) // ppc
+    part = torch.zeros(F * nchunk * 32 * 3, device=DEV)
+    y0, y1, lo = (torch.zeros(F * Npix, C, device=DEV, dtype=torch.float16) for _ in range(3))
+    hip.groupnorm_stats(x, C, F, Npix, C, ppc, part)
+    hip.groupnorm_apply(x, C, F, Npix, C, ppc, part, gamma, beta, 1e-5, 1, y0, C)
+    hip.groupnorm_apply(x, C, F, Npix, C, ppc, part, gamma, beta, 1e-5, 1, y1, C, lo)
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(x.view(F, Npix, C).permute(0, 2, 1).double(), 32,
+                                                                  gamma.double(), beta.double(), 1e-5)).permute(0, 2, 1).reshape(-1, C)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    check("gn hi+lo", rec(y1, lo), ref.float(), 2e-5, 2e-5)
+    B, T = 1, 2
+    xt = rnd(B * T * Npix, C) * 1.3 - 0.4
+    t0, t1, tlo = (torch.zeros(B * T * Npix, C, device=DEV, dtype=torch.float16) for _ in range(3))
+    e1, elo = torch.zeros_like(t0), torch.zeros_like(t0)
+    hip.groupnorm_temporal_silu(xt, B, T, Npix, C, gamma, beta, 1e-5, t0)
+    hip.groupnorm_temporal_silu(xt, B, T, Npix, C, gamma, beta, 1e-5, t1, tlo)
+    emu.groupnorm_temporal_silu(xt, B, T, Npix, C, gamma, beta, 1e-5, e1, elo)
+    torch.cuda.synchronize()
+    assert torch.equal(t0, t1)
+    check("gnt hi+lo", rec(t1, tlo), rec(e1, elo), 2e-5, 2e-5)
+    M = 513
+    xl = rnd(M, C) * 2.1 + 0.5
+    l0, l1, llo = (torch.zeros(M, C, device=DEV, dtype=torch.float16) for _ in range(3))
+    hip.layernorm(xl, C, M, C, gamma, beta, 1e-5, l0, C)
+    hip.layernorm(xl, C, M, C, gamma, beta, 1e-5, l1, C, llo)
+    torch.cuda.synchronize()
+    assert torch.equal(l0, l1)
+    check("ln hi+lo", rec(l1, llo), torch.nn.functional.layer_norm(xl.double(), (C,), gamma.double(), beta.double(), 1e-5).float(),
+          2e-5, 2e-5)
+    # layout / elementwise helpers
+    Fh, C1, C2, H, W, Cpad = 2, 4, 4, 8, 12, 8
+    a, b, sc = rnd(Fh, C1, H, W) * 7, rnd(Fh, C2, H, W), rnd(Fh).abs() + 0.5
+    oh, ol = (torch.zeros(Fh * H * W, Cpad, device=DEV, dtype=torch.float16) for _ in range(2))
+    hip.nchw_to_tokens_f16(a, C1, b, C2, Fh, H * W, Cpad, oh, ol, a_scale=sc)
+    torch.cuda.synchronize()
+    full = torch.cat([a * sc.view(Fh, 1, 1, 1), b], 1).permute(0, 2, 3, 1).reshape(Fh * H * W, Cpad)
+    assert torch.equal(oh, full.half())
+    assert (rec(oh, ol) - full).abs().max().item() <= 2.0 ** -21 * full.abs().max().item()
+    Mh, Ca, Cb = 300, 128, 64
+    aa, ss, cc = rnd(Mh, Ca) * 5, rnd(Mh, Cb), rnd(Mh, Cb)
+    o16, o16lo = (torch.zeros(Mh, Ca + Cb, device=DEV, dtype=torch.float16) for _ in range(2))
+    hip.concat_add(aa, Ca, ss, cc, Cb, Mh, None, o16, o16lo)
+    torch.cuda.synchronize()
+    cat = torch.cat([aa, ss + cc], 1)
+    assert torch.equal(o16, cat.half()) and (rec(o16, o16lo) - cat).abs().max().item() <= 2.0 ** -21 * cat.abs().max().item()
+    y16, ylo = (torch.zeros(Mh, Ca, device=DEV, dtype=torch.float16) for _ in range(2))
+    hip.cast_f16(aa, Mh * Ca, y16, ylo)
+    torch.cuda.synchronize()
+    assert torch.equal(y16, aa.half()) and (rec(y16, ylo) - aa).abs().max().item() <= 2.0 ** -21 * aa.abs().max().item()

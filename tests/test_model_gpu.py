@@ -8,8 +8,10 @@
     halves are independent, a frame permutation inside a sample permutes the output (temporal
     attention/conv are the only frame couplings and the text context is per sample), determinism.
 
-Tolerances are the fp16-operand tolerances of the design (fp32 residual stream, fp16 MFMA operands,
-fp32 accumulation) against the fp32 oracle on identical fp16-representable weights: see DESIGN.md §6.
+Tolerances, eps max-abs against the fp32 reference / oracle on identical fp16-representable weights:
+  * precision "precise" (the default of the product: split fp16 operands where the error budget needs them):
+    **1e-3**, the tolerance BASELINE.json's north_star states, on every 8-/4-/2-frame configuration;
+  * precision "fast" (plain fp16 operands): pinned ~1.3x above the measured values so that a regression trips.
 """
 import numpy as np
 import pytest
@@ -21,7 +23,13 @@ from panacea_amd import configs, hip
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-TOL = {"tiny": (4e-3, 8e-4), "plain1": (1.2e-2, 2e-3)}
+NORTH_STAR = 1e-3        # eps max-abs error stated by BASELINE.json north_star
+CONFIG2_TOL = (NORTH_STAR, 2e-4)
+# (max-abs, mean-abs) per (network, precision).  measured r2: tiny 7.7e-4 / 1.3e-4 precise, 1.9e-3 / 3.5e-4 fast;
+# plain1 (T = 1, 64 channels: the temporal GroupNorm normalises 2 values per group, which amplifies the rounding of the
+# conv3x3 output feeding it) 1.0e-3 / 1.6e-4 with every class split, 5.7e-3 / 8.4e-4 fast
+TOL = {("tiny", "precise"): (NORTH_STAR, 2e-4), ("tiny", "fast"): (3e-3, 5e-4),
+       ("plain1", "precise-all"): (1.4e-3, 2.2e-4), ("plain1", "fast"): (8e-3, 1.2e-3)}
 
 
 def test_library_is_loaded_and_native():
@@ -31,18 +39,19 @@ def test_library_is_loaded_and_native():
     assert "libpanacea_hip.so" in maps
 
 
-@pytest.mark.parametrize("name", ["tiny", "plain1"])
-def test_hip_path_matches_reference_golden(name):
+@pytest.mark.parametrize("name,prec", list(TOL))
+def test_hip_path_matches_reference_golden(name, prec):
     w, _, kw = product_network(name, DEV)
+    w.diffusion_model.precision = prec
     inp = step_inputs(name, kw, DEV)
     gold = golden(name)
     trace = {}
     eps = w(inp["x"], inp["t"], cond(inp), trace=trace)
     torch.cuda.synchronize()
     st = err_stats(eps, gold["eps"])
-    print(name, st)
+    print(name, prec, st)
     assert eps.is_cuda and eps.dtype == torch.float32
-    assert st["max_abs"] <= TOL[name][0] and st["mean_abs"] <= TOL[name][1], st
+    assert st["max_abs"] <= TOL[(name, prec)][0] and st["mean_abs"] <= TOL[(name, prec)][1], st
     for k in gold.files:
         key = k[6:] if k.startswith("block.") else k
         if key in trace and k != "eps":
@@ -62,15 +71,18 @@ def test_hip_path_other_timesteps_and_frames_vs_oracle():
     eps = w(g["x"], g["t"], cond(g))
     st = err_stats(eps, ref)
     print(st)
-    assert st["max_abs"] <= 4e-3 and st["mean_abs"] <= 8e-4, st
+    assert w.diffusion_model.precision == "precise"
+    assert st["max_abs"] <= NORTH_STAR and st["mean_abs"] <= 2e-4, st
 
 
 def test_hip_path_single_frame_six_views_vs_oracle():
-    """BASELINE config 2 shape class: the 6-view network with num_frames = 1 (temporal attention over one frame, temporal
-    GroupNorm over C/32 x 1 values, conv1d with both neighbours padded) and a CFG batch of 2.  The T = 1 temporal
-    GroupNorm normalises 2 values per group, which amplifies operand rounding (same band as `plain1`)."""
+    """BASELINE config 2 shape class on the 64-channel tiny net: num_frames = 1 (temporal attention over one frame, conv1d
+    with both neighbours padded) and a CFG batch of 2.  At 64 channels the T = 1 temporal GroupNorm normalises 2 values per
+    group, which amplifies the rounding of the conv3x3 output feeding it (same band as `plain1`): every class split gives
+    1.1e-3, the default precise set 4.0e-3; the full-width T = 1 test below (10-40 values per group) is the config-2 gate."""
     kw = configs.with_frames(configs.get("tiny"), 1)
     w, sd, _ = product_network("tiny", DEV, kw=kw)
+    w.diffusion_model.precision = "precise-all"
     inp = step_inputs("tiny", kw, "cpu", t_index=666, shape=(2, 1, 8, 96))
     ref = po.wrapper_forward(sd, oracle_cfg(kw), inp["x"], inp["t"], cond(inp))
     g = {k: v.to(DEV) for k, v in inp.items()}
@@ -78,7 +90,23 @@ def test_hip_path_single_frame_six_views_vs_oracle():
     st = err_stats(eps, ref)
     print("tiny, T=1, 6 views:", st)
     assert st["ref_max"] > 1.0
-    assert st["max_abs"] <= 1.2e-2 and st["mean_abs"] <= 2e-3, st
+    assert st["max_abs"] <= 1.5e-3 and st["mean_abs"] <= 2e-4, st
+
+
+def test_full_width_single_frame_config2_vs_oracle():
+    """BASELINE config 2 at FULL width: the Panacea+ network with num_frames = 1 (6 views, intra-view + cross-view
+    attention; the temporal branch degenerates to one frame), CFG batch 2, latent 16x192, against the oracle."""
+    kw = configs.with_frames(configs.get("full"), 1)
+    w, sd, _ = product_network("full", "cpu", kw=kw)
+    inp = step_inputs("full", kw, "cpu", shape=(2, 1, 16, 192))
+    ref = po.wrapper_forward(sd, oracle_cfg(kw), inp["x"], inp["t"], cond(inp))
+    w = w.to(DEV)
+    g = {k: v.to(DEV) for k, v in inp.items()}
+    eps = w(g["x"], g["t"], cond(g))
+    st = err_stats(eps, ref)
+    print("full network, T=1, 16x192:", w.diffusion_model.precision, st)
+    assert st["ref_max"] > 1.0
+    assert st["max_abs"] <= CONFIG2_TOL[0] and st["mean_abs"] <= CONFIG2_TOL[1], st
 
 
 def test_full_network_small_panorama_vs_oracle():
@@ -94,7 +122,11 @@ def test_full_network_small_panorama_vs_oracle():
     st = err_stats(eps, ref)
     print("full network, 16x192:", st)
     assert st["ref_max"] > 1.0
-    assert st["max_abs"] <= 6e-3 and st["mean_abs"] <= 1e-3, st
+    assert st["max_abs"] <= NORTH_STAR and st["mean_abs"] <= 2e-4, st          # measured 6.4e-4 / 1.2e-4
+    w.diffusion_model.precision = "fast"
+    st = err_stats(w(g["x"], g["t"], cond(g)), ref)
+    print("full network, 16x192, fast:", st)
+    assert st["max_abs"] <= 3.4e-3 and st["mean_abs"] <= 5e-4, st               # measured 2.6e-3 / 3.6e-4
 
 
 @pytest.fixture(scope="module")
@@ -130,8 +162,14 @@ def test_full_size_properties_and_golden(full_net):
     if path.exists():
         g = np.load(path)
         st = err_stats(eps.reshape(-1)[::7], g["eps_s7"])
-        print("config 3 vs reference:", st)
-        assert st["max_abs"] <= 8e-3 and st["mean_abs"] <= 1e-3, st
+        print("config 3 vs reference:", w.diffusion_model.precision, st)
+        assert w.diffusion_model.precision == "precise"
+        assert st["max_abs"] <= NORTH_STAR and st["mean_abs"] <= 2e-4, st
+        w.diffusion_model.precision = "fast"
+        st = err_stats(w(inp["x"], inp["t"], cond(inp)).reshape(-1)[::7], g["eps_s7"])
+        w.diffusion_model.precision = "precise"
+        print("config 3 vs reference, fast:", st)
+        assert st["max_abs"] <= 3.0e-3 and st["mean_abs"] <= 4.7e-4, st           # measured 2.3e-3 / 3.6e-4
     else:
         pytest.skip("tests/golden/full_cfg3.npz not generated yet (property checks passed)")
 

@@ -1,0 +1,167 @@
+"""Error budget of the fp16 operand roundings (CPU, torch emulation of the C-ABI — tests/emu.py).
+
+    python tools/exp/error_budget.py [tiny|full16] [--modes ...]
+
+Every activation rounding of the path goes through `emu.r16(value, entry_point)`.  This tool classifies each
+rounding by (entry point, calling host function) into operand classes and re-runs the network with a chosen rounding
+per class:
+    h   = fp16 (what the kernels do today)
+    s   = split fp16 pair hi + lo*2^-11 (22-bit operand, the "precise" mode of DESIGN §6)
+    x   = exact (fp32 kept)
+Activations are kept in fp32 buffers so that a class set to s/x really carries the extra bits to its consumer.
+Prints max-abs / mean-abs of eps against the oracle (tiny: reference golden) per experiment.
+"""
+import inspect
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import emu  # noqa: E402
+from helpers import cond, err_stats, golden, oracle_cfg, product_network, step_inputs  # noqa: E402
+from oracle import panacea_oracle as po  # noqa: E402
+from panacea_amd import configs, engine as E  # noqa: E402
+
+CLASSES = ["ln", "gn_res", "gn_stt", "gn_head", "gnt", "qkv_views", "qkv_temporal", "q_text", "kv_text", "ff_hidden", "ff_out", "attn_o",
+           "stream", "conv_mid", "stem", "ctx"]
+
+
+def classify(site: str) -> str:
+    """operand class of the rounding that `site` performs, from the host function that called the backend"""
+    fn = None
+    for fr in inspect.stack()[2:12]:
+        if "/panacea_amd/" in fr.filename:
+            fn = fr.function
+            break
+    if site == "layernorm":
+        return "ln"
+    if site == "groupnorm_apply":
+        for fr in inspect.stack()[2:12]:
+            if "/panacea_amd/" in fr.filename and fr.function in ("_branch", "_head"):
+                return "gn_stt" if fr.function == "_branch" else "gn_head"
+        return "gn_res"
+    if site == "groupnorm_temporal":
+        return "gnt"
+    if site in ("attn_views", "attn_temporal"):
+        return "attn_o"
+    if site in ("concat_add", "add_f32"):
+        return "stream"
+    if site == "nchw_to_tokens":
+        return "stem"
+    if site == "gemm.geglu":
+        return "ff_hidden"
+    if site in ("gemm.out16", "gemm.out16t"):
+        if fn == "_run_views":
+            return "qkv_views"
+        if fn == "_run_temporal":
+            return "qkv_temporal"
+        if fn == "_run_text":
+            return "q_text"
+        if fn in ("_text_kv", "run"):
+            return "kv_text"
+        if fn == "_run" and site == "gemm.out16":
+            # FeedForward._run (last block: fp16 copy for proj_out) or ResBlock3D / TimestepEmbedSequential stream copies
+            for fr in inspect.stack()[2:12]:
+                if "/panacea_amd/" in fr.filename and fr.function == "_run":
+                    if "attention.py" in fr.filename:
+                        return "ff_out"
+                    return "stream"
+        if fn == "_branch":
+            return "stream"
+        if fn == "run_conv3x3":
+            # hint stem intermediate layers (fp16 between layers) or stream copies next to an fp32 output
+            return "conv_mid"
+        return "stream"
+    raise KeyError(site)
+
+
+def rounder(mode: str):
+    if mode == "h":
+        return lambda v: v.half().float()
+    if mode == "s":
+        def split(v):
+            hi = v.half().float()
+            lo = ((v - hi) * 2048.0).half().float() / 2048.0
+            return hi + lo
+        return split
+    return lambda v: v
+
+
+class Experiment:
+    def __init__(self, modes: dict):
+        self.modes = {c: modes.get(c, modes.get("*", "h")) for c in CLASSES}
+        self.count = {c: 0 for c in CLASSES}
+
+    def r16(self, v, site):
+        c = classify(site)
+        self.count[c] += v.numel()
+        return rounder(self.modes[c])(v.float())
+
+    def __enter__(self):
+        self._r16, self._strict = emu.r16, emu.STRICT_DTYPES
+        emu.r16, emu.STRICT_DTYPES = self.r16, False
+        self._empty, self._zeros, self._ctx = E.Runtime.empty, E.Runtime.zeros, E.Runtime.set_context
+        f32 = lambda d: torch.float32 if d == torch.float16 else d   # noqa: E731
+        E.Runtime.empty = lambda rt, shape, dtype: torch.empty(shape, device=rt.device, dtype=f32(dtype))
+        E.Runtime.zeros = lambda rt, shape, dtype: torch.zeros(shape, device=rt.device, dtype=f32(dtype))
+        exp = self
+
+        def set_context(rt, context):
+            B, n, D = context.shape
+            rt.n_text = n
+            c = torch.zeros((B, E.TEXT_PAD, D), dtype=torch.float32)
+            exp.count["ctx"] += context.numel()
+            c[:, :n] = rounder(exp.modes["ctx"])(context.float())
+            rt.ctx16 = c.view(B * E.TEXT_PAD, D)
+        E.Runtime.set_context = set_context
+        return self
+
+    def __exit__(self, *a):
+        emu.r16, emu.STRICT_DTYPES = self._r16, self._strict
+        E.Runtime.empty, E.Runtime.zeros, E.Runtime.set_context = self._empty, self._zeros, self._ctx
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
+    if which == "tiny":
+        w, sd, kw = product_network("tiny")
+        inp = step_inputs("tiny", kw)
+        ref = torch.from_numpy(golden("tiny")["eps"])
+    else:
+        kw = configs.with_frames(configs.get("full"), 2)
+        w, sd, _ = product_network("full", "cpu", kw=kw)
+        inp = step_inputs("full", kw, "cpu", shape=(1, 2, 16, 192))
+        ref = po.wrapper_forward(sd, oracle_cfg(kw), inp["x"], inp["t"], cond(inp))
+
+    def run(modes, label):
+        with Experiment(modes) as ex, E.use_backend(emu):
+            eps = w(inp["x"], inp["t"], cond(inp))
+        st = err_stats(eps, ref)
+        print(f"{label:60s} max {st['max_abs']:.3e}  mean {st['mean_abs']:.3e}", flush=True)
+        return st, ex
+
+    st, ex = run({"*": "h"}, "all fp16 (today)")
+    print("elements rounded per class:", {k: v for k, v in ex.count.items() if v})
+    run({"*": "x"}, "no activation rounding")
+    run({"*": "s"}, "all split")
+    base = st["mean_abs"] ** 2
+    for c in CLASSES:
+        if ex.count[c]:
+            s1, _ = run({"*": "h", c: "x"}, f"fp16 except {c} exact")
+            print(f"    -> {c}: {100 * (1 - s1['mean_abs'] ** 2 / base):5.1f} % of the error variance")
+    for extra in sys.argv[2:]:
+        modes = {"*": "h"}
+        for kv in extra.split(","):
+            k, v = kv.split("=")
+            modes[k] = v
+        run(modes, extra)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    main()

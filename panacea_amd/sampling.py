@@ -147,6 +147,14 @@ class EulerEDMSampler:
         return x
 
 
+def share_noise_init(randn: torch.Tensor, concat: torch.Tensor, share_noise_level: float) -> torch.Tensor:
+    """DiffusionEngine3D.sample (sgm/models/diffusion.py:242-249): the initial latent of every frame of a clip carries
+    `share_noise_level` x the conditioning latent of the LAST frame (`concat[-1]` tiled over the frames)."""
+    if share_noise_level <= 0.0:
+        return randn
+    return randn + concat[-1].unsqueeze(0).expand(randn.shape[0], *concat.shape[1:]) * share_noise_level
+
+
 def hoist_invariants(network, guider, cond: Dict, uc: Dict):
     """Returns copies of (cond, uc) that carry the network's StepInvariants for the batch the guider will build from
     them.  The concatenated conditioning tensors are built ONCE here and shared by every step (prepare_inputs would

@@ -90,3 +90,13 @@ def test_hoisted_step_invariants_are_bit_identical_and_guarded():
         inp["cond_feat"].add_(0.0)                                   # in-place write bumps the version counter
         with pytest.raises(ValueError):
             model.denoise(x8, inp["t"], inp["crossattn"], inp["cond_feat"], invariants=inv)
+
+
+def test_share_noise_init_matches_the_engine_formula():
+    """diffusion.py:242-249: randn + share_noise_level * repeat(concat[-1], 'c h w -> t c h w', t=num_frames)"""
+    from panacea_amd import sampling as S
+    g = torch.Generator().manual_seed(1)
+    randn, concat = torch.randn(8, 4, 6, 10, generator=g), torch.randn(8, 4, 6, 10, generator=g)
+    ref = randn + concat[-1][None].repeat(8, 1, 1, 1) * 0.07
+    assert torch.equal(S.share_noise_init(randn, concat, 0.07), ref)
+    assert S.share_noise_init(randn, concat, 0.0) is randn

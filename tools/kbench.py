@@ -44,9 +44,6 @@ def report(name, t, flops=None, bytes_=None):
     print(s, flush=True)
 
 
-import os
-ABL = int(os.environ.get("PNC_ABLATE", "0"))
-
 
 def bench_gemm(flt):
     for li, (C, H, W) in enumerate(LEVELS):
@@ -60,14 +57,20 @@ def bench_gemm(flt):
             bias = torch.zeros(N, device=DEV)
             if kw.get("geglu"):
                 o = torch.empty(M, N // 2, device=DEV, dtype=torch.float16)
-                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, geglu=True, out16=o, ldc16=N // 2, act=ABL)
+                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, geglu=True, out16=o, ldc16=N // 2)
             elif kw.get("res"):
                 o = torch.zeros(M, N, device=DEV)
-                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, res1=o, ldr1=N, out32=o, ldc32=N, act=ABL)
+                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, res1=o, ldr1=N, out32=o, ldc32=N)
             else:
                 o = torch.empty(M, N, device=DEV, dtype=torch.float16)
-                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, out16=o, ldc16=N, act=ABL)
+                fn = lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, out16=o, ldc16=N)
             report(tag, timeit(fn), flops=2.0 * M * N * K)
+            if kw.get("res") and name == "proj":
+                # the same call-site with a precise (split) operand: K loop over the lo and the hi plane
+                alo = h16(M, K)
+                report(tag + " PRECISE", timeit(lambda: hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, res1=o, ldr1=N, out32=o,
+                                                                 ldc32=N, a16_lo=alo)), flops=2.0 * M * N * K)
+                del alo
             del a, w, o
         # conv3x3 C->C and temporal conv1d
         tag = f"conv3x3 L{li} C={C} {H}x{W}"
@@ -75,14 +78,18 @@ def bench_gemm(flt):
             x, w = h16(F, H, W, C), h16(C, 9 * C)
             o = torch.empty(M, C, device=DEV)
             conv = dict(Cin=C, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0)
-            report(tag, timeit(lambda: hip.gemm(x, w, M=M, N=C, K=9 * C, a_mode=hip.A_CONV3X3, conv=conv, out32=o, ldc32=C, act=ABL)),
+            report(tag, timeit(lambda: hip.gemm(x, w, M=M, N=C, K=9 * C, a_mode=hip.A_CONV3X3, conv=conv, out32=o, ldc32=C)),
                    flops=2.0 * M * C * 9 * C)
+            xlo = h16(F, H, W, C)
+            report(tag + " PRECISE", timeit(lambda: hip.gemm(x, w, M=M, N=C, K=9 * C, a_mode=hip.A_CONV3X3, conv=conv, out32=o,
+                                                             ldc32=C, a16_lo=xlo)), flops=2.0 * M * C * 9 * C)
+            del xlo
         tag = f"conv1d_t L{li} C={C}"
         if not flt or flt in tag:
             x, w = h16(M, C), h16(C, 3 * C)
             o = torch.zeros(M, C, device=DEV)
             report(tag, timeit(lambda: hip.gemm(x, w, M=M, N=C, K=3 * C, a_mode=hip.A_CONV1D_T,
-                                                tconv=dict(C=C, T=8, Npix=H * W), res1=o, ldr1=C, out32=o, ldc32=C, act=ABL)),
+                                                tconv=dict(C=C, T=8, Npix=H * W), res1=o, ldr1=C, out32=o, ldc32=C)),
                    flops=2.0 * M * C * 3 * C)
 
 

@@ -191,6 +191,11 @@ def main():
     ap.add_argument("--precision", default="precise", choices=["fast", "precise", "precise-all"],
                     help="operand policy of the timed region (DESIGN §6).  precise (default) meets eps max-abs < 1e-3; the "
                          "other of fast / precise is timed too and reported under `modes`")
+    ap.add_argument("--parallelism", default="replica", choices=["replica", "cfg", "cfg+frames", "frames"],
+                    help="N > 1: replica = one sample per rank (the reference's strategy, weak scaling, default); cfg = one "
+                         "sample per rank pair (CFG halves, one all-gather per step); cfg+frames = one sample over "
+                         "2 CFG halves x min(4, N/2) frame groups (RCCL all-to-all at the temporal sites, SURVEY §8e): "
+                         "per-sample latency, strong scaling")
     ap.add_argument("--frames", type=int, default=8, choices=[1, 2, 4, 8],
                     help="frames per sample: 8 = BASELINE config 3 (headline); 1 = BASELINE config 2 (6-view 1-frame 256x512)")
     ap.add_argument("--yaml-exact", action="store_true",
@@ -233,8 +238,10 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    from panacea_amd import build_network, configs, hip, sampling, synth
+    from panacea_amd import build_network, configs, hip, parallel, sampling, synth
     hip.load()
+    layout = parallel.layout_for(world, rank, args.parallelism)
+    groups = parallel.Groups(layout) if (layout.cfg > 1 or layout.frames > 1) else None
     kw = configs.with_frames(configs.get(args.config), args.frames) if args.config == "full" else configs.get(args.config)
     B, T, h, w = configs.SHAPES[args.config]
     T = kw["num_frames"]
@@ -249,13 +256,19 @@ def main():
     net.diffusion_model.precision = args.precision
     log(f"[rank {rank}] network built in {time.time() - t0:.0f}s")
 
-    # one sample per rank: c / uc conditioning of ONE 6-view x T-frame clip (seed offset by rank, inference.py:250)
-    inp = synth.synth_inputs(2, T, h, w, context_dim=kw["context_dim"], salt=rank)
+    # one sample per rank (or per rank group): c / uc conditioning of ONE 6-view x T-frame clip, seed offset by SAMPLE
+    # (inference.py:250) — all ranks of one sample draw the same latent
+    inp = synth.synth_inputs(2, T, h, w, context_dim=kw["context_dim"], salt=layout.sample)
     g = {k: v.to(dev) for k, v in inp.items()}
     cond = {"crossattn": g["crossattn"][1:2], "concat": g["concat"][T:], "cond_feat": g["cond_feat"][T:]}
     uc = {"crossattn": g["crossattn"][0:1], "concat": g["concat"][:T], "cond_feat": g["cond_feat"][:T]}
     den = sampling.DiscreteDenoiser().to(dev)
-    smp = sampling.EulerEDMSampler(args.num_sampling_steps, guider=sampling.VanillaCFG(5.0), device=dev)
+    guider = groups.guider(5.0) if groups is not None else sampling.VanillaCFG(5.0)
+    smp = sampling.EulerEDMSampler(args.num_sampling_steps, guider=guider, device=dev)
+    shard = groups.frame_shard() if groups is not None else None
+    if shard is not None:
+        parallel.apply_frame_shard(net, shard)
+        cond, uc = parallel.shard_conditioning(cond, layout, T), parallel.shard_conditioning(uc, layout, T)
     sig = smp.sigmas()
     nsig = len(sig) - 1
     x0 = g["x"][T:]
@@ -270,7 +283,10 @@ def main():
             d["concat"] = cc
         x0 = sampling.share_noise_init(x0, cond["concat"], 0.07)
     x = x0 * torch.sqrt(1.0 + sig[0] ** 2.0)
-    s_in = x.new_ones([T])
+    x = parallel.local_frames(x, layout, T)                     # this rank's frame group of the sample
+    s_in = x.new_ones([x.shape[0]])
+    if layout.cfg > 1:
+        guider.check_pair_consistency(x, s_in * sig[0])
     denoiser = lambda xi, sigma, cc: den(net, xi, sigma, cc)   # noqa: E731
 
     sig_rows = [s_in * sig[j] for j in range(nsig + 1)]          # per-step sigma vectors, resident
@@ -294,8 +310,8 @@ def main():
 
     def parity_of(prec):
         """eps of one network call at BASELINE config 3 vs the REFERENCE's own fp32 forward (committed golden)"""
-        if not (args.config == "full" and T == 8 and rank == 0 and GOLDEN_FULL.exists()):
-            return None
+        if not (args.config == "full" and T == 8 and rank == 0 and GOLDEN_FULL.exists()) or shard is not None:
+            return None          # (a frame-sharded network runs collectives: no single-rank evaluation)
         import numpy as np
         gold = np.load(GOLDEN_FULL)
         net.diffusion_model.precision = prec
@@ -339,23 +355,25 @@ def main():
     assert torch.isfinite(xx).all()
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.steps / elapsed           # every rank advances its own sample by `steps`
+    value = layout.samples * args.steps / elapsed    # every rank (group) advances its own sample by `steps`
     out = {
         "metric": f"denoising steps/s (6-view x {T}-frame 256x512)", "value": value, "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if layout.per_sample == 1 else "strong", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
         "config": {"workload": (f"BASELINE config {5 if args.yaml_exact else (3 if T == 8 else 2)}: Panacea+ stage-2 UNet+ControlNet, "
                                 f"CFG 2 x {T} frames, 6 views, latent 32x384, hint 256x3072, Euler/LegacyDDPM "
                                 f"{args.num_sampling_steps}-step schedule" +
                                 (", last-frame concat conditioning, share-noise init (inference_nuscenes.yaml)" if args.yaml_exact else ""))
                                if args.config == "full" else "tiny",
                    "precision": E_precision_name(args.precision),
-                   "frames_per_step": 2 * T, "parallelism": f"replica x{world}" if world > 1 else "single",
+                   "frames_per_step": 2 * T, "parallelism": layout.name,
+                   "ranks_per_sample": layout.per_sample, "per_sample_latency_ms": ms_per_step,
                    "graph": bool(args.graph), "streams": 1 if args.one_stream else 2,
                    "hoisted_step_invariants": bool(args.hoist)},
     }
     if args.config == "full":
-        ach = ALGO_TFLOP_PER_STEP * (value / world) if T == 8 else None
+        ach = ALGO_TFLOP_PER_STEP * (value / world) if T == 8 else None     # per GPU
         # HBM-side bytes per step come from separate rocprofv3 --pmc passes of this same command (they cannot be collected
         # inside a timed run).  The record names the build it was measured on: a stale record reports null, not a number.
         traffic, tnote = None, "no PMC record for this build (tools/pmc_traffic.py writes profiles/round2/pmc_traffic.json)"
@@ -378,8 +396,13 @@ def main():
             out["roofline"]["basis"] = "sum of 2MNK over the contractions launched in one step (HIP-event pass) / measured step time"
     if parity:
         out["parity"] = parity
+    if shard is not None:
+        nsteps = args.steps + args.warmup
+        out["config"]["exchange"] = {"all_to_all_per_step": shard.exchanges // max(1, nsteps),
+                                     "MB_sent_per_rank_and_step": round(shard.bytes_sent / max(1, nsteps) / 1e6, 1),
+                                     "note": "engine.FrameShard: temporal sites run pixel-sharded (DESIGN.md §9)"}
 
-    if rank == 0 and not args.no_kernel_breakdown:
+    if rank == 0 and not args.no_kernel_breakdown and layout.per_sample == 1:
         prof = hip.Profiler()
         hip.set_profiler(prof)
         two = net.diffusion_model.two_stream

@@ -123,13 +123,85 @@ class Act:
         return t.view(self.F, self.H, self.W, self.C).permute(0, 3, 1, 2).contiguous()
 
 
-class Runtime:
-    """Per-forward execution context."""
+class FrameShard:
+    """The T frames of every sample sharded over the G ranks of a process group: rank g of the group
+    holds frames [g*T/G, (g+1)*T/G) of each sample — whole panoramic frames, so every spatial op (3x3 convs, spatial
+    GroupNorm, intra-/cross-view attention) stays local.  The cross-frame couplings of the path,
+        ResBlock3D   temporal GroupNorm + conv1d            (openaimodel.py:505-515, 533-539)
+        STT          temporal transformer branch            (attention.py:1106-1134)
+    are all POINTWISE PER PIXEL across frames, so they run in the transposed sharding: all T frames of N/G pixels per
+    rank.  `to_pixels` / `to_frames` are the two exchanges (one all-to-all each: a rank sends (G-1)/G of its slab and
+    receives as much — half the received bytes of all-gathering the slab, and the unmodified kernels run on both sides);
+    `gather_rows` all-gathers tiny per-frame rows (the timestep embedding).  RCCL over xGMI on MI355X ("nccl"), gloo in
+    the CPU tests; `group=None` with G = 1 is the loop-back used by the single-device GPU test."""
 
-    def __init__(self, device: torch.device, B: int, T: int):
+    def __init__(self, G: int, index: int, group=None):
+        if G < 1 or not (0 <= index < G):
+            raise ValueError(f"bad frame shard {index} of {G}")
+        if G > 1 and group is None:
+            raise ValueError("a frame shard over more than one rank needs its process group")
+        self.G, self.index, self.group = G, index, group
+        self.bytes_sent = 0                       # accounting for bench / DESIGN §9 (this rank, since construction)
+        self.exchanges = 0
+
+    def _a2a(self, send: torch.Tensor) -> torch.Tensor:
+        self.exchanges += 1
+        self.bytes_sent += send.numel() * send.element_size() * (self.G - 1) // self.G
+        if self.group is None:
+            return send.clone()
+        import torch.distributed as dist
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    def to_pixels(self, x: torch.Tensor, B: int, N: int) -> torch.Tensor:
+        """[B*T_l*N, C] rows (b, t_local, p) -> [B*T*(N/G), C] rows (b, t, p_local)"""
+        G = self.G
+        if N % G:
+            raise ValueError(f"{N} pixels per frame do not split over {G} frame groups")
+        C = x.shape[-1]
+        Tl, Np = x.shape[0] // (B * N), N // G
+        send = x.view(B, Tl, G, Np, C).permute(2, 0, 1, 3, 4).contiguous()      # [dest pixel group, b, t_l, p, c]
+        recv = self._a2a(send)                                                  # [src frame group, b, t_l, p, c]
+        return recv.permute(1, 0, 2, 3, 4).contiguous().view(B * G * Tl * Np, C)
+
+    def to_frames(self, x: torch.Tensor, B: int, N: int) -> torch.Tensor:
+        """inverse of to_pixels: [B*T*(N/G), C] -> [B*T_l*N, C]"""
+        G = self.G
+        C = x.shape[-1]
+        Np = N // G
+        Tl = x.shape[0] // (B * G * Np)
+        send = x.view(B, G, Tl, Np, C).permute(1, 0, 2, 3, 4).contiguous()      # [dest frame group, b, t_l, p, c]
+        recv = self._a2a(send)                                                  # [src pixel group, b, t_l, p, c]
+        return recv.permute(1, 2, 0, 3, 4).contiguous().view(B * Tl * N, C)
+
+    def gather_rows(self, x: torch.Tensor, B: int) -> torch.Tensor:
+        """[B*T_l, D] per-frame rows -> [B*T, D] (frames of a sample in global order)"""
+        G = self.G
+        D = x.shape[-1]
+        Tl = x.shape[0] // B
+        if self.group is None:
+            return x.clone()
+        import torch.distributed as dist
+        parts = [torch.empty_like(x) for _ in range(G)]
+        dist.all_gather(parts, x.contiguous(), group=self.group)
+        return torch.stack([p.view(B, Tl, D) for p in parts], dim=1).reshape(B * G * Tl, D)
+
+
+class Runtime:
+    """Per-forward execution context.  B samples x T frames; with a FrameShard only T_local = T / G frames of every
+    sample live on this rank (F = B * T_local frames in the resident layout)."""
+
+    def __init__(self, device: torch.device, B: int, T: int, shard: Optional[FrameShard] = None):
         self.be = backend()
         self.device = device
-        self.B, self.T, self.F = B, T, B * T
+        self.shard = shard
+        G = shard.G if shard is not None else 1
+        if T % G:
+            raise ValueError(f"{T} frames per sample do not split over {G} frame groups")
+        self.B, self.T, self.T_local = B, T, T // G
+        self.F = B * self.T_local
+        self.emb_all: Optional[torch.Tensor] = None    # frame-sharded runs: SiLU(emb) rows of ALL B*T frames
         self.prec: Precision = FAST                    # operand precision policy of this evaluation
         self.ctx16: Optional[torch.Tensor] = None      # [B*TEXT_PAD, context_dim] fp16, zero padded
         self.n_text = 77
@@ -263,9 +335,10 @@ def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, be
 
 
 def gn_temporal(rt: Runtime, x32: torch.Tensor, N: int, C: int, gamma, beta, eps: float):
-    """-> (y16, y16_lo) (operand class `gnt`)"""
-    y = rt.empty((rt.F * N, C), torch.float16)
-    ylo = rt.empty((rt.F * N, C), torch.float16) if rt.prec.gnt else None
+    """-> (y16, y16_lo) (operand class `gnt`).  x32 holds ALL T frames of N pixels per sample (the resident layout, or
+    the pixel-sharded layout of a FrameShard with N = pixels per rank)."""
+    y = rt.empty((rt.B * rt.T * N, C), torch.float16)
+    ylo = rt.empty((rt.B * rt.T * N, C), torch.float16) if rt.prec.gnt else None
     rt.be.groupnorm_temporal_silu(x32, rt.B, rt.T, N, C, gamma, beta, eps, y, ylo)
     return y, ylo
 

@@ -147,7 +147,7 @@ class _AttentionBase(nn.Module, Packable):
         o = rt.empty((M, C), torch.float16)
         rt.be.attn_views(q, C, k, ldk, vt, ldvt, vt_gs, o, C, groups=F, heads=self.heads, H=H, W=W,
                          views=1, kvH=1, kvW=E.TEXT_PAD, kv_views=1, kv_rows_per_group=E.TEXT_PAD,
-                         q_per_kv=rt.T, kv_valid=rt.n_text, segs=[[0]], scale=self.scale)
+                         q_per_kv=F // rt.B, kv_valid=rt.n_text, segs=[[0]], scale=self.scale)
         rt.be.gemm(o, pk["wo"], M=M, N=self.query_dim, K=C, lda=C, bias=pk["bo"], res1=res32,
                    ldr1=self.query_dim, out32=out32, ldc32=self.query_dim)
 
@@ -174,7 +174,7 @@ class _AttentionBase(nn.Module, Packable):
     def _run_temporal(self, rt: Runtime, x16, N, res32, out32):
         pk = self.packed()
         C = self.inner_dim
-        M = rt.F * N
+        M = rt.B * rt.T * N              # all T frames of N pixels per sample (N = pixels per rank when frame-sharded)
         qkv = rt.empty((M, 3 * C), torch.float16)
         rt.be.gemm(x16, pk["wqkv"], M=M, N=3 * C, K=self.query_dim, lda=self.query_dim, out16=qkv, ldc16=3 * C)
         o = rt.empty((M, C), torch.float16)
@@ -342,19 +342,33 @@ class SpatialTemporalTransformer(nn.Module, Packable):
         C, M = x.C, x.M
         n16, n16lo = E.gn_spatial(rt, x.f32, x.F, x.N, C, pk["g" + sfx], pk["b" + sfx], 1e-6, False,
                                   split=rt.prec.gn_stt)
-        t32 = rt.empty((M, C), torch.float32)
+        sh = rt.shard if branch == "temporal" else None
+        if sh is not None:
+            # Frame-sharded run: the temporal branch is pointwise per pixel (LN, projections, text cross-attention, FF) or
+            # couples the T frames of ONE pixel (temporal self-attention), so it runs on all T frames of N/G pixels.
+            # Exchanged: the GroupNorm output going in, the last block's fp16 output coming back (fp16 planes only).
+            n16 = sh.to_pixels(n16, rt.B, x.N)
+            n16lo = sh.to_pixels(n16lo, rt.B, x.N) if n16lo is not None else None
+            Fb, Hb, Wb = rt.B * rt.T, 1, x.N // sh.G
+        else:
+            Fb, Hb, Wb = x.F, x.H, x.W
+        Mb = Fb * Hb * Wb
+        t32 = rt.empty((Mb, C), torch.float32)
         if branch == "temporal":
             # + position table indexed by t = frame % T (attention.py:1117-1118)
-            rt.be.gemm(n16, pk["wi" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bi" + sfx], rowbias=pk["pos"],
-                       rb_rows=x.N, rb_mod=rt.T, out32=t32, ldc32=C, a16_lo=n16lo)
+            rt.be.gemm(n16, pk["wi" + sfx], M=Mb, N=C, K=C, lda=C, bias=pk["bi" + sfx], rowbias=pk["pos"],
+                       rb_rows=Hb * Wb, rb_mod=rt.T, out32=t32, ldc32=C, a16_lo=n16lo)
         else:
-            rt.be.gemm(n16, pk["wi" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bi" + sfx], out32=t32, ldc32=C,
+            rt.be.gemm(n16, pk["wi" + sfx], M=Mb, N=C, K=C, lda=C, bias=pk["bi" + sfx], out32=t32, ldc32=C,
                        a16_lo=n16lo)
         p16 = p16lo = None
         for i, blk in enumerate(blocks):
-            r = blk._run(rt, t32, x.F, x.H, x.W, branch, last=(i == len(blocks) - 1))
+            r = blk._run(rt, t32, Fb, Hb, Wb, branch, last=(i == len(blocks) - 1))
             if r is not None:
                 p16, p16lo = r
+        if sh is not None:
+            p16 = sh.to_frames(p16, rt.B, x.N)
+            p16lo = sh.to_frames(p16lo, rt.B, x.N) if p16lo is not None else None
         # x = proj_out(t) + x_in, in place on the stream
         rt.be.gemm(p16, pk["wo" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bo" + sfx], res1=x.f32, ldr1=C,
                    out32=x.f32, ldc32=C, out16=out16, ldc16=C, a16_lo=p16lo, out16_lo=out16_lo)

@@ -128,7 +128,7 @@ class ControlNet3D(UNetModel3D):
         assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"
         with torch.no_grad():
-            rt = runtime_for(x, self.num_frames)
+            rt = runtime_for(x, self.num_frames, self.frame_shard)
             rt.prec = E.precision(self.precision)
             rt.set_context(context)
             emb = self._time_embedding(rt, timesteps)
@@ -153,7 +153,7 @@ class ControlledUNetModel3D(UNetModel3D):
         assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"
         with torch.no_grad():
-            rt = runtime_for(x, self.num_frames)
+            rt = runtime_for(x, self.num_frames, self.frame_shard)
             rt.prec = E.precision(self.precision)
             rt.set_context(context)
             emb = self._time_embedding(rt, timesteps)
@@ -171,7 +171,8 @@ class ControlledUNetModel3D(UNetModel3D):
         compute them once — `denoise(..., invariants=inv)` is then bit-identical to the plain call."""
         with torch.no_grad():
             F = hint.shape[0]
-            rt = Runtime(hint.device, F // self.num_frames, self.num_frames)
+            sh = self.frame_shard
+            rt = Runtime(hint.device, F // (self.num_frames // (sh.G if sh is not None else 1)), self.num_frames, sh)
             rt.prec = E.precision(self.precision)
             rt.set_context(context)
             self._project_text(rt)
@@ -188,7 +189,7 @@ class ControlledUNetModel3D(UNetModel3D):
         feeds the UNet from its middle block on (controlmodel.py:191-195), so it runs on a side stream next to the
         UNet encoder: its small-grid kernels (L2/L3, 4x48 tokens) fill CUs the encoder's leave idle, and vice versa.
         Samples of the batch never interact inside the network, so they can be issued as independent stream pairs."""
-        T = self.num_frames
+        T = self.num_frames // (self.frame_shard.G if self.frame_shard is not None else 1)   # frames per sample on this rank
         B = x.shape[0] // T
         if invariants is not None:
             return self._denoise_one(x, timesteps, context, hint, trace, 0, invariants)
@@ -211,7 +212,7 @@ class ControlledUNetModel3D(UNetModel3D):
 
     def _denoise_one(self, x, timesteps, context, hint, trace, side_idx, inv=None) -> torch.Tensor:
         with torch.no_grad():
-            rt = runtime_for(x, self.num_frames)
+            rt = runtime_for(x, self.num_frames, self.frame_shard)
             rt.prec = E.precision(self.precision)
             rt.trace = trace
             if inv is not None:
@@ -223,7 +224,8 @@ class ControlledUNetModel3D(UNetModel3D):
             x16 = self._stem_tokens(rt, x)
             cn = self.controlnet
             hint32 = hint if inv is not None else hint.detach().to(torch.float32).contiguous()
-            if self.two_stream and x.is_cuda and trace is None:
+            # frame-sharded runs issue collectives from both networks: one stream keeps their order identical on all ranks
+            if self.two_stream and x.is_cuda and trace is None and rt.shard is None:
                 main = torch.cuda.current_stream()
                 side = _side_stream(x.device, side_idx)
                 side.wait_stream(main)

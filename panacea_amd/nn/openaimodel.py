@@ -200,21 +200,31 @@ class ResBlock3D(TimestepBlock, Packable):
         F, H, W, N, M = x.F, x.H, x.W, x.N, x.M
         Cin, Co = self.channels, self.out_channels
         hip = E._hip
-        tconv = dict(C=Co, T=rt.T, Npix=N)
+        sh = rt.shard
+        # The two temporal sites (GroupNorm over (C/32, T) of one pixel + conv1d over its T frames) see all T frames of
+        # a pixel.  Frame-sharded runs (engine.FrameShard) execute them in the pixel-sharded layout: Mt rows of Nt pixels.
+        Nt = N // sh.G if sh is not None else N
+        Mt = rt.B * rt.T * Nt
+        tconv = dict(C=Co, T=rt.T, Npix=Nt)
         # in_layers: GN + SiLU + conv3x3
         a16, a16lo = E.gn_spatial(rt, x.f32, F, N, Cin, pk["g1"], pk["b1"], 1e-5, True, split=rt.prec.gn_res)
         h = run_conv3x3(rt, a16, F, H, W, Cin, pk["w1"], pk["c1"], Co, x16_lo=a16lo).f32
         # h = h + conv1d_t(SiLU(GN_t(h))) + emb_layers(emb)[frame]      (:505-531)
-        t16, t16lo = E.gn_temporal(rt, h, N, Co, pk["gt1"], pk["bt1"], 1e-5)
         # emb32 arrives as SiLU(emb): the activation of `emb_layers` is applied ONCE per network evaluation by
         # _time_embedding (32 ResBlocks x 16 x 1280 identical SiLUs otherwise), the Linear runs here
-        emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
-        rt.be.gemm(t16, pk["wt1"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct1"],
-                   rowbias=emb_out, rb_rows=N, rb_mod=F, res1=h, ldr1=Co, out32=h, ldc32=Co, a16_lo=t16lo)
+        if sh is not None:
+            h = sh.to_pixels(h, rt.B, N)
+            emb_out = E.small_linear(rt, rt.emb_all, pk["we"], pk["be"], rt.B * rt.T, Co, self.emb_channels)
+        else:
+            emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
+        t16, t16lo = E.gn_temporal(rt, h, Nt, Co, pk["gt1"], pk["bt1"], 1e-5)
+        rt.be.gemm(t16, pk["wt1"], M=Mt, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct1"],
+                   rowbias=emb_out, rb_rows=Nt, rb_mod=rt.B * rt.T, res1=h, ldr1=Co, out32=h, ldc32=Co, a16_lo=t16lo)
+        if sh is not None:
+            h = sh.to_frames(h, rt.B, N)
         # out_layers: GN + SiLU + conv3x3
         a16, a16lo = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True, split=rt.prec.gn_res)
         g = run_conv3x3(rt, a16, F, H, W, Co, pk["w2"], pk["c2"], Co, x16_lo=a16lo).f32
-        t16, t16lo = E.gn_temporal(rt, g, N, Co, pk["gt2"], pk["bt2"], 1e-5)
         # skip path
         if "ws" in pk:
             s = rt.empty((M, Co), torch.float32)
@@ -225,9 +235,19 @@ class ResBlock3D(TimestepBlock, Packable):
         # return skip(x) + (g + conv1d_t(SiLU(GN_t(g))))                 (:533-542)
         o16 = rt.empty((M, Co), torch.float16) if want_f16 else None
         o16lo = rt.empty((M, Co), torch.float16) if (want_f16 and rt.prec.stream) else None
-        rt.be.gemm(t16, pk["wt2"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct2"],
-                   res1=g, ldr1=Co, res2=s, ldr2=Co, out32=g, ldc32=Co, out16=o16, ldc16=Co, a16_lo=t16lo,
-                   out16_lo=o16lo)
+        if sh is None:
+            t16, t16lo = E.gn_temporal(rt, g, N, Co, pk["gt2"], pk["bt2"], 1e-5)
+            rt.be.gemm(t16, pk["wt2"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct2"],
+                       res1=g, ldr1=Co, res2=s, ldr2=Co, out32=g, ldc32=Co, out16=o16, ldc16=Co, a16_lo=t16lo,
+                       out16_lo=o16lo)
+        else:
+            # the skip path stays in the frame layout: g + conv1d in the pixel layout, exchange back, then + skip
+            gp = sh.to_pixels(g, rt.B, N)
+            t16, t16lo = E.gn_temporal(rt, gp, Nt, Co, pk["gt2"], pk["bt2"], 1e-5)
+            rt.be.gemm(t16, pk["wt2"], M=Mt, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct2"],
+                       res1=gp, ldr1=Co, out32=gp, ldc32=Co, a16_lo=t16lo)
+            g = sh.to_frames(gp, rt.B, N)
+            rt.be.add_f32(g, s, M * Co, g, o16, o16lo)
         return Act(F, H, W, Co, f32=g, f16=o16, f16_lo=o16lo)
 
     def forward(self, x, emb):
@@ -345,6 +365,10 @@ class UNetModel3D(nn.Module, Packable):
         super().invalidate_packed()
         self.__dict__.pop("_text_proj", None)
 
+    # engine.FrameShard when the frames of every sample are sharded over a process group (panacea_amd.parallel); the
+    # batch then carries num_frames / G frames per sample
+    frame_shard = None
+
     # Operand precision policy (engine.Precision or "fast" | "precise" | "precise-all").  "precise" carries the operand
     # classes that dominate the eps error as split fp16 pairs and meets the 1e-3 max-abs contract of the boundary
     # (wrappers.py:37-70); "fast" is plain fp16 operands everywhere (2.3e-3 at BASELINE config 3).
@@ -390,7 +414,11 @@ class UNetModel3D(nn.Module, Packable):
         t_emb = timestep_embedding(timesteps.to(rt.device), mc)
         h = E.small_linear(rt, t_emb, pk["tw0"], pk["tb0"], rt.F, td, mc, silu_out=True)
         # returns SiLU(emb): every consumer of emb (ResBlock3D.emb_layers, :468-476) starts with nn.SiLU
-        return E.small_linear(rt, h, pk["tw2"], pk["tb2"], rt.F, td, td, silu_out=True)
+        emb = E.small_linear(rt, h, pk["tw2"], pk["tb2"], rt.F, td, td, silu_out=True)
+        if rt.shard is not None:
+            # the temporal sites run on all T frames of a pixel: they index the embedding rows of ALL frames (40 KB)
+            rt.emb_all = rt.shard.gather_rows(emb, rt.B)
+        return emb
 
     def _head(self, rt: Runtime, h: Act) -> torch.Tensor:
         """self.out: GN + SiLU + conv3x3 -> NCHW fp32 (:1245-1253, controlmodel.py:197-202)."""
@@ -458,7 +486,7 @@ class UNetModel3D(nn.Module, Packable):
             "must specify y if and only if the model is class-conditional"
         from .util import runtime_for
         with torch.no_grad():
-            rt = runtime_for(x, self.num_frames)
+            rt = runtime_for(x, self.num_frames, self.frame_shard)
             rt.prec = E.precision(self.precision)
             rt.set_context(context)
             emb = self._time_embedding(rt, timesteps)

@@ -1,30 +1,36 @@
 """Multi-GPU execution of the denoising path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL
 over xGMI on MI355X, "gloo" in the CPU tests).
 
-What shards, and how:
+What shards, and how.  Rank grid of one node: samples x CFG halves x frame groups,
+rank = (sample * cfg + half) * G + frame_group  (`RankLayout`).
 
 * **samples** — the reference's own strategy (`inference.py:248-280`: DistributedSampler + a DDP wrapper used only
   for `.module`): independent units, no collective on the data path.  `replica_seed()` mirrors `inference.py:250`.
-* **CFG halves** — inside `OpenAIWrapperControlLDM3D.forward` the unconditional and conditional halves of the
+* **CFG halves** (cfg = 2) — inside `OpenAIWrapperControlLDM3D.forward` the unconditional and conditional halves of the
   guidance batch never interact (every op is per sample; GroupNorm statistics are per frame).  Only
   `VanillaCFG.__call__` (guiders.py:25-29) combines them.  `ShardedCFG` is a drop-in guider that gives each rank
-  of a pair ONE half (half the frames per network evaluation => half the latency per step) and exchanges the
-  denoised halves with one all-gather of (T, 4, h, w) per step — 0.8 MB at the nuScenes shape, the only real
-  exchange step of the path; each peer pair has its own xGMI link, so pairs do not contend.
-* **frame groups / view groups** inside a half are NOT sharded here: every ResBlock3D (temporal GroupNorm +
-  conv1d, 64 sites/step) and every temporal attention (23 sites/step) needs all T frames of a pixel, i.e. an
-  all-gather of a full-resolution activation per site (≈ 94 MB received per L0 site at 4 frame groups, ≈ 3-4 GB
-  per step and rank — as much time on 7 x 153 GB/s links as the compute it would save), and every 3x3 conv and
-  spatial GroupNorm couples the views.  Recorded as the next row in DESIGN.md §9.
+  of a pair ONE half (half the frames per network evaluation) and exchanges the denoised halves with one all-gather of
+  (T_local, 4, h, w) per step — 0.8 MB at the nuScenes shape; each peer pair has its own xGMI link.
+* **frame groups** (G = 2 | 4) — rank g of a frame group holds frames [g*T/G, (g+1)*T/G) of its half: whole panoramic
+  frames, so the 3x3 convs, the spatial GroupNorms and the intra-/cross-view attention (which couple the six VIEWS of a
+  frame: attention.py:545-559, util.py:276-283) need nothing from another rank.  The cross-frame couplings — the two
+  temporal GroupNorm + conv1d sites of every ResBlock3D (openaimodel.py:505-515, 533-539) and the temporal transformer
+  branch of every STT (attention.py:1106-1134) — are pointwise per pixel across frames and run in the transposed
+  sharding (all T frames of N/G pixels per rank): `engine.FrameShard.to_pixels / to_frames`, one all-to-all each.
+  Bytes per rank and step, and the overlap plan, are in DESIGN.md §9.
+  View-group sharding (splitting the 6 views) is not built: every 3x3 conv and spatial GroupNorm couples the views, i.e.
+  a halo / partial-sum exchange at ~300 sites per step instead of ~90 frame exchanges that move whole tiles.
 """
 from __future__ import annotations
 
 import os
+from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
 
+from .engine import FrameShard
 from .sampling import VanillaCFG
 
 
@@ -46,9 +52,10 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     return rank, world, local_rank
 
 
-def replica_seed(rank: int, base: int = 3407) -> int:
-    """inference.py:250 — every replica draws its own noise."""
-    return base + rank
+def replica_seed(sample: int, base: int = 3407) -> int:
+    """inference.py:250 — every replica (SAMPLE) draws its own noise.  With intra-sample sharding pass
+    `RankLayout.sample`, never the rank: all ranks of one sample must draw the same latent."""
+    return base + sample
 
 
 def cfg_pair_groups(world: int) -> List[Optional[dist.ProcessGroup]]:
@@ -58,9 +65,141 @@ def cfg_pair_groups(world: int) -> List[Optional[dist.ProcessGroup]]:
     return [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]
 
 
+@dataclass(frozen=True)
+class RankLayout:
+    """rank = (sample * cfg + half) * frames + frame_group"""
+    world: int
+    rank: int
+    cfg: int = 1            # 1: both CFG halves on every rank; 2: one half per rank
+    frames: int = 1         # frame groups per half (G)
+
+    def __post_init__(self):
+        if self.cfg not in (1, 2) or self.frames < 1 or self.world % (self.cfg * self.frames):
+            raise ValueError(f"{self.world} ranks do not factor into cfg {self.cfg} x frame groups {self.frames}")
+
+    @property
+    def per_sample(self) -> int:
+        return self.cfg * self.frames
+
+    @property
+    def samples(self) -> int:
+        return self.world // self.per_sample
+
+    @property
+    def sample(self) -> int:
+        return self.rank // self.per_sample
+
+    @property
+    def half(self) -> int:
+        return (self.rank // self.frames) % self.cfg
+
+    @property
+    def frame_group(self) -> int:
+        return self.rank % self.frames
+
+    def frame_group_ranks(self, sample: int, half: int) -> List[int]:
+        base = (sample * self.cfg + half) * self.frames
+        return [base + g for g in range(self.frames)]
+
+    def cfg_pair_ranks(self, sample: int, frame_group: int) -> List[int]:
+        return [(sample * self.cfg + h) * self.frames + frame_group for h in range(self.cfg)]
+
+    @property
+    def name(self) -> str:
+        parts = [f"replica x{self.samples}"] if self.samples > 1 else []
+        if self.cfg > 1:
+            parts.append("cfg x2")
+        if self.frames > 1:
+            parts.append(f"frames x{self.frames}")
+        return " . ".join(parts) or "single"
+
+
+def layout_for(world: int, rank: int, parallelism: str) -> RankLayout:
+    """`replica` (one sample per rank) | `cfg` (one sample per rank pair) | `cfg+frames` (one sample over up to 8 ranks:
+    2 CFG halves x min(4, world/2) frame groups; with a single rank it degenerates to `replica`)."""
+    if parallelism == "replica" or world == 1:
+        return RankLayout(world, rank)
+    if parallelism == "cfg":
+        return RankLayout(world, rank, cfg=2)
+    if parallelism == "cfg+frames":
+        return RankLayout(world, rank, cfg=2, frames=max(1, min(4, world // 2)))
+    if parallelism == "frames":
+        return RankLayout(world, rank, cfg=1, frames=min(4, world))
+    raise ValueError(f"unknown parallelism {parallelism!r}")
+
+
+class Groups:
+    """The process groups of this rank.  Group creation is collective: EVERY rank constructs this with the same layout
+    (all groups are created by all ranks, in the same order)."""
+
+    def __init__(self, layout: RankLayout):
+        self.layout = layout
+        self.frame_group = self.cfg_pair = None
+        for smp in range(layout.samples):
+            for h in range(layout.cfg):
+                ranks = layout.frame_group_ranks(smp, h)
+                if layout.frames > 1:
+                    g = dist.new_group(ranks)
+                    if layout.rank in ranks:
+                        self.frame_group = g
+            for fg in range(layout.frames):
+                ranks = layout.cfg_pair_ranks(smp, fg)
+                if layout.cfg > 1:
+                    g = dist.new_group(ranks)
+                    if layout.rank in ranks:
+                        self.cfg_pair = g
+
+    def frame_shard(self) -> Optional[FrameShard]:
+        lo = self.layout
+        return FrameShard(lo.frames, lo.frame_group, self.frame_group) if lo.frames > 1 else None
+
+    def guider(self, scale: float) -> VanillaCFG:
+        return ShardedCFG(scale, self.cfg_pair, self.layout.half) if self.layout.cfg > 1 else VanillaCFG(scale)
+
+
+def apply_frame_shard(network, shard: Optional[FrameShard]):
+    """Tell the network (OpenAIWrapperControlLDM3D or ControlledUNetModel3D) that its batches carry this rank's frame
+    group only."""
+    model = getattr(network, "diffusion_model", network)
+    model.frame_shard = shard
+    if hasattr(model, "controlnet"):
+        model.controlnet.frame_shard = shard
+    return network
+
+
+def local_frames(t: torch.Tensor, layout: RankLayout, num_frames: int) -> torch.Tensor:
+    """this rank's frames of a per-frame tensor whose leading dimension is (samples_in_t * num_frames)"""
+    if layout.frames == 1:
+        return t
+    tl = num_frames // layout.frames
+    v = t.view(t.shape[0] // num_frames, num_frames, *t.shape[1:])
+    return v[:, layout.frame_group * tl:(layout.frame_group + 1) * tl].reshape(-1, *t.shape[1:]).contiguous()
+
+
+def shard_conditioning(cond: Dict, layout: RankLayout, num_frames: int) -> Dict:
+    """per-frame conditioning (`concat`, `cond_feat`) cut to this rank's frame group; per-sample entries untouched"""
+    out = dict(cond)
+    for k in ("concat", "cond_feat"):
+        if k in out:
+            out[k] = local_frames(out[k], layout, num_frames)
+    return out
+
+
+def gather_frames(x_local: torch.Tensor, groups: "Groups", num_frames: int) -> torch.Tensor:
+    """all frames of the sample from the frame group (end of the schedule: hand the latent to the first-stage decoder)"""
+    lo = groups.layout
+    if lo.frames == 1:
+        return x_local
+    parts = [torch.empty_like(x_local) for _ in range(lo.frames)]
+    dist.all_gather(parts, x_local.contiguous(), group=groups.frame_group)
+    return torch.cat(parts, dim=0)
+
+
 class ShardedCFG(VanillaCFG):
-    """VanillaCFG over a pair of ranks: rank 2k evaluates the unconditional half, rank 2k+1 the conditional
-    half (the reference's batch order, uncond first: guiders.py:36,40)."""
+    """VanillaCFG over a pair of ranks: one evaluates the unconditional half, the other the conditional half (the
+    reference's batch order, uncond first: guiders.py:36,40).  BOTH ranks of a pair must hold the SAME latent x and sigma:
+    seed the pair with `replica_seed(layout.sample)` (not the rank) or broadcast x from the first rank of the pair —
+    `check_pair_consistency()` asserts it."""
 
     def __init__(self, scale: float, group: dist.ProcessGroup, half: int):
         super().__init__(scale)
@@ -82,3 +221,13 @@ class ShardedCFG(VanillaCFG):
         dist.all_gather(parts, x.contiguous(), group=self.group)
         x_u, x_c = parts
         return x_u + self.scale * (x_c - x_u)
+
+    def check_pair_consistency(self, x: torch.Tensor, sigma: torch.Tensor):
+        """Debug guard for the first step: both ranks of the pair must start from bit-identical (x, sigma) — a caller
+        that seeds per RANK would silently combine eps of two different latents."""
+        digest = torch.stack([x.double().sum(), x.double().abs().sum(), sigma.double().sum()]).to(x.device)
+        parts = [torch.empty_like(digest), torch.empty_like(digest)]
+        dist.all_gather(parts, digest, group=self.group)
+        if not torch.equal(parts[0], parts[1]):
+            raise RuntimeError("ShardedCFG: the two ranks of a CFG pair hold different latents / sigmas; seed the pair with "
+                               "replica_seed(layout.sample) or broadcast the initial latent over the pair group")

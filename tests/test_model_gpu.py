@@ -218,3 +218,53 @@ def test_streams_and_graph_replay_are_bit_identical():
         gh1 = gh(gh(x0, s_in * sig[0], s_in * sig[1]).clone(), s_in * sig[1], s_in * sig[2]).clone()
     torch.cuda.synchronize()
     assert torch.equal(h0, e0) and torch.equal(h1, e1) and torch.equal(gh1, e1)
+
+
+def _rccl_world1_worker(rank, port, out):
+    """frame-shard exchanges through torch.distributed "nccl" (= RCCL) on the MI355X with a one-rank group"""
+    import os
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    sys.path.insert(0, str(root / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    from helpers import cond as cond_of, product_network, step_inputs
+    from panacea_amd import configs as cfgs, engine as E, parallel
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    grp = dist.new_group([0])
+    kw = cfgs.with_frames(cfgs.get("tiny"), 4)
+    w, _, _ = product_network("tiny", "cuda", kw=kw)
+    inp = step_inputs("tiny", kw, "cuda", t_index=500, shape=(2, 4, 8, 96))
+    ref = w(inp["x"], inp["t"], cond_of(inp))
+    sh = E.FrameShard(1, 0, None)
+    sh.group = grp                      # G = 1 over a real RCCL group: all_to_all_single / all_gather run on the GPU
+    parallel.apply_frame_shard(w, sh)
+    got = w(inp["x"], inp["t"], cond_of(inp))
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(got, ref)) and sh.exchanges > 0
+    open(out, "w").write("ok" if ok else f"mismatch {(got - ref).abs().max().item()}")
+    dist.destroy_process_group()
+
+
+def test_frame_shard_code_path_single_device(tmp_path):
+    """SURVEY §8e on ONE GPU: (1) the loop-back FrameShard (G = 1) drives every exchange site of the network — to_pixels /
+    to_frames around the ResBlock3D temporal sites and the STT temporal branch, the embedding-row gather — and must not
+    change a bit; (2) the same through a one-rank RCCL group in a child process (collectives on the HIP stream)."""
+    from panacea_amd import engine as E, parallel
+    kw = configs.with_frames(configs.get("tiny"), 4)
+    w, _, _ = product_network("tiny", DEV, kw=kw)
+    inp = step_inputs("tiny", kw, DEV, t_index=500, shape=(2, 4, 8, 96))
+    ref = w(inp["x"], inp["t"], cond(inp))
+    sh = E.FrameShard(1, 0, None)
+    parallel.apply_frame_shard(w, sh)
+    got = w(inp["x"], inp["t"], cond(inp))
+    torch.cuda.synchronize()
+    assert sh.exchanges >= 20 and torch.equal(got, ref)
+    import torch.multiprocessing as mp
+    out = tmp_path / "rccl.txt"
+    mp.get_context("spawn")
+    mp.spawn(_rccl_world1_worker, args=(29400 + (hash(str(tmp_path)) % 500), str(out)), nprocs=1, join=True)
+    assert out.read_text() == "ok", out.read_text()

@@ -61,6 +61,14 @@ def _worker(rank, world, port, out_dir):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert t.item() == float(world)
     assert parallel.replica_seed(rank) == 3407 + rank
+    # a pair that was seeded per RANK is refused instead of silently combining two different latents
+    g = parallel.ShardedCFG(5.0, groups[rank // 2], rank % 2)
+    g.check_pair_consistency(x0, torch.ones(T))
+    try:
+        g.check_pair_consistency(x0 + rank, torch.ones(T))
+        raise AssertionError("a per-rank latent must be refused")
+    except RuntimeError:
+        pass
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,3 +85,92 @@ def test_cfg_sharding_and_replicas_world2():
     # invariant and this equality is asserted bit-exactly on the GPU (tests/test_model_gpu.py).
     err = (r["sharded"] - r["single"]).abs().max().item()
     assert err <= 5e-3 * r["single"].abs().max().item(), err
+
+
+# ------------------------------------------------------------------------ frame-group sharding
+def _frames_worker(rank, world, port, out_dir, cfg, G, T):
+    """rank grid cfg x G over one sample of the tiny network with T frames: one eps evaluation and a 3-step schedule"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import emu
+    from helpers import cond as cond_of, product_network, step_inputs
+    from panacea_amd import configs, engine as E, parallel, sampling as S
+    parallel.init_distributed("gloo")
+    lo = parallel.RankLayout(world, rank, cfg=cfg, frames=G)
+    assert lo.samples == 1 and lo.name
+    groups = parallel.Groups(lo)
+    shard = groups.frame_shard()
+    kw = configs.with_frames(configs.get("tiny"), T)
+    net, _, _ = product_network("tiny", kw=kw)
+    inp = step_inputs("tiny", kw, t_index=500, shape=(2, T, 8, 96))
+    # --- (1) the exchanges themselves: to_pixels / to_frames against the global tensor
+    Bx, N, C = 2, 48, 8
+    full = torch.arange(Bx * T * N * C, dtype=torch.float32).view(Bx, T, N, C)
+    tl, Np = T // G, N // G
+    mine = full[:, lo.frame_group * tl:(lo.frame_group + 1) * tl].reshape(-1, C)
+    px = shard.to_pixels(mine, Bx, N)
+    assert torch.equal(px.view(Bx, T, Np, C), full[:, :, lo.frame_group * Np:(lo.frame_group + 1) * Np])
+    assert torch.equal(shard.to_frames(px, Bx, N), mine)
+    rows = shard.gather_rows(full[:, lo.frame_group * tl:(lo.frame_group + 1) * tl, 0, :].reshape(-1, C), Bx)
+    assert torch.equal(rows, full[:, :, 0, :].reshape(-1, C))
+    # --- (2) one network evaluation on this rank's frames of this rank's half/halves
+    halves = [lo.half] if cfg == 2 else [0, 1]
+    def pick(t):                                   # per-frame tensor of the CFG batch -> this rank's rows
+        v = t.view(2, T, *t.shape[1:])[halves]
+        return v[:, lo.frame_group * tl:(lo.frame_group + 1) * tl].reshape(-1, *t.shape[1:]).contiguous()
+    loc = {"x": pick(inp["x"]), "t": pick(inp["t"]), "concat": pick(inp["concat"]), "cond_feat": pick(inp["cond_feat"]),
+           "crossattn": inp["crossattn"][halves]}
+    parallel.apply_frame_shard(net, shard)
+    with E.use_backend(emu), torch.no_grad():
+        eps_loc = net(loc["x"], loc["t"], cond_of(loc))
+        assert shard.exchanges > 0 and shard.bytes_sent > 0
+        torch.save({"eps": eps_loc, "halves": halves, "fg": lo.frame_group}, Path(out_dir) / f"eps{rank}.pt")
+        # --- (3) three sampler steps with the layout's guider; the latent stays sharded, gathered once at the end
+        cond = {"crossattn": inp["crossattn"][1:2], "concat": inp["concat"][T:], "cond_feat": inp["cond_feat"][T:]}
+        uc = {"crossattn": inp["crossattn"][0:1], "concat": inp["concat"][:T], "cond_feat": inp["cond_feat"][:T]}
+        den = S.DiscreteDenoiser()
+        denoiser = lambda xi, sigma, cc: den(net, xi, sigma, cc)     # noqa: E731
+        smp = S.EulerEDMSampler(3, guider=groups.guider(5.0), device="cpu")
+        x0 = inp["x"][T:]
+        xs = smp(denoiser, parallel.local_frames(x0, lo, T), parallel.shard_conditioning(cond, lo, T),
+                 parallel.shard_conditioning(uc, lo, T))
+        xs_all = parallel.gather_frames(xs, groups, T)
+        if rank == 0:
+            parallel.apply_frame_shard(net, None)
+            eps_ref = net(inp["x"], inp["t"], cond_of(inp))
+            single = S.EulerEDMSampler(3, guider=S.VanillaCFG(5.0), device="cpu")
+            torch.save({"eps_ref": eps_ref, "traj": xs_all, "traj_ref": single(denoiser, x0.clone(), cond, uc)},
+                       Path(out_dir) / "ref.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,cfg,G,T", [(2, 1, 2, 4), (4, 2, 2, 4), (4, 1, 4, 4)])
+def test_frame_group_sharding_reproduces_the_single_process_eps(world, cfg, G, T):
+    """Frames of a sample over G ranks (x CFG halves): eps of every rank's frames and a 3-step trajectory equal the
+    single-process result.  Tolerance: the torch emulation is not batch-invariant (GEMMs over M/G rows round differently)
+    and a 1e-7 difference decorrelates the fp16 operand rounding downstream — the bound is the stated eps tolerance
+    (1e-3 max-abs, BASELINE.json north_star), the observed difference is ~1e-4."""
+    from panacea_amd.parallel import RankLayout
+    port = 29500 + ((os.getpid() * 7 + world * 13 + G) % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_frames_worker, args=(world, port, d, cfg, G, T), nprocs=world, join=True)
+        ref = torch.load(Path(d) / "ref.pt")
+        eps_ref = ref["eps_ref"].view(2, T, *ref["eps_ref"].shape[1:])
+        tl = T // G
+        worst = 0.0
+        for r in range(world):
+            e = torch.load(Path(d) / f"eps{r}.pt")
+            want = eps_ref[e["halves"]][:, e["fg"] * tl:(e["fg"] + 1) * tl].reshape(e["eps"].shape)
+            worst = max(worst, (e["eps"] - want).abs().max().item())
+        print(f"world {world} cfg {cfg} G {G}: max |eps_sharded - eps_single| = {worst:.3e}")
+        assert worst <= 1e-3
+        err = (ref["traj"] - ref["traj_ref"]).abs().max().item()
+        assert err <= 5e-3 * ref["traj_ref"].abs().max().item(), err
+    lo = RankLayout(8, 5, cfg=2, frames=4)
+    assert (lo.sample, lo.half, lo.frame_group) == (0, 1, 1) and lo.frame_group_ranks(0, 1) == [4, 5, 6, 7]
+    assert lo.cfg_pair_ranks(0, 1) == [1, 5]

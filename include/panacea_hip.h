@@ -206,12 +206,22 @@ int pnc_linear_smallm(const float* a, int lda, const void* W, const float* bias,
  * tabulated by the caller  (diffusionmodules/util.py:224-248) */
 int pnc_timestep_embedding(const int64_t* t, int F, int dim, const float* freqs,
                            float* out, void* stream);
-/* NCHW (fp32) -> channels-last fp16 with optional second source (channel concat)
- * and zero padding to Cpad: out[f][p][c] = c<C1 ? a[f][c][p]*a_scale[f] : c<C1+C2 ? b[f][c-C1][p] : 0
- * (a_scale NULL = 1: the per-frame c_in of DiscreteDenoiser, denoiser.py:27-28, folded into the conversion)
+/* NCHW (fp32) -> channels-last fp16 with optional second source (channel concat) and zero padding to Cpad:
+ *   out[f][p][c] = c<C1 ? a[f % a_frames][c][p]*a_scale[f] : c<C1+C2 ? b[f][c-C1][p] : 0
+ * a_scale NULL = 1: the per-frame c_in of DiscreteDenoiser (denoiser.py:27-28) folded into the conversion; a_frames < F:
+ * `a` holds the latent once and both CFG halves read it (torch.cat([x] * 2), guiders.py:36, without the copy)
  *    -> torch.cat in wrappers.py:41 + layout change */
-int pnc_nchw_to_tokens_f16(const float* a, int C1, const float* a_scale, const float* b, int C2,
+int pnc_nchw_to_tokens_f16(const float* a, int C1, const float* a_scale, int a_frames, const float* b, int C2,
                            int F, int Npix, int Cpad, void* out16, void* out16_lo, void* stream);
+/* Exit of one sampler step on the network's channels-last eps, one pass, reference rounding order:
+ *   D_h    = eps_h * c_out + x                       DiscreteDenoiser + EpsScaling: c_out = -sigma snapped to the table,
+ *                                                    c_skip = 1 (denoiser.py:22-28, denoiser_scaling.py:16-22)
+ *   D      = D_u + scale * (D_c - D_u)               VanillaCFG (guiders.py:25-29); cfg = 0: D = D_c, one half only
+ *   x_next = x + (sigma_next - sigma) * ((x - D) / sigma)      EulerEDMSampler.sampler_step (sampling.py:96-133)
+ * eps_tok [(cfg ? 2 : 1) * T * Npix][ld] fp32, uncond frames first; x, x_next NCHW [T][C][Npix]; c_out, sigma, sigma_next [T]. */
+int pnc_cfg_euler_step(const float* eps_tok, int ld, int T, int Npix, int C, int cfg, float scale,
+                       const float* x, const float* c_out, const float* sigma, const float* sigma_next, float* x_next,
+                       void* stream);
 /* channels-last fp32 [F*Npix][ld] -> NCHW fp32 (first C columns) */
 int pnc_tokens_to_nchw_f32(const float* x, int ld, int F, int Npix, int C,
                            float* out, void* stream);

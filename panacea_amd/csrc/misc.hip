@@ -66,13 +66,14 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int F, 
 
 // thread per (f, pixel): gather channels (stride Npix), write Cpad fp16 contiguous
 __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __restrict__ a, int C1,
-                                                             const float* __restrict__ a_scale,
+                                                             const float* __restrict__ a_scale, int a_frames,
                                                              const float* __restrict__ b, int C2, int F,
                                                              int Npix, int Cpad, half_t* __restrict__ out,
                                                              half_t* __restrict__ out_lo) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)F * Npix) return;
     const int64_t f = i / Npix, pix = i - f * Npix;
+    const int64_t fa = f % a_frames;                 // CFG batch doubling: both halves read the same latent
     const float sa = a_scale ? a_scale[f] : 1.0f;
     half_t* o = out + i * Cpad;
     for (int c0 = 0; c0 < Cpad; c0 += 8) {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __rest
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e;
             float v = 0.0f;
-            if (c < C1) v = a[(f * C1 + c) * Npix + pix] * sa;
+            if (c < C1) v = a[(fa * C1 + c) * Npix + pix] * sa;
             else if (c < C1 + C2) v = b[(f * C2 + (c - C1)) * Npix + pix];
             h[e] = (half_t)v;
             l[e] = (half_t)((v - (float)h[e]) * PNC_LO_SCALE);
@@ -150,7 +151,46 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, c
     }
 }
 
+// Exit of a sampler step: eps tokens of the CFG batch -> next latent, one pass.  The arithmetic
+// follows the reference's sequence of fp32 roundings (no contraction into FMAs), so a trajectory matches the reference's
+// sampler to the last few ulps.
+__global__ __launch_bounds__(256) void cfg_euler_step_kernel(const float* __restrict__ eps, int ld, int T, int Npix, int C,
+                                                             int cfg, float scale, const float* __restrict__ x,
+                                                             const float* __restrict__ c_out,
+                                                             const float* __restrict__ sigma,
+                                                             const float* __restrict__ sigma_next,
+                                                             float* __restrict__ xn) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)T * Npix) return;
+    const int64_t t = i / Npix, pix = i - t * Npix;
+    const float sg = sigma[t], dt = __fsub_rn(sigma_next[t], sg), co = c_out[t];
+    const float* eu = eps + i * ld;                               // uncond half first (guiders.py:36)
+    const float* ec = eps + ((int64_t)(cfg ? T : 0) * Npix + i) * ld;
+    for (int c = 0; c < C; ++c) {
+        const int64_t o = (t * C + c) * Npix + pix;
+        const float xv = x[o];
+        const float dc = __fadd_rn(__fmul_rn(ec[c], co), xv);            // eps * c_out + x * c_skip   (c_skip = 1)
+        float d = dc;
+        if (cfg) {
+            const float du = __fadd_rn(__fmul_rn(eu[c], co), xv);
+            d = __fadd_rn(du, __fmul_rn(scale, __fsub_rn(dc, du)));      // x_u + scale * (x_c - x_u)
+        }
+        const float dir = __fdiv_rn(__fsub_rn(xv, d), sg);               // (x - denoised) / sigma
+        xn[o] = __fadd_rn(xv, __fmul_rn(dt, dir));                       // x + (sigma_next - sigma) * d
+    }
+}
+
 }  // namespace
+
+extern "C" int pnc_cfg_euler_step(const float* eps_tok, int ld, int T, int Npix, int C, int cfg, float scale,
+                                  const float* x, const float* c_out, const float* sigma, const float* sigma_next,
+                                  float* x_next, void* stream) {
+    if (!eps_tok || !x || !c_out || !sigma || !sigma_next || !x_next || T < 1 || Npix < 1 || C < 1 || ld < C) return PNC_EINVAL;
+    const int64_t n = (int64_t)T * Npix;
+    hipLaunchKernelGGL(cfg_euler_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), eps_tok, ld, T, Npix, C, cfg, scale, x, c_out, sigma, sigma_next, x_next);
+    return pnc_launch_status();
+}
 
 extern "C" const char* pnc_version(void) { return "panacea_hip 0.2.0 gfx950"; }
 
@@ -184,14 +224,15 @@ extern "C" int pnc_timestep_embedding(const int64_t* t, int F, int dim, const fl
     return pnc_launch_status();
 }
 
-extern "C" int pnc_nchw_to_tokens_f16(const float* a, int C1, const float* a_scale, const float* b, int C2,
+extern "C" int pnc_nchw_to_tokens_f16(const float* a, int C1, const float* a_scale, int a_frames, const float* b, int C2,
                                       int F, int Npix, int Cpad, void* out16, void* out16_lo, void* stream) {
     if (!a || !out16 || F < 1 || Npix < 1 || C1 < 1 || C2 < 0 || (C2 > 0 && !b)) return PNC_EINVAL;
+    if (a_frames < 1 || a_frames > F) return PNC_EINVAL;
     if (Cpad % 8 || Cpad < C1 + C2) return PNC_EINVAL;
     if (((uintptr_t)out16 | (uintptr_t)out16_lo) & 15) return PNC_EALIGN;
     const int64_t n = (int64_t)F * Npix;
     hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), a, C1, a_scale, b, C2, F, Npix, Cpad,
+                       reinterpret_cast<hipStream_t>(stream), a, C1, a_scale, a_frames, b, C2, F, Npix, Cpad,
                        reinterpret_cast<half_t*>(out16), reinterpret_cast<half_t*>(out16_lo));
     return pnc_launch_status();
 }

@@ -77,8 +77,9 @@ class Precision:
 
 
 FAST = Precision()
-# eps max-abs < 1e-3 at BASELINE config 3: every class except the ResBlock conv inputs
-PRECISE = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True, gnt=True, conv_mid=True)
+# eps max-abs < 1e-3 at BASELINE config 3: every class except the ResBlock conv inputs (36 ms of conv3x3
+# for 5 % of the variance) and the hint stem's inner activations (4 ms for 2 %)
+PRECISE = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True, gnt=True)
 PRECISE_ALL = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True, gn_res=True, gnt=True, conv_mid=True)
 PRECISIONS = {"fast": FAST, "precise": PRECISE, "precise-all": PRECISE_ALL}
 

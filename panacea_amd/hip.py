@@ -84,7 +84,8 @@ _SIGNATURES = {
     "pnc_layernorm": (_I, [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P]),
     "pnc_linear_smallm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "pnc_timestep_embedding": (_I, [_P, _I, _I, _P, _P, _P]),
-    "pnc_nchw_to_tokens_f16": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "pnc_nchw_to_tokens_f16": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "pnc_cfg_euler_step": (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "pnc_tokens_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pnc_concat_add": (_I, [_P, _I, _P, _P, _I, _L, _P, _P, _P, _P]),
     "pnc_add_f32": (_I, [_P, _P, _L, _P, _P, _P, _P]),
@@ -316,10 +317,16 @@ def timestep_embedding(t_i64, F, dim, freqs, out32):
            "pnc_timestep_embedding")
 
 
-def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16, out16_lo=None, a_scale=None):
+def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16, out16_lo=None, a_scale=None, a_frames=0):
     _check(_timed("layout", 0.0, F * Npix * (4.0 * (C1 + C2) + 2.0 * Cpad), load().pnc_nchw_to_tokens_f16, _ptr(a32),
-                  C1, _ptr(a_scale), _ptr(b32), C2, F, Npix, Cpad, _ptr(out16), _ptr(out16_lo), _stream()),
+                  C1, _ptr(a_scale), a_frames or F, _ptr(b32), C2, F, Npix, Cpad, _ptr(out16), _ptr(out16_lo), _stream()),
            "pnc_nchw_to_tokens_f16")
+
+
+def cfg_euler_step(eps_tok, ld, T, Npix, Cch, cfg, scale, x, c_out, sigma, sigma_next, x_next):
+    _check(_timed("elementwise", 0.0, T * Npix * Cch * (16.0 if cfg else 12.0), load().pnc_cfg_euler_step, _ptr(eps_tok), ld, T,
+                  Npix, Cch, int(cfg), float(scale), _ptr(x), _ptr(c_out), _ptr(sigma), _ptr(sigma_next), _ptr(x_next),
+                  _stream()), "pnc_cfg_euler_step")
 
 
 def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):

@@ -210,9 +210,15 @@ class ControlledUNetModel3D(UNetModel3D):
             return torch.cat(outs, dim=0)
         return self._denoise_one(x, timesteps, context, hint, trace, 0)
 
-    def _denoise_one(self, x, timesteps, context, hint, trace, side_idx, inv=None) -> torch.Tensor:
+    def denoise_tokens(self, x, c_in, timesteps, context, concat, hint, invariants=None) -> Act:
+        """Fused sampler entry: `x` is the UNSCALED latent of one CFG half, `c_in` the per-frame input scale of
+        the whole batch, `concat` the batch's conditioning latents; returns eps as channels-last fp32 tokens (Act.f32
+        [F*h*w, 4]) for pnc_cfg_euler_step.  Same network evaluation as `denoise(cat(x * c_in, concat), ...)`."""
+        return self._denoise_one(x, timesteps, context, hint, None, 0, invariants, fused=(c_in, concat))
+
+    def _denoise_one(self, x, timesteps, context, hint, trace, side_idx, inv=None, fused=None):
         with torch.no_grad():
-            rt = runtime_for(x, self.num_frames, self.frame_shard)
+            rt = runtime_for(x if fused is None else fused[1], self.num_frames, self.frame_shard)
             rt.prec = E.precision(self.precision)
             rt.trace = trace
             if inv is not None:
@@ -221,7 +227,7 @@ class ControlledUNetModel3D(UNetModel3D):
                 rt.guided = inv.guided
             else:
                 rt.set_context(context)
-            x16 = self._stem_tokens(rt, x)
+            x16 = self._stem_tokens(rt, x) if fused is None else self._stem_tokens(rt, x, fused[1], fused[0])
             cn = self.controlnet
             hint32 = hint if inv is not None else hint.detach().to(torch.float32).contiguous()
             # frame-sharded runs issue collectives from both networks: one stream keeps their order identical on all ranks
@@ -239,14 +245,14 @@ class ControlledUNetModel3D(UNetModel3D):
                     for c in control:
                         c.f32.record_stream(main)
                     return control
-                out = self._run_unet(rt, x16, self._time_embedding(rt, timesteps), join)
+                out = self._run_unet(rt, x16, self._time_embedding(rt, timesteps), join, tokens=fused is not None)
             else:
                 control = cn._run_control(rt, x16, hint32, cn._time_embedding(rt, timesteps))
                 if trace is not None:
                     for j, c in enumerate(control):
                         trace[f"control.{j}"] = c.to_nchw()
-                out = self._run_unet(rt, x16, self._time_embedding(rt, timesteps), control)
-        return out.to(x.dtype)
+                out = self._run_unet(rt, x16, self._time_embedding(rt, timesteps), control, tokens=fused is not None)
+        return out if fused is not None else out.to(x.dtype)
 
 
 class StepInvariants:

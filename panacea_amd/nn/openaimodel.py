@@ -420,23 +420,32 @@ class UNetModel3D(nn.Module, Packable):
             rt.emb_all = rt.shard.gather_rows(emb, rt.B)
         return emb
 
-    def _head(self, rt: Runtime, h: Act) -> torch.Tensor:
-        """self.out: GN + SiLU + conv3x3 -> NCHW fp32 (:1245-1253, controlmodel.py:197-202)."""
+    def _head(self, rt: Runtime, h: Act, tokens: bool = False):
+        """self.out: GN + SiLU + conv3x3 -> NCHW fp32 (:1245-1253, controlmodel.py:197-202); `tokens`: the channels-last
+        fp32 tokens instead (consumed by the fused sampler-step exit, pnc_cfg_euler_step)."""
         pk = self.packed()
         a16, a16lo = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, pk["og"], pk["ob"], 1e-5, True, split=rt.prec.gn_head)
         o = run_conv3x3(rt, a16, h.F, h.H, h.W, h.C, pk["ow"], pk["oc"], self.out_channels, x16_lo=a16lo)
+        if tokens:
+            return o
         out = rt.empty((h.F, self.out_channels, h.H, h.W), torch.float32)
         rt.be.tokens_to_nchw_f32(o.f32, self.out_channels, h.F, h.N, self.out_channels, out)
         return out
 
-    def _stem_tokens(self, rt: Runtime, x: torch.Tensor) -> Act:
-        """NCHW network input -> channels-last fp16 tokens (channel count padded to 8)."""
-        F, C, H, W = x.shape
-        cp = (C + 7) // 8 * 8
+    def _stem_tokens(self, rt: Runtime, x: torch.Tensor, concat: Optional[torch.Tensor] = None,
+                     scale: Optional[torch.Tensor] = None) -> Act:
+        """NCHW network input -> channels-last fp16 tokens (channel count padded to 8).  Fused sampler entry: `x` is the
+        latent of ONE CFG half (x.shape[0] divides the batch: both halves read it), scaled per frame by `scale` (c_in of
+        DiscreteDenoiser), with `concat` appended on the channel axis (wrappers.py:41) — no torch.cat, no x * c_in pass."""
+        Fx, C, H, W = x.shape
+        F = Fx if concat is None else concat.shape[0]
+        C2 = 0 if concat is None else concat.shape[1]
+        cp = (C + C2 + 7) // 8 * 8
         x32 = x.detach().to(torch.float32).contiguous()
+        b32 = None if concat is None else concat.detach().to(torch.float32).contiguous()
         t16 = rt.empty((F * H * W, cp), torch.float16)
         t16lo = rt.empty((F * H * W, cp), torch.float16) if rt.prec.stem else None
-        rt.be.nchw_to_tokens_f16(x32, C, None, 0, F, H * W, cp, t16, t16lo)
+        rt.be.nchw_to_tokens_f16(x32, C, b32, C2, F, H * W, cp, t16, t16lo, a_scale=scale, a_frames=Fx)
         return Act(F, H, W, cp, f16=t16, f16_lo=t16lo)
 
     def _own_blocks(self):
@@ -444,7 +453,7 @@ class UNetModel3D(nn.Module, Packable):
             if hasattr(self, name):
                 yield getattr(self, name)
 
-    def _run_unet(self, rt: Runtime, x16: Act, emb32: torch.Tensor, control) -> torch.Tensor:
+    def _run_unet(self, rt: Runtime, x16: Act, emb32: torch.Tensor, control, tokens: bool = False):
         """controlmodel.py:186-202 / openaimodel.py:1305-1319 on tokens.  `control` is None, the list of ControlNet
         residuals, or a callable returning that list (called after the middle block: the join point when the
         ControlNet runs on a second stream)."""
@@ -478,7 +487,7 @@ class UNetModel3D(nn.Module, Packable):
             h = module._run(rt, Act(h.F, h.H, h.W, ct, f32=cat32, f16=cat16, f16_lo=cat16lo), emb32)
             if rt.trace is not None:
                 rt.trace[f"output_blocks.{i}"] = h.to_nchw()
-        return self._head(rt, h)
+        return self._head(rt, h, tokens)
 
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         """openaimodel.py:1279-1319 — x (B*T, C, h, w), timesteps (B*T,), context (B, 77, D)."""

@@ -110,8 +110,22 @@ class VanillaCFG:
         return torch.cat([x] * 2), torch.cat([s] * 2), c_out
 
 
+class BoundDenoiser:
+    """`lambda input, sigma, c: denoiser(model, input, sigma, c)` of DiffusionEngine3D.sample (diffusion.py:251-253) as an
+    object: the sampler can see which denoiser and which network it drives and run the whole step on the device — the
+    c_in scaling and the CFG batch doubling folded into the network's entry kernel, c_out / c_skip + CFG combine + Euler
+    update in ONE exit kernel on the network's channels-last output.  Calling it is exactly the lambda."""
+
+    def __init__(self, denoiser: "DiscreteDenoiser", network):
+        self.denoiser, self.network = denoiser, network
+
+    def __call__(self, x, sigma, cond):
+        return self.denoiser(self.network, x, sigma, cond)
+
+
 class EulerEDMSampler:
     """sampling.py:27-133,214-218 with s_churn = 0 (deterministic; == DDIM for eps-prediction)."""
+    fuse = True          # use the fused device step when the denoiser is a BoundDenoiser around the HIP network
 
     def __init__(self, num_steps: int, guider: Optional[VanillaCFG] = None, discretization=None, device="cuda"):
         self.num_steps = num_steps
@@ -127,7 +141,44 @@ class EulerEDMSampler:
             return denoiser(x, sigma, cond)
         return self.guider(denoiser(*self.guider.prepare_inputs(x, sigma, cond, uc)), sigma)
 
+    def _fusable(self, denoiser, x, cond) -> bool:
+        if not (self.fuse and isinstance(denoiser, BoundDenoiser) and x.is_cuda):
+            return False
+        model = getattr(denoiser.network, "diffusion_model", None)
+        den = denoiser.denoiser
+        return (hasattr(model, "denoise_tokens") and getattr(model, "frame_shard", None) is None
+                and type(self.guider) in (VanillaCFG, type(None)) and isinstance(den, DiscreteDenoiser)
+                and isinstance(den.scaling, EpsScaling) and den.quantize_c_noise
+                and "concat" in cond and cond.get("vector") is None)
+
+    def _fused_step(self, sigma, next_sigma, denoiser, x, cond, uc):
+        """One step with three tiny torch ops (table snap of T sigmas) + the network + one exit kernel; same arithmetic, in
+        the reference's rounding order, as denoise() + the Euler update below."""
+        from . import engine as E
+        den, model = denoiser.denoiser, denoiser.network.diffusion_model
+        T = x.shape[0]
+        idx = den.sigma_to_idx(sigma)
+        sig_q = den.idx_to_sigma(idx)                                 # denoiser.py:24
+        c_in = 1 / (sig_q ** 2 + 1.0) ** 0.5
+        c_noise = den.sigma_to_idx(sig_q)                             # quantised c_noise = the table index
+        if self.guider is None:
+            cat, inv, nh = cond, cond.get("_invariants"), 1
+        else:
+            pre = cond.get("_cat")
+            cat = pre if pre is not None else {k: torch.cat((uc[k], cond[k]), 0) for k in ("crossattn", "concat", "cond_feat")}
+            inv, nh = cond.get("_invariants"), 2
+        ctx = cat["crossattn"].to(model.controlnet.input_hint_block[0].weight.dtype)
+        eps = model.denoise_tokens(x, c_in.repeat(nh).contiguous(), c_noise.repeat(nh).contiguous(), ctx, cat["concat"],
+                                   cat["cond_feat"], invariants=inv)
+        x32 = x.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(x32)
+        E.backend().cfg_euler_step(eps.f32, eps.C, T, eps.N, x.shape[1], nh == 2, float(self.guider.scale) if nh == 2 else 0.0,
+                                   x32, (-sig_q).contiguous(), sigma.contiguous(), next_sigma.contiguous(), out)
+        return out.to(x.dtype)
+
     def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc=None):
+        if self._fusable(denoiser, x, cond):
+            return self._fused_step(sigma, next_sigma, denoiser, x, cond, uc)
         denoised = self.denoise(x, denoiser, sigma, cond, uc)
         d = (x - denoised) / append_dims(sigma, x.ndim)
         return x + append_dims(next_sigma - sigma, x.ndim) * d

@@ -240,9 +240,10 @@ def timestep_embedding(t_i64, F, dim, freqs, out32):
     out32.reshape(-1)[: F * dim].view(F, dim)[:, : 2 * (dim // 2)].copy_(emb)
 
 
-def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16, out16_lo=None, a_scale=None):
+def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16, out16_lo=None, a_scale=None, a_frames=0):
     v = torch.zeros((F, Npix, Cpad), dtype=torch.float32, device=a32.device)
-    a = a32.reshape(F, C1, Npix).float()
+    af = a_frames or F
+    a = a32.reshape(af, C1, Npix).float().repeat(F // af, 1, 1)
     if a_scale is not None:
         a = a * a_scale.reshape(F, 1, 1).float()
     v[:, :, :C1] = a.permute(0, 2, 1)
@@ -252,6 +253,17 @@ def nchw_to_tokens_f16(a32, C1, b32, C2, F, Npix, Cpad, out16, out16_lo=None, a_
     out16.reshape(-1)[: F * Npix * Cpad].view(F, Npix, Cpad).copy_(h)
     if out16_lo is not None:
         out16_lo.reshape(-1)[: F * Npix * Cpad].view(F, Npix, Cpad).copy_(_lo(v, h))
+
+
+def cfg_euler_step(eps_tok, ld, T, Npix, Cch, cfg, scale, x, c_out, sigma, sigma_next, x_next):
+    """the reference's op sequence (denoiser.py:22-28, guiders.py:25-29, sampling.py:96-133) on channels-last eps"""
+    E = _mat(eps_tok, (2 if cfg else 1) * T * Npix, Cch, ld).view(-1, T, Npix, Cch).permute(0, 1, 3, 2)   # [halves, T, C, Npix]
+    X = x.reshape(T, Cch, Npix)
+    sg = sigma.reshape(T, 1, 1)
+    D = E * c_out.reshape(T, 1, 1) + X
+    Dn = D[0] + scale * (D[1] - D[0]) if cfg else D[0]
+    d = (X - Dn) / sg
+    x_next.reshape(T, Cch, Npix).copy_(X + (sigma_next.reshape(T, 1, 1) - sg) * d)
 
 
 def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):

@@ -268,3 +268,37 @@ def test_frame_shard_code_path_single_device(tmp_path):
     mp.get_context("spawn")
     mp.spawn(_rccl_world1_worker, args=(29400 + (hash(str(tmp_path)) % 500), str(out)), nprocs=1, join=True)
     assert out.read_text() == "ok", out.read_text()
+
+
+def test_fused_sampler_step_on_device_replays_the_reference_trajectory():
+    """SURVEY §8 f1 on the GPU: (1) pnc_cfg_euler_step replays the reference's 3- and 25-step Euler/CFG trajectory
+    (tests/golden/sampler.npz, produced by the reference's own sampler / denoiser / guider classes); (2) the fused
+    sampler step of the product (BoundDenoiser: c_in + CFG doubling in the entry kernel, one exit kernel) gives the bits
+    of the plain step, eagerly and replayed from a hipGraph."""
+    import test_sampling as ts
+    from panacea_amd import sampling as S
+    from panacea_amd.graph import GraphedStep
+    for n in (3, 25):
+        xs = ts._trajectory_through_exit_kernel(hip, n, DEV)
+        assert np.allclose(xs.cpu().numpy(), ts.G[f"sampler.{n}.x_final"], atol=2e-5, rtol=1e-5)
+    w, _, kw = product_network("tiny", DEV)
+    inp = step_inputs("tiny", kw, DEV)
+    T = kw["num_frames"]
+    c = {"crossattn": inp["crossattn"][1:2], "concat": inp["concat"][T:], "cond_feat": inp["cond_feat"][T:]}
+    uc = {"crossattn": inp["crossattn"][0:1], "concat": inp["concat"][:T], "cond_feat": inp["cond_feat"][:T]}
+    den = S.DiscreteDenoiser().to(DEV)
+    smp = S.EulerEDMSampler(3, guider=S.VanillaCFG(5.0), device=DEV)
+    sig = smp.sigmas()
+    x0 = inp["x"][T:] * 14.6
+    s_in = x0.new_ones([T])
+    bd = S.BoundDenoiser(den, w)
+    with torch.no_grad():
+        assert smp._fusable(bd, x0, c)
+        fused = smp.sampler_step(s_in * sig[0], s_in * sig[1], bd, x0, c, uc)
+        smp.fuse = False
+        plain = smp.sampler_step(s_in * sig[0], s_in * sig[1], bd, x0, c, uc)
+        smp.fuse = True
+        g = GraphedStep(lambda xi, s0, s1: smp.sampler_step(s0, s1, bd, xi, c, uc), x0, s_in * sig[0], s_in * sig[1])
+        graphed = g(x0, s_in * sig[0], s_in * sig[1]).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(fused, plain) and torch.equal(graphed, plain)

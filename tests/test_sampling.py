@@ -100,3 +100,62 @@ def test_share_noise_init_matches_the_engine_formula():
     ref = randn + concat[-1][None].repeat(8, 1, 1, 1) * 0.07
     assert torch.equal(S.share_noise_init(randn, concat, 0.07), ref)
     assert S.share_noise_init(randn, concat, 0.0) is randn
+
+
+def _trajectory_through_exit_kernel(be, n, dev):
+    """the reference trajectory with the step's tail (c_out / c_skip, CFG combine, Euler update) done by ONE call of the
+    backend's cfg_euler_step on channels-last eps tokens, as the fused sampler step does"""
+    x0, c, uc = _inputs()
+    x0 = x0.to(dev)
+    c, uc = {k: v.to(dev) for k, v in c.items()}, {k: v.to(dev) for k, v in uc.items()}
+    den = S.DiscreteDenoiser().to(dev)
+    sig = S.LegacyDDPMDiscretization()(n, device=dev)
+    T, C, H, W = x0.shape
+    x = x0 * torch.sqrt(1.0 + sig[0] ** 2.0)
+    s_in = x.new_ones([T])
+    for i in range(n):
+        sigma, nxt = s_in * sig[i], s_in * sig[i + 1]
+        idx = den.sigma_to_idx(sigma)
+        sq = den.idx_to_sigma(idx)
+        c_in = (1 / (sq ** 2 + 1.0) ** 0.5)[:, None, None, None]
+        t = den.sigma_to_idx(sq)
+        cat = {k: torch.cat((uc[k], c[k]), 0) for k in c}                       # VanillaCFG.prepare_inputs (uncond first)
+        eps = fake_network(torch.cat([x * c_in] * 2), torch.cat([t] * 2), cat)
+        tok = eps.permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+        out = torch.empty_like(x)
+        be.cfg_euler_step(tok, C, T, H * W, C, True, 5.0, x.contiguous(), (-sq).contiguous(), sigma, nxt, out)
+        x = out
+    return x
+
+
+def test_exit_kernel_replays_the_reference_trajectory_on_the_emulation():
+    import emu
+    for n in (3, 25):
+        xs = _trajectory_through_exit_kernel(emu, n, "cpu")
+        assert np.allclose(xs.numpy(), G[f"sampler.{n}.x_final"], atol=2e-5, rtol=1e-5)
+
+
+def test_fused_step_is_the_plain_step_on_the_emulation():
+    """BoundDenoiser + EulerEDMSampler._fused_step (c_in and the CFG batch doubling in the entry kernel, one exit kernel) vs
+    the plain sampler_step (torch ops of the reference): same bits, also with hoisted step invariants."""
+    import emu
+    from helpers import product_network, step_inputs
+    from panacea_amd import engine as E
+    w, _, kw = product_network("tiny")
+    inp = step_inputs("tiny", kw)
+    T = kw["num_frames"]
+    c = {"crossattn": inp["crossattn"][1:2], "concat": inp["concat"][T:], "cond_feat": inp["cond_feat"][T:]}
+    uc = {"crossattn": inp["crossattn"][0:1], "concat": inp["concat"][:T], "cond_feat": inp["cond_feat"][:T]}
+    den = S.DiscreteDenoiser()
+    smp = S.EulerEDMSampler(3, guider=S.VanillaCFG(5.0), device="cpu")
+    sig = smp.sigmas()
+    x0 = inp["x"][T:] * 14.6
+    s_in = x0.new_ones([T])
+    bd = S.BoundDenoiser(den, w)
+    with E.use_backend(emu), torch.no_grad():
+        assert not smp._fusable(bd, x0, c)                    # CPU tensors: the product path never fuses off-device
+        plain = smp.sampler_step(s_in * sig[0], s_in * sig[1], bd, x0, c, uc)
+        fused = smp._fused_step(s_in * sig[0], s_in * sig[1], bd, x0, c, uc)
+        c2, u2 = S.hoist_invariants(w, smp.guider, c, uc)
+        fused_h = smp._fused_step(s_in * sig[0], s_in * sig[1], bd, x0, c2, u2)
+    assert torch.equal(plain, fused) and torch.equal(fused, fused_h)

@@ -146,9 +146,63 @@ def bench_norm(flt):
             report(tag, timeit(lambda: hip.layernorm(x, C, M, C, g, b, 1e-5, y, C)), bytes_=M * C * 6.0)
 
 
+def bench_tiles(flt):
+    """every GEMM shape of the network's transformer blocks on every tile geometry (pnc_set_option PNC_OPT_GEMM_TILE):
+    the table the score-based tile choice of gemm_kernel.h is tuned from"""
+    names = {0: "auto", 1: "128x128", 2: "256x128", 3: "256x320", 4: "256x256"}
+    for li, (C, H, W) in enumerate(LEVELS):
+        M = F * H * W
+        for name, N, K, kind in [("qkv", 3 * C, C, "vt"), ("q", C, C, "o16"), ("proj", C, C, "res"), ("ff1", 8 * C, C, "geglu"),
+                                 ("ff2", C, 4 * C, "res"), ("conv1d", C, 3 * C, "conv1d"), ("conv3x3", C, 9 * C, "conv3x3")]:
+            tag = f"tiles L{li} {name} M={M} N={N} K={K}"
+            if flt and flt not in tag:
+                continue
+            w = h16(N, K)
+            bias = torch.zeros(N, device=DEV)
+            if kind == "conv3x3":
+                a = h16(F, H, W, C)
+            else:
+                a = h16(M, K if kind != "conv1d" else C)
+            o32 = torch.zeros(M, N if kind != "geglu" else 8, device=DEV) if kind in ("res", "conv1d", "conv3x3") else None
+            o16 = torch.empty(M, (N // 2 if kind == "geglu" else (2 * C if kind == "vt" else N)), device=DEV, dtype=torch.float16) \
+                if kind in ("vt", "o16", "geglu") else None
+            vt = torch.empty(F, C, H * W, device=DEV, dtype=torch.float16) if kind == "vt" else None
+            emb = torch.zeros(F, N, device=DEV)
+
+            def fn():
+                if kind == "vt":
+                    hip.gemm(a, w, M=M, N=N, K=K, lda=K, out16=o16, ldc16=2 * C, out16t=vt, ldt=H * W, t_rows=H * W,
+                             t_gstride=C * H * W, n_split=2 * C)
+                elif kind == "o16":
+                    hip.gemm(a, w, M=M, N=N, K=K, lda=K, out16=o16, ldc16=N)
+                elif kind == "res":
+                    hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, res1=o32, ldr1=N, out32=o32, ldc32=N)
+                elif kind == "geglu":
+                    hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, geglu=True, out16=o16, ldc16=N // 2)
+                elif kind == "conv1d":
+                    hip.gemm(a, w, M=M, N=N, K=K, a_mode=hip.A_CONV1D_T, tconv=dict(C=C, T=8, Npix=H * W), bias=bias,
+                             rowbias=emb, rb_rows=H * W, rb_mod=F, res1=o32, ldr1=N, out32=o32, ldc32=N)
+                else:
+                    hip.gemm(a, w, M=M, N=N, K=K, a_mode=hip.A_CONV3X3, bias=bias, out32=o32, ldc32=N,
+                             conv=dict(Cin=C, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0))
+            res = []
+            for t in (0, 1, 2, 3, 4):
+                prev = hip.set_option(hip.OPT_GEMM_TILE, t)
+                try:
+                    res.append((names[t], timeit(fn, iters=12, warm=2)))
+                finally:
+                    hip.set_option(hip.OPT_GEMM_TILE, prev)
+            fl = 2.0 * M * N * K
+            print(f"{tag:48s} " + "  ".join(f"{n} {tt * 1e6:7.1f}us {fl / tt / 1e12:6.1f}TF" for n, tt in res), flush=True)
+            del a, w
+
+
 if __name__ == "__main__":
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     print(torch.cuda.get_device_name(0))
+    if flt.startswith("tiles"):
+        bench_tiles(sys.argv[2] if len(sys.argv) > 2 else "")
+        sys.exit(0)
     bench_gemm(flt)
     bench_attn(flt)
     bench_norm(flt)

@@ -1,0 +1,60 @@
+"""HBM-side traffic of one denoising step from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass:
+TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots"), calibrated on the LayerNorm launches whose byte count is known
+(the guide: FETCH_SIZE under-counts wide loads by 2 on gfx950, WRITE_SIZE uncalibrated).
+
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <evaluations> <precision> <command string>
+
+Reads the counter_collection CSVs under the two rocprofv3 output directories, prints per-kernel tables and merges a record
+    records[precision] = {build_stamp, fetch/write factors, traffic_GB_calibrated, ...}
+into profiles/round2/pmc_traffic.json, which bench.py reports as roofline.traffic ONLY while the build stamp matches.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+# all LayerNorm launches of one network evaluation at BASELINE config 3: 207 launches, 6 B per element in total
+# (4 B fp32 read + 2 B fp16 write); element count from the module tree: 9 LN per STT x (5 + 2 STT at L0 ...) -- taken from
+# bench.py's own kernel breakdown (layernorm bytes = 6 * elements): 41.9 GB per evaluation
+LN_BYTES_PER_EVAL = 42.04e9
+
+
+def per_kernel(d, counter):
+    agg = collections.defaultdict(float)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                agg[r["Kernel_Name"]] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    fdir, wdir, evals, prec, cmd = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")      # KB
+    ln_f = sum(v for k, v in fetch.items() if "layernorm" in k) * 1024 / evals
+    ln_w = sum(v for k, v in write.items() if "layernorm" in k) * 1024 / evals
+    ff, wf = (LN_BYTES_PER_EVAL * 4 / 6) / ln_f, (LN_BYTES_PER_EVAL * 2 / 6) / ln_w
+    tf, tw = sum(fetch.values()) * 1024 / evals, sum(write.values()) * 1024 / evals
+    rec = {"build_stamp": (ROOT / "panacea_amd" / "lib" / "build.stamp").read_text().strip(), "command": cmd,
+           "evaluations": evals, "fetch_factor": round(ff, 3), "write_factor": round(wf, 3),
+           "fetch_GB_raw": round(tf / 1e9, 1), "write_GB_raw": round(tw / 1e9, 1),
+           "fetch_GB_calibrated": round(tf * ff / 1e9, 1), "write_GB_calibrated": round(tw * wf / 1e9, 1),
+           "traffic_GB_calibrated": round((tf * ff + tw * wf) / 1e9, 1),
+           "calibration": f"LayerNorm launches: {LN_BYTES_PER_EVAL / 1e9:.1f} GB known per evaluation vs counters "
+                          f"{ln_f / 1e9:.2f} GB fetched / {ln_w / 1e9:.2f} GB written"}
+    out = ROOT / "profiles" / "round2" / "pmc_traffic.json"
+    out.parent.mkdir(parents=True, exist_ok=True)
+    doc = json.loads(out.read_text()) if out.exists() else {"records": {}}
+    doc["records"][prec] = rec
+    out.write_text(json.dumps(doc, indent=1))
+    print(json.dumps(rec, indent=1))
+    for name, agg, fac in (("fetch", fetch, ff), ("write", write, wf)):
+        lines = [f"{k[:100]:100s} {v * 1024 * fac / evals / 1e9:9.2f} GB/eval" for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:50]]
+        (out.parent / f"pmc_{prec}_{name}_by_kernel.txt").write_text("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -24,13 +24,25 @@ VIEW_SLOT = {"CAM_FRONT": 0, "CAM_FRONT_RIGHT": 1, "CAM_BACK_RIGHT": 5, "CAM_BAC
              "CAM_FRONT_LEFT": 2}
 
 
-def read_state_dict(path: str) -> Dict[str, torch.Tensor]:
-    """The flat `name -> tensor` dict of a checkpoint file, in the three formats of inference.py:205-214."""
+def read_state_dict(path: str, trust: bool = False) -> Dict[str, torch.Tensor]:
+    """The flat `name -> tensor` dict of a checkpoint file, in the three formats of inference.py:205-214.
+    `.ckpt` files are unpickled with weights_only=True first; Lightning / DeepSpeed checkpoints that carry other objects
+    (OmegaConf `hyper_parameters`, callback / loop state) need the full unpickler the reference uses
+    (inference.py:209: `torch.load(ckpt, map_location="cpu")`) — that executes code from the file, so it is only done when
+    the caller says the file is trusted (`trust=True`)."""
     if path.endswith("safetensors"):
         from safetensors.torch import load_file
         return load_file(path)
     if path.endswith("ckpt"):
-        sd = torch.load(path, map_location="cpu", weights_only=True)
+        import pickle
+        try:
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as e:
+            if not trust:
+                raise pickle.UnpicklingError(
+                    f"{path} holds objects beyond tensors (e.g. Lightning hyper_parameters); pass trust=True to unpickle it "
+                    f"fully like the reference does (only for files you trust): {e}") from e
+            sd = torch.load(path, map_location="cpu", weights_only=False)
         if isinstance(sd, dict) and "state_dict" in sd and not any(torch.is_tensor(v) for v in sd.values()):
             sd = sd["state_dict"]                                   # Lightning
         return {k.replace("_forward_module.", ""): v for k, v in sd.items() if torch.is_tensor(v)}   # DeepSpeed
@@ -45,10 +57,10 @@ def denoiser_state_dict(sd: Dict[str, torch.Tensor], prefix: str = DENOISER_PREF
     return out
 
 
-def load_denoiser(wrapper: torch.nn.Module, path: str, verbose: bool = True) -> Tuple[List[str], List[str]]:
+def load_denoiser(wrapper: torch.nn.Module, path: str, verbose: bool = True, trust: bool = False) -> Tuple[List[str], List[str]]:
     """Load a reference checkpoint into `wrapper.diffusion_model` (strict=False, inference.py:216-226).
     Returns (missing, unexpected).  Packed kernel-layout copies are invalidated by the load hook."""
-    sd = denoiser_state_dict(read_state_dict(path))
+    sd = denoiser_state_dict(read_state_dict(path, trust=trust))
     res = wrapper.diffusion_model.load_state_dict({k: v.to(torch.float32) for k, v in sd.items()}, strict=False)
     missing, unexpected = list(res.missing_keys), list(res.unexpected_keys)
     if verbose:

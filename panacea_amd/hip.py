@@ -115,6 +115,13 @@ def load():
         raise HipLibraryError(
             f"{LIB_PATH} is missing: the HIP extension is the only compute path of panacea_amd. "
             "Build it with `python -m panacea_amd.build` (hipcc --offload-arch=gfx950).")
+    if not os.environ.get("PANACEA_HIP_LIB"):
+        # a library older than the sources next to it is an ABI hazard (argument lists change): refuse it, do not guess
+        from . import build as _build
+        stamp = LIB_PATH.parent / "build.stamp"
+        if _build.CSRC.exists() and (not stamp.exists() or stamp.read_text().strip() != _build._digest()):
+            raise HipLibraryError(f"{LIB_PATH} was built from other sources than panacea_amd/csrc holds now; "
+                                  "rebuild it with `python -m panacea_amd.build`")
     try:
         lib = C.CDLL(str(LIB_PATH))
     except OSError as e:  # pragma: no cover
@@ -190,23 +197,23 @@ def _check(rc: int, what: str):
 
 
 def _stream() -> int:
+    """the CURRENT torch stream of the CURRENT device: every wrapper launches there, and `_ptr` refuses operands that
+    live on another device (a launch on device A's stream with device B's pointers reads garbage without an error)"""
     return torch.cuda.current_stream().cuda_stream
 
 
-def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+def _ptr(t: Optional[torch.Tensor], dtype=None, name: str = "operand") -> Optional[int]:
     if t is None:
         return None
     if not t.is_cuda:
         raise PncError("panacea_amd kernels need tensors resident in HBM (got a CPU tensor); "
                        "there is no CPU fallback")
-    return t.data_ptr()
-
-
-def _need(t: torch.Tensor, dtype, name: str):
-    if t.dtype != dtype:
+    if t.device.index != torch.cuda.current_device():
+        raise PncError(f"{name} lives on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}: "
+                       "select the tensors' device (torch.cuda.device / set_device) before calling the kernels")
+    if dtype is not None and t.dtype != dtype:
         raise PncError(f"{name}: expected {dtype}, got {t.dtype}")
-    if not t.is_contiguous():
-        raise PncError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -226,8 +233,9 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
     """`a16_lo` / `out16_lo`: lo planes of precise (split) operands, see PncGemmParams.A_lo in the header."""
     p = GemmParams()
     p.struct_bytes = C.sizeof(GemmParams)
-    p.A, p.W = _ptr(a16), _ptr(w16)
-    p.A_lo, p.out16_lo = _ptr(a16_lo), _ptr(out16_lo)
+    f16, f32 = torch.float16, torch.float32
+    p.A, p.W = _ptr(a16, f16, "a16"), _ptr(w16, f16, "w16")
+    p.A_lo, p.out16_lo = _ptr(a16_lo, f16, "a16_lo"), _ptr(out16_lo, f16, "out16_lo")
     p.M, p.N, p.K, p.lda, p.a_mode = M, N, K, lda, a_mode
     if conv:
         p.Cin, p.Hin, p.Win = conv["Cin"], conv["Hin"], conv["Win"]
@@ -236,10 +244,10 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
         p.conv_pad_br = int(conv.get("pad_br", 0))
     if tconv:
         p.Cin, p.T, p.Npix = tconv["C"], tconv["T"], tconv["Npix"]
-    p.bias, p.rowbias, p.rb_rows, p.rb_mod = _ptr(bias), _ptr(rowbias), rb_rows, rb_mod
-    p.res1, p.ldr1, p.res2, p.ldr2 = _ptr(res1), ldr1, _ptr(res2), ldr2
-    p.out32, p.ldc32, p.out16, p.ldc16 = _ptr(out32), ldc32, _ptr(out16), ldc16
-    p.out16t, p.ldt, p.t_rows, p.t_gstride = _ptr(out16t), ldt, t_rows, t_gstride
+    p.bias, p.rowbias, p.rb_rows, p.rb_mod = _ptr(bias, f32, "bias"), _ptr(rowbias, f32, "rowbias"), rb_rows, rb_mod
+    p.res1, p.ldr1, p.res2, p.ldr2 = _ptr(res1, f32, "res1"), ldr1, _ptr(res2, f32, "res2"), ldr2
+    p.out32, p.ldc32, p.out16, p.ldc16 = _ptr(out32, f32, "out32"), ldc32, _ptr(out16, f16, "out16"), ldc16
+    p.out16t, p.ldt, p.t_rows, p.t_gstride = _ptr(out16t, f16, "out16t"), ldt, t_rows, t_gstride
     p.n_split = n_split if out16t is not None else N
     p.act, p.geglu = act, int(geglu)
     lib = load()

@@ -233,6 +233,11 @@ class ControlledUNetModel3D(UNetModel3D):
             # frame-sharded runs issue collectives from both networks: one stream keeps their order identical on all ranks
             if self.two_stream and x.is_cuda and trace is None and rt.shard is None:
                 main = torch.cuda.current_stream()
+                # per-device tables that both streams read are created HERE, on the main stream, before the fork: their
+                # first use would otherwise be an H2D copy on the side stream that the main stream does not wait for
+                E.timestep_freqs(self.model_channels, x.device)
+                E.timestep_freqs(cn.model_channels, x.device)
+                self.packed(), cn.packed()
                 side = _side_stream(x.device, side_idx)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):

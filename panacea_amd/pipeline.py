@@ -26,5 +26,5 @@ def sample_frames(network, first_stage, cond: Dict[str, torch.Tensor], uc: Dict[
     den = sampling.DiscreteDenoiser().to(dev)
     smp = sampling.EulerEDMSampler(num_steps, guider=sampling.VanillaCFG(cfg_scale), device=dev)
     with torch.no_grad():
-        z = smp(S.BoundDenoiser(den, network), noise, cond, uc, network=network if hoist else None)
+        z = smp(sampling.BoundDenoiser(den, network), noise, cond, uc, network=network if hoist else None)
         return first_stage.decode(z / scale_factor)

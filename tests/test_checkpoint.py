@@ -48,3 +48,20 @@ def test_image_writers(tmp_path):
     assert im.size == (Wv, H) and im.mode == "RGB"
     g = Image.open(ck.save_gif(frames, str(tmp_path / "pano.gif")))
     assert g.n_frames == T and g.size == (6 * Wv, H) and g.info.get("loop") == 0
+
+
+def test_lightning_checkpoint_with_hyper_parameters_needs_trust(tmp_path):
+    """a Lightning .ckpt that carries non-tensor objects is refused by the safe unpickler and loads with
+    trust=True (the reference always unpickles fully, inference.py:209)."""
+    import pickle
+    import types
+    import pytest
+    import torch
+    from panacea_amd import checkpoint as ck
+    hp = types.SimpleNamespace(lr=1e-4)                         # stands in for an OmegaConf container
+    path = str(tmp_path / "lightning.ckpt")
+    torch.save({"state_dict": {"model.diffusion_model.a": torch.ones(3)}, "hyper_parameters": hp, "epoch": 3}, path)
+    with pytest.raises(pickle.UnpicklingError):
+        ck.read_state_dict(path)
+    sd = ck.read_state_dict(path, trust=True)
+    assert list(sd) == ["model.diffusion_model.a"] and torch.equal(sd["model.diffusion_model.a"], torch.ones(3))

@@ -36,7 +36,8 @@ def _digest() -> str:
     h = hashlib.sha256()
     for f in [CSRC / s for s in SOURCES] + HEADERS:
         h.update(f.read_bytes())
-    h.update(" ".join(FLAGS).encode())
+    # flags enter WITHOUT the checkout's absolute path: the digest must be the same wherever the tree is copied to
+    h.update(" ".join(f.replace(str(ROOT), "<root>") for f in FLAGS).encode())
     return h.hexdigest()
 
 

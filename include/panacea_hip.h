@@ -72,13 +72,13 @@ int pnc_set_option(int option, int value);
  *     v = acc + bias[n] + rowbias[((m / rb_rows) % rb_mod)*N + n]
  *     if geglu: v = value * gelu_erf(gate) on interleaved 32-column blocks
  *               (attention.py:91-98); output has N/2 columns
- *     if act == PNC_ACT_SILU: v = v*sigmoid(v)
+ *     if act == PNC_ACT_SILU: v = v*sigmoid(v);  PNC_ACT_GELU: v = v*Phi(v)
  *     v += res1[m*ldr1+n] + res2[m*ldr2+n]          (fp32 residual stream)
  *     out32[m*ldc32+n] = v;  out16[m*ldc16+n] = (fp16)v  for n <  n_split
  *     out16t[(m/t_rows)*t_gstride + (n-n_split)*ldt + m%t_rows] = (fp16)v for n >= n_split
  * ------------------------------------------------------------------------- */
 enum { PNC_A_PLAIN = 0, PNC_A_CONV3X3 = 1, PNC_A_CONV1D_T = 2 };
-enum { PNC_ACT_NONE = 0, PNC_ACT_SILU = 1 };
+enum { PNC_ACT_NONE = 0, PNC_ACT_SILU = 1, PNC_ACT_GELU = 2 /* erf GELU: open_clip text-tower MLP */ };
 
 typedef struct PncGemmParams {
     const void* A;          /* fp16 */
@@ -113,7 +113,7 @@ typedef struct PncGemmParams {
      * (sgm/modules/diffusionmodules/model.py:108-112) */
     int32_t conv_pad_br;
     /* sizeof(PncGemmParams) as the CALLER compiled it.  pnc_gemm_f16 / pnc_gemm_workspace_floats return PNC_EABI when
-     * it differs from the library's, instead of reading past a shorter struct (ABI version 2: 240 bytes). */
+     * it differs from the library's, instead of reading past a shorter struct (ABI version 2: 248 bytes). */
     int32_t struct_bytes;
     /* Precise ("split") activation operands.  An fp16 operand v is carried as two fp16 planes,
      *     hi = fp16(v),   lo = fp16((v - hi) * 2^11)        (a 22-bit operand; the 2^11 keeps lo out of the subnormals)
@@ -125,6 +125,10 @@ typedef struct PncGemmParams {
      * computes these contractions in fp32 on CPU / fp16 autocast on GPU (wrappers.py:37-70). */
     const void* A_lo;
     void* out16_lo;
+    /* elements between rows of W (0 = K: dense [N][K]).  A strided W lets the K matrix of one attention head, a column
+     * block of a [tokens][C] projection buffer, serve as the second operand of S = Q K^T (text tower, first-stage mid block) */
+    int32_t ldw;
+    int32_t reserved1;
 } PncGemmParams;
 
 int pnc_gemm_f16(const PncGemmParams* p, void* stream);
@@ -239,13 +243,14 @@ int pnc_cast_f16(const float* x, int64_t n, void* y16, void* y16_lo, void* strea
 /* ------------------------------------------------------------------------- *
  * 5. First-stage decoder: row softmax of a materialised score
  *    matrix, p[m][:] = softmax(scale * s[m][:]) (fp32 in, fp32 statistics, fp16
- *    out), N <= 16384, N % 4 == 0.  The single-head d = 512 attention of the VAE
+ *    out), N <= 16384, N % 4 == 0.  Columns >= n_valid (n_valid <= 0: N) are masked; causal != 0 also masks columns
+ *    j > m (row m = query m of ONE sequence: the OpenCLIP text tower's attn_mask, sgm/modules/encoders/modules.py:608).  The single-head d = 512 attention of the VAE
  *    mid block runs as  S = Q K^T (pnc_gemm_f16, fp32 out) -> this -> O = P V
  *    (pnc_gemm_f16 against the channel-major V^T).
  *     -> AttnBlock / MemoryEfficientAttnBlock.attention
  *        (sgm/modules/diffusionmodules/model.py:393-408, 444-472)
  * ------------------------------------------------------------------------- */
-int pnc_softmax_rows_f16(const float* s, int64_t lds, int M, int N, float scale,
+int pnc_softmax_rows_f16(const float* s, int64_t lds, int M, int N, float scale, int causal, int n_valid,
                          void* p16, int64_t ldp, void* stream);
 
 #ifdef __cplusplus

@@ -74,6 +74,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const PncGemmParams 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
     }
+    if (p.act == PNC_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+    }
     if (p.res1) {
         const float* rp = p.res1 + (int64_t)m * p.ldr1 + ncol;
 #pragma unroll
@@ -159,7 +163,8 @@ static int validate(const PncGemmParams& p) {
     } else {
         return PNC_EINVAL;
     }
-    if (p.act != PNC_ACT_NONE && p.act != PNC_ACT_SILU) return PNC_EINVAL;
+    if (p.act != PNC_ACT_NONE && p.act != PNC_ACT_SILU && p.act != PNC_ACT_GELU) return PNC_EINVAL;
+    if (p.ldw != 0 && (p.ldw < p.K || p.ldw % 8)) return PNC_EALIGN;
     if (p.rowbias && (p.rb_rows <= 0 || p.rb_mod <= 0)) return PNC_EINVAL;
     if (p.geglu) {
         if ((p.N % 64) || p.out16t || p.out32 || p.res1 || p.res2 || p.rowbias || p.act != PNC_ACT_NONE || !p.out16)
@@ -189,6 +194,7 @@ extern "C" int pnc_gemm_f16(const PncGemmParams* pp, void* stream) {
     if (rc != PNC_OK) return rc;
     PncGemmParams p = *pp;
     if (!p.out16t) p.n_split = p.N;
+    if (p.ldw == 0) p.ldw = p.K;
     if (!p.res1 && p.res2) { p.res1 = p.res2; p.ldr1 = p.ldr2; p.res2 = nullptr; }   // fp32 addition commutes bit-exactly for two terms
     const unsigned epi = select_epilogue(p);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

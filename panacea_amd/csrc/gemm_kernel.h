@@ -136,6 +136,9 @@ __device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, con
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// exact (erf) GELU of the plain activation epilogue (text-tower MLP: a few thousand rows per sample, not a hot site)
+__device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
 // fp16 store of 8 consecutive columns, plus the lo plane of a precise operand when the caller asked for one
 __device__ __forceinline__ void store_h8(half_t* out16, half_t* out16_lo, int64_t off, const float (&v)[8]) {
     half8v o;
@@ -178,7 +181,7 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
     constexpr int NPMAX = ENI == 2 ? 4 : 2;
     half_t* out16 = reinterpret_cast<half_t*>(p.out16);
     half_t* out16_lo = reinterpret_cast<half_t*>(p.out16_lo);
-    const bool silu = (!HAS_X) && (p.act == PNC_ACT_SILU);
+    const bool silu = (!HAS_X) && (p.act == PNC_ACT_SILU), gelu = (!HAS_X) && (p.act == PNC_ACT_GELU);
     const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 x0[NPMAX], x1[NPMAX], y0[NPMAX], y1[NPMAX];
 
@@ -249,6 +252,10 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
                 if (silu) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                }
+                if (gelu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
                 }
             }
             if constexpr (R2) {
@@ -391,6 +398,7 @@ __device__ __forceinline__ void epi_generic(const PncGemmParams& p, f32x16 (&acc
             float v = acc[i][j][r] + bn;
             if (p.rowbias) v += p.rowbias[(int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + n];
             if (p.act == PNC_ACT_SILU) v = silu_f(v);
+            if (p.act == PNC_ACT_GELU) v = gelu_erf_f(v);
             if (p.res1) v += p.res1[(int64_t)m * p.ldr1 + n];
             if (p.res2) v += p.res2[(int64_t)m * p.ldr2 + n];
             if (to_t) {
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int n = n0 + i * RPI + srow;
-        wrow[i] = (n < p.N) ? Wt + (int64_t)n * p.K : nullptr;
+        wrow[i] = (n < p.N) ? Wt + (int64_t)n * p.ldw : nullptr;
     }
     auto issue_tile = [&](int kt_local, int stage) {
         const bool lo = kt_local < nt_lo;

@@ -160,23 +160,31 @@ __global__ __launch_bounds__(256) void cfg_euler_step_kernel(const float* __rest
                                                              const float* __restrict__ sigma,
                                                              const float* __restrict__ sigma_next,
                                                              float* __restrict__ xn) {
+    // every product and sum below is rounded on its own, like the reference's separate elementwise kernels.  The operators
+    // are written out under `fp contract(off)` (HIP's __fmul_rn / __fadd_rn are plain inline operators compiled under the
+    // default contract(fast), so they DO fuse into FMAs)
+#pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)T * Npix) return;
     const int64_t t = i / Npix, pix = i - t * Npix;
-    const float sg = sigma[t], dt = __fsub_rn(sigma_next[t], sg), co = c_out[t];
+    const float sg = sigma[t], dt = sigma_next[t] - sg, co = c_out[t];
     const float* eu = eps + i * ld;                               // uncond half first (guiders.py:36)
     const float* ec = eps + ((int64_t)(cfg ? T : 0) * Npix + i) * ld;
     for (int c = 0; c < C; ++c) {
         const int64_t o = (t * C + c) * Npix + pix;
         const float xv = x[o];
-        const float dc = __fadd_rn(__fmul_rn(ec[c], co), xv);            // eps * c_out + x * c_skip   (c_skip = 1)
+        const float pc = ec[c] * co;
+        const float dc = pc + xv;                                        // eps * c_out + x * c_skip   (c_skip = 1)
         float d = dc;
         if (cfg) {
-            const float du = __fadd_rn(__fmul_rn(eu[c], co), xv);
-            d = __fadd_rn(du, __fmul_rn(scale, __fsub_rn(dc, du)));      // x_u + scale * (x_c - x_u)
+            const float pu = eu[c] * co;
+            const float du = pu + xv;
+            const float g = scale * (dc - du);
+            d = du + g;                                                  // x_u + scale * (x_c - x_u)
         }
-        const float dir = __fdiv_rn(__fsub_rn(xv, d), sg);               // (x - denoised) / sigma
-        xn[o] = __fadd_rn(xv, __fmul_rn(dt, dir));                       // x + (sigma_next - sigma) * d
+        const float dir = (xv - d) / sg;                                 // (x - denoised) / sigma
+        const float stp = dt * dir;
+        xn[o] = xv + stp;                                                // x + (sigma_next - sigma) * d
     }
 }
 
@@ -269,12 +277,15 @@ extern "C" int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32
 
 // row softmax: one 256-thread block per row, the row lives in registers (<= 16 x float4 per thread), one HBM read
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int64_t lds, int N, float scale,
+                                                           int causal, int n_valid,
                                                            half_t* __restrict__ p, int64_t ldp) {
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = s + (int64_t)blockIdx.x * lds;
     half_t* prow = p + (int64_t)blockIdx.x * ldp;
     const int nv = N >> 2;
+    // keys this row may see: the first n_valid columns, and with a causal mask only those up to the row's own index
+    const int lim = causal ? min(n_valid, (int)blockIdx.x + 1) : n_valid;
     f32x4 v[16];
     float m = -3.0e38f;
 #pragma unroll
@@ -282,6 +293,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         const int c = tid + j * 256;
         if (c < nv) {
             v[j] = *reinterpret_cast<const f32x4*>(row + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = (c * 4 + e < lim) ? v[j][e] : -3.0e38f;      // masked: exp2 -> 0
             m = fmaxf(fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])), m);
         }
     }
@@ -317,13 +330,14 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     }
 }
 
-extern "C" int pnc_softmax_rows_f16(const float* s, int64_t lds, int M, int N, float scale,
+extern "C" int pnc_softmax_rows_f16(const float* s, int64_t lds, int M, int N, float scale, int causal, int n_valid,
                                     void* p16, int64_t ldp, void* stream) {
-    if (!s || !p16 || M < 1 || N < 4 || N > 16384 || (N & 3)) return PNC_EINVAL;
+    if (!s || !p16 || M < 1 || N < 4 || N > 16384 || (N & 3) || n_valid > N) return PNC_EINVAL;
+    if (n_valid <= 0) n_valid = N;
     if ((lds & 3) || (ldp & 3) || lds < N || ldp < N) return PNC_EINVAL;
     if (((uintptr_t)s & 15) || ((uintptr_t)p16 & 7)) return PNC_EALIGN;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)M), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, lds, N,
-                       scale, reinterpret_cast<half_t*>(p16), ldp);
+                       scale, causal, n_valid, reinterpret_cast<half_t*>(p16), ldp);
     return pnc_launch_status();
 }
 

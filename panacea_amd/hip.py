@@ -19,7 +19,7 @@ LIB_PATH = PKG / "lib" / "libpanacea_hip.so"
 HEADER = PKG.parent / "include" / "panacea_hip.h"
 
 A_PLAIN, A_CONV3X3, A_CONV1D_T = 0, 1, 2
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 ABI_VERSION = 2          # PNC_ABI_VERSION of include/panacea_hip.h this binding was written against
 
 
@@ -50,6 +50,7 @@ class GemmParams(C.Structure):
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("conv_pad_br", C.c_int32), ("struct_bytes", C.c_int32),
         ("A_lo", C.c_void_p), ("out16_lo", C.c_void_p),
+        ("ldw", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -76,7 +77,7 @@ _SIGNATURES = {
     "pnc_gemm_f16": (_I, [C.POINTER(GemmParams), _P]),
     "pnc_gemm_workspace_floats": (_L, [C.POINTER(GemmParams)]),
     "pnc_attn_views_f16": (_I, [C.POINTER(AttnParams), _P]),
-    "pnc_softmax_rows_f16": (_I, [_P, _L, _I, _I, _F, _P, _L, _P]),
+    "pnc_softmax_rows_f16": (_I, [_P, _L, _I, _I, _F, _I, _I, _P, _L, _P]),
     "pnc_attn_temporal_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "pnc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "pnc_groupnorm_apply": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P, _P]),
@@ -229,14 +230,14 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
          out16: Optional[torch.Tensor] = None, ldc16: int = 0,
          out16t: Optional[torch.Tensor] = None, ldt: int = 0, t_rows: int = 0, t_gstride: int = 0,
          n_split: int = 0, act: int = ACT_NONE, geglu: bool = False,
-         a16_lo: Optional[torch.Tensor] = None, out16_lo: Optional[torch.Tensor] = None):
+         a16_lo: Optional[torch.Tensor] = None, out16_lo: Optional[torch.Tensor] = None, w_ld: int = 0):
     """`a16_lo` / `out16_lo`: lo planes of precise (split) operands, see PncGemmParams.A_lo in the header."""
     p = GemmParams()
     p.struct_bytes = C.sizeof(GemmParams)
     f16, f32 = torch.float16, torch.float32
     p.A, p.W = _ptr(a16, f16, "a16"), _ptr(w16, f16, "w16")
     p.A_lo, p.out16_lo = _ptr(a16_lo, f16, "a16_lo"), _ptr(out16_lo, f16, "out16_lo")
-    p.M, p.N, p.K, p.lda, p.a_mode = M, N, K, lda, a_mode
+    p.M, p.N, p.K, p.lda, p.a_mode, p.ldw = M, N, K, lda, a_mode, w_ld
     if conv:
         p.Cin, p.Hin, p.Win = conv["Cin"], conv["Hin"], conv["Win"]
         p.Hout, p.Wout = conv["Hout"], conv["Wout"]
@@ -279,9 +280,9 @@ def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H
                   C.byref(p), _stream()), "pnc_attn_views_f16")
 
 
-def softmax_rows(s32, lds, M, N, scale, p16, ldp):
-    _check(_timed("softmax_rows", 0.0, 6.0 * M * N, load().pnc_softmax_rows_f16, _ptr(s32), lds, M, N, scale, _ptr(p16),
-                  ldp, _stream()), "pnc_softmax_rows_f16")
+def softmax_rows(s32, lds, M, N, scale, p16, ldp, causal=False, n_valid=0):
+    _check(_timed("softmax_rows", 0.0, 6.0 * M * N, load().pnc_softmax_rows_f16, _ptr(s32), lds, M, N, scale, int(causal),
+                  n_valid, _ptr(p16), ldp, _stream()), "pnc_softmax_rows_f16")
 
 
 def attn_temporal(q, ldq, k, ldk, v, ldv, o, ldo, *, B, T, Npix, heads, scale):

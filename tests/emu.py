@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as TF
 
 A_PLAIN, A_CONV3X3, A_CONV1D_T = 0, 1, 2
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
 
 class PncError(RuntimeError):
@@ -54,10 +54,10 @@ def load():
 def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bias=None, rowbias=None,
          rb_rows=0, rb_mod=0, res1=None, ldr1=0, res2=None, ldr2=0, out32=None, ldc32=0, out16=None,
          ldc16=0, out16t=None, ldt=0, t_rows=0, t_gstride=0, n_split=0, act=ACT_NONE, geglu=False,
-         a16_lo=None, out16_lo=None):
+         a16_lo=None, out16_lo=None, w_ld=0):
     assert (not STRICT_DTYPES) or (a16.dtype == torch.float16 and w16.dtype == torch.float16)
     assert K % 8 == 0
-    Wm = w16.reshape(-1)[: N * K].view(N, K).float()
+    Wm = _mat(w16, N, K, w_ld or K).float()
     if a16_lo is not None:       # precise operand: A = hi + lo * 2^-11 (the kernel sums the two planes' products in fp32)
         a16 = _join(a16.reshape(-1), a16_lo.reshape(-1)[: a16.numel()])
     if a_mode == A_PLAIN:
@@ -107,6 +107,8 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
         v = v + rowbias.reshape(-1)[: rb_mod * N].view(rb_mod, N).float()[idx]
     if act == ACT_SILU:
         v = TF.silu(v)
+    if act == ACT_GELU:
+        v = TF.gelu(v)
     if res1 is not None:
         v = v + _mat(res1, M, N, ldr1)
     if res2 is not None:
@@ -155,8 +157,13 @@ def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H
         O[:, :, v * Wv:(v + 1) * Wv] = r16(ov, 'attn_views')
 
 
-def softmax_rows(s32, lds, M, N, scale, p16, ldp):
-    pr = torch.softmax(_mat(s32, M, N, lds).float() * scale, dim=-1)
+def softmax_rows(s32, lds, M, N, scale, p16, ldp, causal=False, n_valid=0):
+    sc = _mat(s32, M, N, lds).float() * scale
+    col, row = torch.arange(N, device=sc.device)[None, :], torch.arange(M, device=sc.device)[:, None]
+    keep = col < (n_valid or N)
+    if causal:
+        keep = keep & (col <= row)
+    pr = torch.softmax(sc.masked_fill(~keep, float("-inf")), dim=-1)
     _mat(p16, M, N, ldp).copy_(r16(pr, 'softmax_rows'))
 
 

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const PncGemmParams 
     }
     if (p.act == PNC_ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_call(v[e]);
     }
     if (p.res1) {
         const float* rp = p.res1 + (int64_t)m * p.ldr1 + ncol;
@@ -129,8 +129,9 @@ static unsigned select_epilogue(const PncGemmParams& p) {
                        (p.n_split == 0 || p.out16);
     const int nstreams = (p.res1 != nullptr) + (p.res2 != nullptr) + (p.rowbias != nullptr);
     if (nstreams == 3 || (nstreams && p.act != PNC_ACT_NONE)) ok = false;
+    if (p.act == PNC_ACT_GELU && (p.out32 || p.out16t || !p.out16)) ok = false;   // one specialised GELU variant: fp16 out
     if (!ok) return E_GENERIC;
-    unsigned e = 0;
+    unsigned e = p.act == PNC_ACT_GELU ? E_GELU : 0;
     if (p.res1 || p.res2) e |= E_R1;              // a single residual is passed to the kernel as res1
     if (p.res1 && p.res2) e |= E_R2;
     if (p.rowbias) e |= E_RB;

@@ -41,7 +41,8 @@ enum : unsigned {
     E_O16 = 16,      // fp16 output (+ optional lo plane)
     E_VT = 32,       // column blocks >= n_split go channel-major (V^T)
     E_GEGLU = 64,    // value * gelu(gate) on interleaved 32-column blocks, fp16 output
-    E_GENERIC = 128  // run-time flags, scalar predicated accesses: ragged N, unaligned pointers / leading dimensions
+    E_GENERIC = 128, // run-time flags, scalar predicated accesses: ragged N, unaligned pointers / leading dimensions
+    E_GELU = 256     // erf GELU on the fp16 output (text-tower MLP); its own variant: erff is ~60 instructions per element
 };
 
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;   // lo plane = (v - hi) * 2^11
@@ -138,6 +139,8 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 
 // exact (erf) GELU of the plain activation epilogue (text-tower MLP: a few thousand rows per sample, not a hot site)
 __device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// the same out of line, for the generic epilogue / split-K reduce (keeps the erff expansion out of their unrolled loops)
+__device__ __attribute__((noinline)) static float gelu_erf_call(float v) { return gelu_erf_f(v); }
 
 // fp16 store of 8 consecutive columns, plus the lo plane of a precise operand when the caller asked for one
 __device__ __forceinline__ void store_h8(half_t* out16, half_t* out16_lo, int64_t off, const float (&v)[8]) {
@@ -181,7 +184,8 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
     constexpr int NPMAX = ENI == 2 ? 4 : 2;
     half_t* out16 = reinterpret_cast<half_t*>(p.out16);
     half_t* out16_lo = reinterpret_cast<half_t*>(p.out16_lo);
-    const bool silu = (!HAS_X) && (p.act == PNC_ACT_SILU), gelu = (!HAS_X) && (p.act == PNC_ACT_GELU);
+    constexpr bool GELU = (EPI & E_GELU) != 0;
+    const bool silu = (!HAS_X) && (p.act == PNC_ACT_SILU);
     const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 x0[NPMAX], x1[NPMAX], y0[NPMAX], y1[NPMAX];
 
@@ -253,7 +257,7 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
                 }
-                if (gelu) {
+                if constexpr (GELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
                 }
@@ -398,7 +402,7 @@ __device__ __forceinline__ void epi_generic(const PncGemmParams& p, f32x16 (&acc
             float v = acc[i][j][r] + bn;
             if (p.rowbias) v += p.rowbias[(int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + n];
             if (p.act == PNC_ACT_SILU) v = silu_f(v);
-            if (p.act == PNC_ACT_GELU) v = gelu_erf_f(v);
+            if (p.act == PNC_ACT_GELU) v = gelu_erf_call(v);
             if (p.res1) v += p.res1[(int64_t)m * p.ldr1 + n];
             if (p.res2) v += p.res2[(int64_t)m * p.ldr2 + n];
             if (to_t) {
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         if constexpr (GEGLU) {
             epi_geglu<MI, NI>(p, acc, ep, lane, mw, nw, reinterpret_cast<const float*>(smem + RING_BYTES));
         } else {
-            epi_fast<MI, NI, (EPI & ~E_VT)>(p, acc, ep, lane, mw, nw, (EPI & E_VT) ? p.n_split : p.N);
+            epi_fast<MI, NI, (EPI & ~E_VT)>(p, acc, ep, lane, mw, nw, (EPI & E_VT) ? p.n_split : p.N);   // E_GELU rides along
         }
     }
 }

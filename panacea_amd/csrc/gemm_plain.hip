@@ -8,6 +8,7 @@ int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st) {
     constexpr int AM = PNC_A_PLAIN;
     const TileChoice tc = choose_tile(p);
     if (tc.tile == T_128x32 && epi != E_O16 && epi != E_O32) epi = E_GENERIC;     // narrow-N: two fast variants
+    if (epi == (E_O16 | E_GELU) && tc.tile != T_256x256 && tc.tile != T_128x128) epi = E_GENERIC;
     switch (epi) {
         case E_O16: return launch_tile<AM, E_O16>(p, st, tc);                       // q (text), qkv (temporal), text K
         case E_O16 | E_VT: return launch_tile<AM, E_O16 | E_VT>(p, st, tc);         // qkv of the view attention, text V^T
@@ -18,6 +19,9 @@ int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st) {
         case E_R1 | E_O16: return launch_tile<AM, E_R1 | E_O16>(p, st, tc);         // ff2 of the last block: fp16 for proj_out
         case E_RB | E_O32: return launch_tile<AM, E_RB | E_O32>(p, st, tc);         // proj_in_temporal + position table
         case E_GEGLU | E_O16: return launch_tile<AM, E_GEGLU | E_O16>(p, st, tc);   // ff1
+        case E_O16 | E_GELU:                                                        // text-tower c_fc + GELU (two geometries)
+            if (tc.tile == T_256x256) return launch<AM, 256, 256, 4, 2, 2, true, E_O16 | E_GELU>(p, st);
+            return launch<AM, 128, 128, 2, 2, 2, true, E_O16 | E_GELU>(p, st);
         default: return launch_tile<AM, E_GENERIC>(p, st, tc);
     }
 }

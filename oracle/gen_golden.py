@@ -38,9 +38,11 @@ def oracle_cfg(kw: dict) -> po.OracleConfig:
                            insert_crossview=kw["insert_crossview"])
 
 
-def run_config(ns, name: str):
+def run_config(ns, name: str, shape=None, out_name=None, eps_only=False):
+    """`shape` / `out_name`: the same network on another latent size (plain64 = BASELINE config 1 as written: single view,
+    one frame, 64x64 latent); `eps_only` stores eps alone."""
     kw = configs.get(name)
-    B, T, h, w = configs.SHAPES[name]
+    B, T, h, w = shape or configs.SHAPES[name]
     net, wrapper = ref_import.build_reference_network(ns, kw)
     manifest = {k: list(v.shape) for k, v in net.state_dict().items()}
     sd = synth.synth_state_dict(manifest)
@@ -89,11 +91,13 @@ def run_config(ns, name: str):
 
     out = {"eps": eps.numpy()}
     # everything but eps: a fixed stride-7 sample of the flattened tensor keeps the fixture small
-    out.update({k: v.reshape(-1)[::7].numpy() for k, v in controls.items()})
-    out.update({"block." + k: v.reshape(-1)[::7].numpy() for k, v in trace.items()})
+    if not eps_only:
+        out.update({k: v.reshape(-1)[::7].numpy() for k, v in controls.items()})
+        out.update({"block." + k: v.reshape(-1)[::7].numpy() for k, v in trace.items()})
     GOLDEN.mkdir(parents=True, exist_ok=True)
-    np.savez_compressed(GOLDEN / f"{name}.npz", **out)
-    (GOLDEN / f"manifest_{name}.json").write_text(json.dumps(manifest, indent=0, sort_keys=True))
+    np.savez_compressed(GOLDEN / f"{out_name or name}.npz", **out)
+    if out_name is None:
+        (GOLDEN / f"manifest_{name}.json").write_text(json.dumps(manifest, indent=0, sort_keys=True))
     print(f"[{name}] wrote {len(out)} arrays, {len(manifest)} manifest entries")
 
 
@@ -161,8 +165,12 @@ if __name__ == "__main__":
     if "--sampler-only" in sys.argv:
         sampler_vectors(ns)
         sys.exit(0)
+    if "--plain64-only" in sys.argv:
+        run_config(ns, "plain1", shape=(1, 1, 64, 64), out_name="plain64", eps_only=True)
+        sys.exit(0)
     small_vectors(ns)
     sampler_vectors(ns)
     for name in ("tiny", "plain1"):
         run_config(ns, name)
+    run_config(ns, "plain1", shape=(1, 1, 64, 64), out_name="plain64", eps_only=True)     # BASELINE config 1 as written
     full_manifest(ns)

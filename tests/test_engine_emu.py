@@ -126,3 +126,19 @@ def test_unsupported_options_fail_loudly():
         w, _, _ = product_network("tiny")
         inp = step_inputs("tiny", kw)
         w(inp["x"], inp["t"], cond(inp))
+
+
+def test_baseline_config1_as_written_64x64_latent():
+    """BASELINE config 1: single view, one frame, 64x64 latent — the plain-attention network on the
+    reference's golden eps at that size (tests/golden/plain64.npz).  64 channels and T = 1: every temporal GroupNorm
+    normalises 2 values per group, which amplifies the rounding of the conv output feeding it (fast 1.9e-2); with every
+    operand class split the path is at 1.3e-3."""
+    from helpers import golden
+    w, _, kw = product_network("plain1")
+    w.diffusion_model.precision = "precise-all"
+    inp = step_inputs("plain1", kw, shape=(1, 1, 64, 64))
+    with E.use_backend(emu):
+        eps = w(inp["x"], inp["t"], cond(inp))
+    st = err_stats(eps, golden("plain64")["eps"])
+    assert eps.shape == (1, 4, 64, 64)
+    assert st["max_abs"] <= 1.7e-3 and st["mean_abs"] <= 1.8e-4, st

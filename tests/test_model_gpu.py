@@ -61,6 +61,18 @@ def test_hip_path_matches_reference_golden(name, prec):
             assert np.abs(got - ref).max() <= lim, (k, np.abs(got - ref).max())
 
 
+def test_baseline_config1_64x64_latent_vs_reference_golden():
+    """BASELINE config 1 as written (single view, 1 frame, 64x64 latent) on the GPU against the reference's golden eps;
+    tolerance and its reason: tests/test_engine_emu.py::test_baseline_config1_as_written_64x64_latent."""
+    w, _, kw = product_network("plain1", DEV)
+    w.diffusion_model.precision = "precise-all"
+    inp = step_inputs("plain1", kw, DEV, shape=(1, 1, 64, 64))
+    eps = w(inp["x"], inp["t"], cond(inp))
+    st = err_stats(eps, golden("plain64")["eps"])
+    print("plain 64x64:", st)
+    assert st["max_abs"] <= 2.2e-3 and st["mean_abs"] <= 2.2e-4, st
+
+
 def test_hip_path_other_timesteps_and_frames_vs_oracle():
     """tiny network, T = 4 frames, t = 333: outside the golden vectors, against the oracle directly."""
     kw = configs.with_frames(configs.get("tiny"), 4)

@@ -113,7 +113,7 @@ typedef struct PncGemmParams {
      * (sgm/modules/diffusionmodules/model.py:108-112) */
     int32_t conv_pad_br;
     /* sizeof(PncGemmParams) as the CALLER compiled it.  pnc_gemm_f16 / pnc_gemm_workspace_floats return PNC_EABI when
-     * it differs from the library's, instead of reading past a shorter struct (ABI version 2: 248 bytes). */
+     * it differs from the library's, instead of reading past a shorter struct (ABI version 2: 280 bytes). */
     int32_t struct_bytes;
     /* Precise ("split") activation operands.  An fp16 operand v is carried as two fp16 planes,
      *     hi = fp16(v),   lo = fp16((v - hi) * 2^11)        (a 22-bit operand; the 2^11 keeps lo out of the subnormals)
@@ -128,6 +128,17 @@ typedef struct PncGemmParams {
     /* elements between rows of W (0 = K: dense [N][K]).  A strided W lets the K matrix of one attention head, a column
      * block of a [tokens][C] projection buffer, serve as the second operand of S = Q K^T (text tower, first-stage mid block) */
     int32_t ldw;
+    /* LayerNorm of the fp32 output rows, fused (attention.py:726-747: x = attn(norm(x)) + x followed by the next norm):
+     *   ln_out16[m*ldln + n] = fp16( (out32[m][n] - mean_m) * rstd_m * ln_gamma[n] + ln_beta[n] ),  statistics over the N columns.
+     * ln_out16 NULL = off.  Needs out32 and no GEGLU / V^T.  When one workgroup owns whole rows (N <= its tile width: the
+     * level-0 width 320) the row statistics are reduced in the epilogue and the normalised fp16 row is written by the GEMM
+     * itself (the LayerNorm launch and its 4-byte read of the stream disappear); otherwise the library runs its LayerNorm
+     * kernel right after the GEMM on the same stream — same result either way. */
+    float ln_eps;
+    const float* ln_gamma;
+    const float* ln_beta;
+    void* ln_out16;
+    int32_t ldln;
     int32_t reserved1;
 } PncGemmParams;
 

@@ -7,7 +7,7 @@
 
 namespace pnc_gemm {
 
-int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st);
+int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st, bool* ln_fused);
 int dispatch_conv3x3(const PncGemmParams& p, unsigned epi, hipStream_t st);
 int dispatch_conv1d(const PncGemmParams& p, unsigned epi, hipStream_t st);
 
@@ -176,6 +176,11 @@ static int validate(const PncGemmParams& p) {
     if (p.out16t && ((p.n_split % 128) || p.t_rows <= 0 || p.N <= 32)) return PNC_EINVAL;
     if (p.out16_lo && !p.out16) return PNC_EINVAL;
     if (!p.out32 && !p.out16 && !p.out16t) return PNC_EINVAL;
+    if (p.ln_out16) {           // fused / trailing LayerNorm of the fp32 output rows (same limits as pnc_layernorm)
+        if (!p.out32 || p.geglu || p.out16t || !p.ln_gamma || !p.ln_beta) return PNC_EINVAL;
+        if (p.N % 4 || p.N > 4 * 64 * 12 || p.ldc32 % 4 || p.ldln % 4 || p.ldln < p.N) return PNC_EINVAL;
+        if (!al16(p.out32) || !al16(p.ln_gamma) || !al16(p.ln_beta) || (((uintptr_t)p.ln_out16) & 7)) return PNC_EALIGN;
+    }
     return PNC_OK;
 }
 
@@ -197,11 +202,20 @@ extern "C" int pnc_gemm_f16(const PncGemmParams* pp, void* stream) {
     if (!p.out16t) p.n_split = p.N;
     if (p.ldw == 0) p.ldw = p.K;
     if (!p.res1 && p.res2) { p.res1 = p.res2; p.ldr1 = p.ldr2; p.res2 = nullptr; }   // fp32 addition commutes bit-exactly for two terms
-    const unsigned epi = select_epilogue(p);
+    unsigned epi = select_epilogue(p);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    bool ln_fused = false;
+    // LayerNorm fused into the epilogue: plain A, fp32 output only, at most one added stream, 16-byte aligned fp16 rows
+    if (p.ln_out16 && p.a_mode == PNC_A_PLAIN && (epi == E_O32 || epi == (E_RB | E_O32) || epi == (E_R1 | E_O32)) &&
+        (p.ldln % 8 == 0) && al16(p.ln_out16))
+        epi |= E_LN;
+    int rc2;
     switch (p.a_mode) {
-        case PNC_A_PLAIN: return dispatch_plain(p, epi, st);
-        case PNC_A_CONV3X3: return dispatch_conv3x3(p, epi, st);
-        default: return dispatch_conv1d(p, epi, st);
+        case PNC_A_PLAIN: rc2 = dispatch_plain(p, epi, st, &ln_fused); break;
+        case PNC_A_CONV3X3: rc2 = dispatch_conv3x3(p, epi, st); break;
+        default: rc2 = dispatch_conv1d(p, epi, st); break;
     }
+    if (rc2 == PNC_OK && p.ln_out16 && !ln_fused)      // rows span several workgroups (or a generic launch): the LayerNorm kernel
+        rc2 = pnc_layernorm(p.out32, p.ldc32, p.M, p.N, p.ln_gamma, p.ln_beta, p.ln_eps, p.ln_out16, p.ldln, nullptr, stream);
+    return rc2;
 }

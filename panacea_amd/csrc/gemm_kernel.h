@@ -42,7 +42,8 @@ enum : unsigned {
     E_VT = 32,       // column blocks >= n_split go channel-major (V^T)
     E_GEGLU = 64,    // value * gelu(gate) on interleaved 32-column blocks, fp16 output
     E_GENERIC = 128, // run-time flags, scalar predicated accesses: ragged N, unaligned pointers / leading dimensions
-    E_GELU = 256     // erf GELU on the fp16 output (text-tower MLP); its own variant: erff is ~60 instructions per element
+    E_GELU = 256,    // erf GELU on the fp16 output (text-tower MLP); its own variant: erff is ~60 instructions per element
+    E_LN = 512       // LayerNorm of the fp32 output rows written as fp16 by the same workgroup (it owns whole rows)
 };
 
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;   // lo plane = (v - hi) * 2^11
@@ -170,11 +171,19 @@ __device__ __forceinline__ void store_h8(half_t* out16, half_t* out16_lo, int64_
 // a load may not move above an earlier store; rows/columns of different slabs are disjoint, so this order is safe.
 // The loads of slab 0 go out after its accumulators have been staged (32 registers free again): with two streams in
 // flight the live set stays below 256 VGPRs next to the 160 accumulator registers of the 256x320 tile.
+//
+// E_LN (the workgroup owns whole rows: N <= BN, two waves per row): every pass also reduces sum / sum of squares of its
+// row segment over the lanes of the row and accumulates them per row in LDS; after a workgroup barrier each wave adds its
+// partner's half, re-reads the fp32 values IT has just written (same lane, same address: program order makes them
+// visible; they come back from L2) and writes the normalised fp16 row.  This replaces the LayerNorm launch that would
+// otherwise read the stream again from HBM (attention.py:726-747: every residual GEMM of a block is followed by a norm).
 template <int MI, int NI, unsigned EPI>
 __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[MI][NI], float* ep, int lane,
-                                         int mw, int nw, int ncols) {
+                                         int mw, int nw, int ncols, float2* ln_mine = nullptr,
+                                         const float2* ln_partner = nullptr) {
     constexpr bool R1 = (EPI & E_R1) != 0, R2 = (EPI & E_R2) != 0, RB = (EPI & E_RB) != 0;
-    constexpr bool O32 = (EPI & E_O32) != 0, O16 = (EPI & E_O16) != 0;
+    constexpr bool O32 = (EPI & E_O32) != 0, O16 = (EPI & E_O16) != 0, LN = (EPI & E_LN) != 0;
+    static_assert(!LN || O32, "the fused LayerNorm normalises the fp32 output it has just written");
     constexpr bool HAS_X = R1 || RB, HAS_Y = R1 && (R2 || RB);
     static_assert(!(R2 && !R1), "a single residual is passed as res1");
     static_assert(!(R1 && R2 && RB), "three added streams run the generic epilogue");
@@ -188,6 +197,9 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
     const bool silu = (!HAS_X) && (p.act == PNC_ACT_SILU);
     const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 x0[NPMAX], x1[NPMAX], y0[NPMAX], y1[NPMAX];
+    if constexpr (LN) {
+        if (lane < MI * 32) ln_mine[lane] = make_float2(0.0f, 0.0f);         // MI * 32 <= 64 rows per wave
+    }
 
     // slab s -> (row block i, first column block jc, width cw in blocks, lanes per row, rows per pass, passes)
     auto load_xy = [&](auto s_, auto ps_) {
@@ -273,6 +285,21 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
                 if constexpr (ps < NPn) load_xy(std::integral_constant<int, s + 1>{}, ps_);
                 // (a narrower next slab has fewer passes; a wider one cannot follow a narrower one: the odd block is last)
             }
+            if constexpr (LN) {
+                // row statistics of this pass: 8 columns per lane, CPL lanes per row (consecutive lanes)
+                float sm = 0.0f, sq = 0.0f;
+                if (on) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { sm += v[e]; sq = fmaf(v[e], v[e], sq); }
+                }
+#pragma unroll
+                for (int o = 1; o < CPL; o <<= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }
+                if (cl == 0) {
+                    float2 t = ln_mine[i * 32 + ps * RPP + rl];
+                    t.x += sm; t.y += sq;
+                    ln_mine[i * 32 + ps * RPP + rl] = t;
+                }
+            }
             if (!on) return;
             if constexpr (O32) {
                 float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
@@ -283,6 +310,51 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
             if constexpr (O16) store_h8(out16, out16_lo, (int64_t)m * p.ldc16 + ncol, v);
         });
     });
+    if constexpr (LN) {
+        __syncthreads();                      // both halves of every row have their statistics in LDS
+        half_t* lnout = reinterpret_cast<half_t*>(p.ln_out16);
+        const float invn = 1.0f / (float)p.N;
+        static_for<NS>([&](auto s_) {
+            constexpr int s = decltype(s_)::value, jc = (s / MI) * ENI, i = s % MI;
+            constexpr int cw = (NI - jc) < ENI ? (NI - jc) : ENI;
+            constexpr int CPL = cw * 4, RPP = 64 / CPL, NP = 32 / RPP;
+            const int cl = lane % CPL, rl = lane / CPL;
+            const int ncol = nw + jc * 32 + cl * 8;
+            const bool col_on = ncol < ncols;
+            f32x4 g0 = z4, g1 = z4, h0 = z4, h1 = z4;
+            if (col_on) {
+                g0 = ld4(p.ln_gamma + ncol); g1 = ld4(p.ln_gamma + ncol + 4);
+                h0 = ld4(p.ln_beta + ncol); h1 = ld4(p.ln_beta + ncol + 4);
+            }
+            f32x4 w0[NP], w1[NP];
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {                      // all loads of the slab first (own stores, L2 hits)
+                const int m = mw + i * 32 + ps * RPP + rl;
+                w0[ps] = z4; w1[ps] = z4;
+                if (col_on && m < p.M) {
+                    const float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
+                    w0[ps] = ld4(op); w1[ps] = ld4(op + 4);
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const int r = i * 32 + ps * RPP + rl;
+                const int m = mw + r;
+                if (!(col_on && m < p.M)) continue;
+                const float2 a = ln_mine[r], b = ln_partner[r];
+                const float mean = (a.x + b.x) * invn;
+                const float var = fmaxf((a.y + b.y) * invn - mean * mean, 0.0f);
+                const float rs = rsqrtf(var + p.ln_eps);
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = fmaf((w0[ps][e] - mean) * rs, g0[e], h0[e]);
+                    y[e + 4] = fmaf((w1[ps][e] - mean) * rs, g1[e], h1[e]);
+                }
+                store_h8(lnout, nullptr, (int64_t)m * p.ldln + ncol, y);
+            }
+        });
+    }
 }
 
 // GEGLU epilogue: the two column blocks of a staged chunk are a value block and its gate block (engine.pk_geglu);
@@ -648,7 +720,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         if constexpr (GEGLU) {
             epi_geglu<MI, NI>(p, acc, ep, lane, mw, nw, reinterpret_cast<const float*>(smem + RING_BYTES));
         } else {
-            epi_fast<MI, NI, (EPI & ~E_VT)>(p, acc, ep, lane, mw, nw, (EPI & E_VT) ? p.n_split : p.N);   // E_GELU rides along
+            if constexpr ((EPI & E_LN) != 0) {
+                static_assert(WGN == 2, "the fused LayerNorm pairs the two waves of a row");
+                float2* lnb = reinterpret_cast<float2*>(reinterpret_cast<float*>(smem) + NW * (32 * EPITCH));
+                epi_fast<MI, NI, EPI>(p, acc, ep, lane, mw, nw, p.N, lnb + wave * 64, lnb + (wave ^ 1) * 64);
+            } else {
+                epi_fast<MI, NI, (EPI & ~E_VT)>(p, acc, ep, lane, mw, nw, (EPI & E_VT) ? p.n_split : p.N);   // E_GELU rides along
+            }
         }
     }
 }
@@ -681,7 +759,7 @@ int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
     constexpr int threads = 64 * WGM * WGN;
     constexpr bool GEGLU = (EPI & E_GEGLU) != 0;
     static_assert(lds + (GEGLU ? PHI_BYTES : 0) <= 160 * 1024, "LDS budget of one CU (operand ring + GEGLU table)");
-    static_assert(lds >= WGM * WGN * 32 * 68 * 4, "epilogue staging must fit the operand ring");
+    static_assert(lds >= WGM * WGN * (32 * 68 * 4 + 64 * 8), "epilogue staging (+ LayerNorm row sums) must fit the operand ring");
     static std::atomic<unsigned char> attr_done[64];      // per instantiation and device; the call is idempotent
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -4,9 +4,22 @@
 
 namespace pnc_gemm {
 
-int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st) {
+// E_LN variants exist for the two geometries whose workgroup can own a whole row of the path's widths
+template <unsigned EPI>
+static int launch_ln(const PncGemmParams& p, hipStream_t st, TileChoice tc) {
+    if (tc.tile == T_256x320) return launch<PNC_A_PLAIN, 256, 320, 4, 2, 2, false, EPI>(p, st);
+    return launch<PNC_A_PLAIN, 128, 128, 2, 2, 2, true, EPI>(p, st);
+}
+
+int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st, bool* ln_fused) {
     constexpr int AM = PNC_A_PLAIN;
     const TileChoice tc = choose_tile(p);
+    if (epi & E_LN) {
+        // fuse only when ONE column tile covers the row (level-0 width 320 on 256x320; <= 128 on 128x128)
+        const bool whole_rows = tc.ksplit == 1 && ((tc.tile == T_256x320 && p.N <= 320) || (tc.tile == T_128x128 && p.N <= 128));
+        if (whole_rows) *ln_fused = true;
+        else epi &= ~E_LN;                      // the caller runs the LayerNorm kernel after this GEMM instead
+    }
     if (tc.tile == T_128x32 && epi != E_O16 && epi != E_O32) epi = E_GENERIC;     // narrow-N: two fast variants
     if (epi == (E_O16 | E_GELU) && tc.tile != T_256x256 && tc.tile != T_128x128) epi = E_GENERIC;
     switch (epi) {
@@ -18,6 +31,9 @@ int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st) {
         case E_R1 | E_O32 | E_O16: return launch_tile<AM, E_R1 | E_O32 | E_O16>(p, st, tc);
         case E_R1 | E_O16: return launch_tile<AM, E_R1 | E_O16>(p, st, tc);         // ff2 of the last block: fp16 for proj_out
         case E_RB | E_O32: return launch_tile<AM, E_RB | E_O32>(p, st, tc);         // proj_in_temporal + position table
+        case E_O32 | E_LN: return launch_ln<E_O32 | E_LN>(p, st, tc);               // proj_in + norm1
+        case E_RB | E_O32 | E_LN: return launch_ln<E_RB | E_O32 | E_LN>(p, st, tc); // proj_in_temporal + pos + norm1
+        case E_R1 | E_O32 | E_LN: return launch_ln<E_R1 | E_O32 | E_LN>(p, st, tc); // to_out + residual + norm2 / norm3
         case E_GEGLU | E_O16: return launch_tile<AM, E_GEGLU | E_O16>(p, st, tc);   // ff1
         case E_O16 | E_GELU:                                                        // text-tower c_fc + GELU (two geometries)
             if (tc.tile == T_256x256) return launch<AM, 256, 256, 4, 2, 2, true, E_O16 | E_GELU>(p, st);

@@ -50,7 +50,9 @@ class GemmParams(C.Structure):
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("conv_pad_br", C.c_int32), ("struct_bytes", C.c_int32),
         ("A_lo", C.c_void_p), ("out16_lo", C.c_void_p),
-        ("ldw", C.c_int32), ("reserved1", C.c_int32),
+        ("ldw", C.c_int32), ("ln_eps", C.c_float),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out16", C.c_void_p),
+        ("ldln", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -230,7 +232,9 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
          out16: Optional[torch.Tensor] = None, ldc16: int = 0,
          out16t: Optional[torch.Tensor] = None, ldt: int = 0, t_rows: int = 0, t_gstride: int = 0,
          n_split: int = 0, act: int = ACT_NONE, geglu: bool = False,
-         a16_lo: Optional[torch.Tensor] = None, out16_lo: Optional[torch.Tensor] = None, w_ld: int = 0):
+         a16_lo: Optional[torch.Tensor] = None, out16_lo: Optional[torch.Tensor] = None, w_ld: int = 0,
+         ln_gamma: Optional[torch.Tensor] = None, ln_beta: Optional[torch.Tensor] = None,
+         ln_out16: Optional[torch.Tensor] = None, ldln: int = 0, ln_eps: float = 1e-5):
     """`a16_lo` / `out16_lo`: lo planes of precise (split) operands, see PncGemmParams.A_lo in the header."""
     p = GemmParams()
     p.struct_bytes = C.sizeof(GemmParams)
@@ -238,6 +242,10 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
     p.A, p.W = _ptr(a16, f16, "a16"), _ptr(w16, f16, "w16")
     p.A_lo, p.out16_lo = _ptr(a16_lo, f16, "a16_lo"), _ptr(out16_lo, f16, "out16_lo")
     p.M, p.N, p.K, p.lda, p.a_mode, p.ldw = M, N, K, lda, a_mode, w_ld
+    if ln_out16 is not None:       # LayerNorm of the fp32 output rows, fused into the GEMM where a workgroup owns whole rows
+        p.ln_gamma, p.ln_beta, p.ln_out16 = _ptr(ln_gamma, torch.float32, "ln_gamma"), _ptr(ln_beta, torch.float32, "ln_beta"), \
+            _ptr(ln_out16, torch.float16, "ln_out16")
+        p.ldln, p.ln_eps = ldln, ln_eps
     if conv:
         p.Cin, p.Hin, p.Win = conv["Cin"], conv["Hin"], conv["Win"]
         p.Hout, p.Wout = conv["Hout"], conv["Wout"]

@@ -91,6 +91,15 @@ class FeedForward(nn.Module, Packable):
                    ldc16=self.dim_out, out16_lo=out16_lo)
 
 
+def _ln_kwargs(rt: Runtime, ln, M: int, C: int):
+    """kwargs that make a GEMM also write LayerNorm(out32 rows) as fp16 (PncGemmParams.ln_*): fused into the epilogue where
+    a workgroup owns whole rows (level 0), the library's LayerNorm kernel right after the GEMM otherwise.  -> (kwargs, x16)"""
+    if ln is None:
+        return {}, None
+    x16 = rt.empty((M, C), torch.float16)
+    return dict(ln_gamma=ln[0], ln_beta=ln[1], ln_out16=x16, ldln=C, ln_eps=1e-5), x16
+
+
 class _AttentionBase(nn.Module, Packable):
     """Parameters of every attention flavour: to_q / to_k / to_v (no bias) and to_out.0 (bias)."""
     kind = "plain"
@@ -138,7 +147,8 @@ class _AttentionBase(nn.Module, Packable):
                    t_gstride=C * E.TEXT_PAD, n_split=0)
         return k, C, vt, E.TEXT_PAD, C * E.TEXT_PAD
 
-    def _run_text(self, rt: Runtime, x16, F, H, W, res32, out32):
+    def _run_text(self, rt: Runtime, x16, F, H, W, res32, out32, ln=None):
+        """`ln` = (gamma, beta) of the LayerNorm that follows the residual add: its fp16 output is returned"""
         pk = self.packed()
         C, M = self.inner_dim, F * H * W
         q = rt.empty((M, C), torch.float16)
@@ -148,11 +158,13 @@ class _AttentionBase(nn.Module, Packable):
         rt.be.attn_views(q, C, k, ldk, vt, ldvt, vt_gs, o, C, groups=F, heads=self.heads, H=H, W=W,
                          views=1, kvH=1, kvW=E.TEXT_PAD, kv_views=1, kv_rows_per_group=E.TEXT_PAD,
                          q_per_kv=F // rt.B, kv_valid=rt.n_text, segs=[[0]], scale=self.scale)
+        lnkw, y16 = _ln_kwargs(rt, ln, M, self.query_dim)
         rt.be.gemm(o, pk["wo"], M=M, N=self.query_dim, K=C, lda=C, bias=pk["bo"], res1=res32,
-                   ldr1=self.query_dim, out32=out32, ldc32=self.query_dim)
+                   ldr1=self.query_dim, out32=out32, ldc32=self.query_dim, **lnkw)
+        return y16
 
     # ---- spatial self-attention over width-sliced views (views = 1: plain attention)
-    def _run_views(self, rt: Runtime, x16, F, H, W, segs, res32, out32):
+    def _run_views(self, rt: Runtime, x16, F, H, W, segs, res32, out32, ln=None):
         pk = self.packed()
         C, N = self.inner_dim, H * W
         M = F * N
@@ -167,11 +179,13 @@ class _AttentionBase(nn.Module, Packable):
         rt.be.attn_views(qk, 2 * C, qk.view(-1)[C:], 2 * C, vt, N, C * N, o, C, groups=F, heads=self.heads,
                          H=H, W=W, views=views, kvH=H, kvW=W, kv_views=views, kv_rows_per_group=N, q_per_kv=1,
                          kv_valid=H * (W // views), segs=segs, scale=self.scale)
+        lnkw, y16 = _ln_kwargs(rt, ln, M, self.query_dim)
         rt.be.gemm(o, pk["wo"], M=M, N=self.query_dim, K=C, lda=C, bias=pk["bo"], res1=res32,
-                   ldr1=self.query_dim, out32=out32, ldc32=self.query_dim)
+                   ldr1=self.query_dim, out32=out32, ldc32=self.query_dim, **lnkw)
+        return y16
 
     # ---- temporal self-attention over the T frames of each pixel
-    def _run_temporal(self, rt: Runtime, x16, N, res32, out32):
+    def _run_temporal(self, rt: Runtime, x16, N, res32, out32, ln=None):
         pk = self.packed()
         C = self.inner_dim
         M = rt.B * rt.T * N              # all T frames of N pixels per sample (N = pixels per rank when frame-sharded)
@@ -181,8 +195,10 @@ class _AttentionBase(nn.Module, Packable):
         flat = qkv.view(-1)
         rt.be.attn_temporal(flat, 3 * C, flat[C:], 3 * C, flat[2 * C:], 3 * C, o, C, B=rt.B, T=rt.T, Npix=N,
                             heads=self.heads, scale=self.scale)
+        lnkw, y16 = _ln_kwargs(rt, ln, M, self.query_dim)
         rt.be.gemm(o, pk["wo"], M=M, N=self.query_dim, K=C, lda=C, bias=pk["bo"], res1=res32,
-                   ldr1=self.query_dim, out32=out32, ldc32=self.query_dim)
+                   ldr1=self.query_dim, out32=out32, ldc32=self.query_dim, **lnkw)
+        return y16
 
 
 class CrossAttention(_AttentionBase):
@@ -243,26 +259,31 @@ class BasicTransformerBlock(nn.Module, Packable):
         return {f"{n}{s}": E.pk_f32(getattr(getattr(self, n), "weight" if s == "w" else "bias"))
                 for n in ("norm1", "norm2", "norm3") for s in ("w", "b")}
 
-    def _run(self, rt: Runtime, t32, F, H, W, branch: str, last: bool):
+    def norm1_params(self):
+        pk = self.packed()
+        return pk["norm1w"], pk["norm1b"]
+
+    def _run(self, rt: Runtime, t32, F, H, W, branch: str, last: bool, x16=None):
         """t32 [M, dim] fp32 stream, updated in place; returns the fp16 copy (hi, lo) of the final x when `last`
-        (operand class `ff_out`)."""
+        (operand class `ff_out`).  `x16`: norm1(t32) when the GEMM that produced t32 has already written it.  norm2 / norm3
+        are written by the residual GEMMs that precede them (PncGemmParams.ln_*), not by LayerNorm launches of their own."""
         pk = self.packed()
         C, N = self.dim, H * W
         M = F * N
-        x16 = E.layer_norm(rt, t32, M, C, pk["norm1w"], pk["norm1b"])
+        if x16 is None:
+            x16 = E.layer_norm(rt, t32, M, C, pk["norm1w"], pk["norm1b"])
+        ln2, ln3 = (pk["norm2w"], pk["norm2b"]), (pk["norm3w"], pk["norm3b"])
         if branch == "temporal":
-            self.attn1._run_temporal(rt, x16, N, t32, t32)
+            x16 = self.attn1._run_temporal(rt, x16, N, t32, t32, ln=ln2)
         elif self.attn1.kind == "intra-view":
             ph, pw = panorama_grid(N)
-            self.attn1._run_views(rt, x16, F, ph, pw, INTRA_SEGS, t32, t32)
+            x16 = self.attn1._run_views(rt, x16, F, ph, pw, INTRA_SEGS, t32, t32, ln=ln2)
         elif self.attn1.kind == "inter-view":
             ph, pw = panorama_grid(N)
-            self.attn1._run_views(rt, x16, F, ph, pw, INTER_SEGS, t32, t32)
+            x16 = self.attn1._run_views(rt, x16, F, ph, pw, INTER_SEGS, t32, t32, ln=ln2)
         else:
-            self.attn1._run_views(rt, x16, F, H, W, [[0]], t32, t32)
-        x16 = E.layer_norm(rt, t32, M, C, pk["norm2w"], pk["norm2b"])
-        self.attn2._run_text(rt, x16, F, H, W, t32, t32)
-        x16 = E.layer_norm(rt, t32, M, C, pk["norm3w"], pk["norm3b"])
+            x16 = self.attn1._run_views(rt, x16, F, H, W, [[0]], t32, t32, ln=ln2)
+        x16 = self.attn2._run_text(rt, x16, F, H, W, t32, t32, ln=ln3)
         if last:
             out16 = rt.empty((M, C), torch.float16)
             out16lo = rt.empty((M, C), torch.float16) if rt.prec.ff_out else None
@@ -354,16 +375,17 @@ class SpatialTemporalTransformer(nn.Module, Packable):
             Fb, Hb, Wb = x.F, x.H, x.W
         Mb = Fb * Hb * Wb
         t32 = rt.empty((Mb, C), torch.float32)
+        lnkw, x16 = _ln_kwargs(rt, blocks[0].norm1_params(), Mb, C)          # norm1 of the first block rides on proj_in
         if branch == "temporal":
             # + position table indexed by t = frame % T (attention.py:1117-1118)
             rt.be.gemm(n16, pk["wi" + sfx], M=Mb, N=C, K=C, lda=C, bias=pk["bi" + sfx], rowbias=pk["pos"],
-                       rb_rows=Hb * Wb, rb_mod=rt.T, out32=t32, ldc32=C, a16_lo=n16lo)
+                       rb_rows=Hb * Wb, rb_mod=rt.T, out32=t32, ldc32=C, a16_lo=n16lo, **lnkw)
         else:
             rt.be.gemm(n16, pk["wi" + sfx], M=Mb, N=C, K=C, lda=C, bias=pk["bi" + sfx], out32=t32, ldc32=C,
-                       a16_lo=n16lo)
+                       a16_lo=n16lo, **lnkw)
         p16 = p16lo = None
         for i, blk in enumerate(blocks):
-            r = blk._run(rt, t32, Fb, Hb, Wb, branch, last=(i == len(blocks) - 1))
+            r = blk._run(rt, t32, Fb, Hb, Wb, branch, last=(i == len(blocks) - 1), x16=x16 if i == 0 else None)
             if r is not None:
                 p16, p16lo = r
         if sh is not None:

@@ -380,6 +380,41 @@ def test_gemm_rejects_a_struct_of_another_abi():
     p.struct_bytes = 224                                                   # round-1 layout
     assert hip.load().pnc_gemm_f16(ctypes.byref(p), None) == -3
 
+@pytest.mark.parametrize("kind", ["plain", "res", "rowbias"])
+@pytest.mark.parametrize("M,N,K,tile", [(1000, 320, 320, "256x320"), (777, 128, 192, "128x128"), (300, 64, 64, "128x128"),
+                                        (600, 640, 128, None), (500, 320, 64, "256x128")])
+def test_gemm_fused_layernorm(M, N, K, tile, kind):
+    """LayerNorm of the fp32 output rows written by the GEMM (PncGemmParams.ln_*): fused into the epilogue when one
+    workgroup owns whole rows (N = 320 on 256x320, N <= 128 on 128x128), the library's LayerNorm kernel after the GEMM
+    otherwise (N = 640; a geometry without the variant) — same result, also in place on the residual stream."""
+    a, w = rnd(M, K, dtype=torch.float16, seed=1), rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=2)
+    bias, res, rowb = rnd(N, seed=3), rnd(M, N, seed=4) * 2.0 + 0.7, rnd(4, N, seed=5)
+    gamma, beta = rnd(N, seed=6) * 0.5 + 1, rnd(N, seed=7) * 0.3
+
+    def outs():
+        return dict(o32=res.clone(), ln=torch.zeros(M, N, device=DEV, dtype=torch.float16))
+
+    def kw(o):
+        d = dict(a16=a, w16=w, M=M, N=N, K=K, lda=K, bias=bias, out32=o["o32"], ldc32=N, ln_gamma=gamma, ln_beta=beta,
+                 ln_out16=o["ln"], ldln=N)
+        if kind == "res":
+            d.update(res1=o["o32"], ldr1=N)
+        elif kind == "rowbias":
+            d.update(rowbias=rowb, rb_rows=100, rb_mod=4)
+        return d
+    prev = hip.set_option(hip.OPT_GEMM_TILE, TILES[tile]) if tile else None
+    try:
+        h, e = _run_both("gemm", outs, kw)
+    finally:
+        if tile:
+            hip.set_option(hip.OPT_GEMM_TILE, prev)
+    check("out32", h["o32"], e["o32"], 2e-3)
+    check("layernorm(out32)", h["ln"], e["ln"], 4e-3)
+    # the normalised rows belong to the fp32 rows the SAME launch wrote
+    ref = torch.nn.functional.layer_norm(h["o32"], (N,), gamma, beta, 1e-5)
+    check("ln vs own out32", h["ln"], ref, 3e-3)
+
+
 # ---------------------------------------------------------------------------------------- split K
 def _splits(**kw):
     """K slices the library would run for this problem (0 workspace -> 1 slice)."""

@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--no-fused-step", action="store_true",
                     help="run the step's elementwise tail (c_in, CFG doubling, c_out / CFG combine / Euler) as the reference's torch "
                          "ops instead of the two fused kernels (SURVEY §8 f1); same bits")
+    ap.add_argument("--no-ln-fusion", action="store_true",
+                    help="A/B: LayerNorm as its own launch after the GEMM instead of inside the residual GEMM epilogues (same result)")
     ap.add_argument("--no-modes", action="store_true", help="do not time the other operand policy (profiling runs)")
     ap.add_argument("--hoist", action="store_true",
                     help="sampler mode (SURVEY §8 f1): text K/V + ControlNet hint stem computed once per schedule, outside "
@@ -244,6 +246,8 @@ def main():
 
     from panacea_amd import build_network, configs, hip, parallel, sampling, synth
     hip.load()
+    if args.no_ln_fusion:
+        hip.set_option(hip.OPT_GEMM_FUSE_LN, 0)
     layout = parallel.layout_for(world, rank, args.parallelism)
     groups = parallel.Groups(layout) if (layout.cfg > 1 or layout.frames > 1) else None
     kw = configs.with_frames(configs.get(args.config), args.frames) if args.config == "full" else configs.get(args.config)

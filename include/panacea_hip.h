@@ -46,7 +46,9 @@ enum {
                                      4 = 256x256 force a geometry where the shape allows it (kernel micro-benchmarks) */
     PNC_OPT_ATTN_VARIANT = 2,     /* 0 (default): by view size; 41 / 81 / 42 / 82 = (waves, query blocks per wave) */
     PNC_OPT_ATTN_DMA = 3,         /* 1 (default): LDS-DMA staging of K / V^T tiles where alignment allows; 0 = register staging */
-    PNC_OPT_COUNT = 4
+    PNC_OPT_GEMM_FUSE_LN = 4,     /* 1 (default): PncGemmParams.ln_* is reduced in the GEMM epilogue where a workgroup owns whole
+                                     rows; 0 = always the LayerNorm kernel after the GEMM (A/B measurements; same result) */
+    PNC_OPT_COUNT = 5
 };
 int pnc_set_option(int option, int value);
 

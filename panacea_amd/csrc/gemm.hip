@@ -207,7 +207,7 @@ extern "C" int pnc_gemm_f16(const PncGemmParams* pp, void* stream) {
     bool ln_fused = false;
     // LayerNorm fused into the epilogue: plain A, fp32 output only, at most one added stream, 16-byte aligned fp16 rows
     if (p.ln_out16 && p.a_mode == PNC_A_PLAIN && (epi == E_O32 || epi == (E_RB | E_O32) || epi == (E_R1 | E_O32)) &&
-        (p.ldln % 8 == 0) && al16(p.ln_out16))
+        (p.ldln % 8 == 0) && al16(p.ln_out16) && pnc_get_option(PNC_OPT_GEMM_FUSE_LN))
         epi |= E_LN;
     int rc2;
     switch (p.a_mode) {

@@ -410,6 +410,16 @@ def test_gemm_fused_layernorm(M, N, K, tile, kind):
             hip.set_option(hip.OPT_GEMM_TILE, prev)
     check("out32", h["o32"], e["o32"], 2e-3)
     check("layernorm(out32)", h["ln"], e["ln"], 4e-3)
+    # fused and un-fused (PNC_OPT_GEMM_FUSE_LN = 0: LayerNorm kernel after the GEMM) agree to fp16 rounding of the output
+    prev = hip.set_option(hip.OPT_GEMM_FUSE_LN, 0)
+    try:
+        u = outs()
+        hip.gemm(**kw(u))
+        torch.cuda.synchronize()
+    finally:
+        hip.set_option(hip.OPT_GEMM_FUSE_LN, prev)
+    assert torch.equal(u["o32"], h["o32"])
+    check("fused vs kernel", h["ln"], u["ln"], 2e-3, 1e-3)
     # the normalised rows belong to the fp32 rows the SAME launch wrote
     ref = torch.nn.functional.layer_norm(h["o32"], (N,), gamma, beta, 1e-5)
     check("ln vs own out32", h["ln"], ref, 3e-3)

@@ -174,9 +174,11 @@ __device__ __forceinline__ void store_h8(half_t* out16, half_t* out16_lo, int64_
 //
 // E_LN (the workgroup owns whole rows: N <= BN, two waves per row): every pass also reduces sum / sum of squares of its
 // row segment over the lanes of the row and accumulates them per row in LDS; after a workgroup barrier each wave adds its
-// partner's half, re-reads the fp32 values IT has just written (same lane, same address: program order makes them
-// visible; they come back from L2) and writes the normalised fp16 row.  This replaces the LayerNorm launch that would
-// otherwise read the stream again from HBM (attention.py:726-747: every residual GEMM of a block is followed by a norm).
+// partner's half and writes the normalised fp16 row from the values it kept ON CHIP: pass 1 writes every final value back
+// into its staging slab and returns the slab to the accumulator registers (dead by then) in the MFMA layout; pass 2 stages
+// them again.  (Re-reading the rows from global memory instead was measured: no gain — a 327 KB tile per workgroup does
+// not stay in L2, so the re-read costs what the LayerNorm launch's read cost.)  This replaces the LayerNorm launch that
+// would otherwise read the stream again from HBM (attention.py:726-747: every residual GEMM of a block is followed by a norm).
 template <int MI, int NI, unsigned EPI>
 __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[MI][NI], float* ep, int lane,
                                          int mw, int nw, int ncols, float2* ln_mine = nullptr,
@@ -299,6 +301,12 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
                     t.x += sm; t.y += sq;
                     ln_mine[i * 32 + ps * RPP + rl] = t;
                 }
+                // the final values go back into the slab they came from: after the slab's passes they return to the (dead)
+                // accumulator registers in the MFMA layout, so that the normalising pass needs no global re-read — a
+                // workgroup's 327 KB tile does not survive in the 4 MB L2 it shares with 31 other CUs
+                float* dst = ep + (ps * RPP + rl) * EPITCH + cl * 8;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
             }
             if (!on) return;
             if constexpr (O32) {
@@ -309,6 +317,15 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
             }
             if constexpr (O16) store_h8(out16, out16_lo, (int64_t)m * p.ldc16 + ncol, v);
         });
+        if constexpr (LN) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every lane's rows are back in the slab
+            static_for<cw>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][jc + j][r] = ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)];
+            });
+        }
     });
     if constexpr (LN) {
         __syncthreads();                      // both halves of every row have their statistics in LDS
@@ -326,15 +343,19 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
                 g0 = ld4(p.ln_gamma + ncol); g1 = ld4(p.ln_gamma + ncol + 4);
                 h0 = ld4(p.ln_beta + ncol); h1 = ld4(p.ln_beta + ncol + 4);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // previous slab fully read back from LDS
+            static_for<cw>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[mfma32_row(r, lane) * EPITCH + j * 32 + (lane & 31)] = acc[i][jc + j][r];
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             f32x4 w0[NP], w1[NP];
 #pragma unroll
-            for (int ps = 0; ps < NP; ++ps) {                      // all loads of the slab first (own stores, L2 hits)
-                const int m = mw + i * 32 + ps * RPP + rl;
-                w0[ps] = z4; w1[ps] = z4;
-                if (col_on && m < p.M) {
-                    const float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
-                    w0[ps] = ld4(op); w1[ps] = ld4(op + 4);
-                }
+            for (int ps = 0; ps < NP; ++ps) {
+                const float* src = ep + (ps * RPP + rl) * EPITCH + cl * 8;
+                w0[ps] = ld4(src); w1[ps] = ld4(src + 4);
             }
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {

@@ -56,7 +56,7 @@ def _oracle_cfg(kw, faithful=True):
                            insert_crossview=kw["insert_crossview"], faithful_temporal_context=faithful)
 
 
-def cpu_baseline(kw, sd, shape, mode="auto", budget_s=480.0):
+def cpu_baseline(kw, sd, shape, mode="auto", budget_s=900.0):
     """The reference's CPU path, restated (oracle = port of the reference's op graph in faithful mode, incl. the per-pixel
     text K/V projection the reference performs), timed on this host's cores.
 
@@ -64,8 +64,8 @@ def cpu_baseline(kw, sd, shape, mode="auto", budget_s=480.0):
                    extrapolation of any kind.  ~5-6 min on the GPU box's 128 threads for BASELINE config 3.
     mode "sample": one CFG half x T frames on a quarter-size (16x192) latent, extrapolated linearly x8 — flatters the CPU
                    (the view attention it under-counts is quadratic in the view size).
-    mode "auto":   the sample first (~45 s); the whole step too when the sample predicts it fits `budget_s`, so that a slow
-                   host cannot push the default bench run past the driver's limit."""
+    mode "auto":   the sample first (~45 s); the whole step too when the sample predicts it fits `budget_s` (15 min), so that a
+                   slow host cannot push the default bench run past the driver's limit."""
     from oracle import panacea_oracle as po
     from panacea_amd import synth
     B, T, h, w = shape
@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "step", "sample", "none"],
                     help="CPU oracle leg (N = 1 only): auto = bounded sample, then ONE whole step when it fits ~8 min")
-    ap.add_argument("--precision", default="precise", choices=["fast", "precise", "precise-all"],
+    ap.add_argument("--precision", default="precise", choices=["fast", "precise", "precise-all", "precise-lite"],
                     help="operand policy of the timed region (DESIGN §6).  precise (default) meets eps max-abs < 1e-3; the "
                          "other of fast / precise is timed too and reported under `modes`")
     ap.add_argument("--parallelism", default="replica", choices=["replica", "cfg", "cfg+frames", "frames"],

@@ -145,6 +145,9 @@ typedef struct PncGemmParams {
 } PncGemmParams;
 
 int pnc_gemm_f16(const PncGemmParams* p, void* stream);
+/* 1 when pnc_gemm_f16 would reduce p->ln_* inside the GEMM epilogue for this problem, 0 when it would launch its LayerNorm
+ * kernel after the GEMM (a caller that times kernel families separately can then issue pnc_layernorm itself) */
+int pnc_gemm_fuses_layernorm(const PncGemmParams* p);
 /* floats of workspace with which pnc_gemm_f16 would split K for this problem (0: it would not) */
 int64_t pnc_gemm_workspace_floats(const PncGemmParams* p);
 

@@ -194,21 +194,40 @@ extern "C" int64_t pnc_gemm_workspace_floats(const PncGemmParams* pp) {
     return ks > 1 ? (int64_t)ks * pp->M * pp->N : 0;
 }
 
+// the epilogue variant of a launch incl. the E_LN decision that does not depend on the tile (dispatch_plain settles the rest)
+static unsigned epilogue_with_ln(const PncGemmParams& p) {
+    unsigned epi = select_epilogue(p);
+    // LayerNorm fused into the epilogue: plain A, fp32 output only, at most one added stream, 16-byte aligned fp16 rows
+    if (p.ln_out16 && p.a_mode == PNC_A_PLAIN && (epi == E_O32 || epi == (E_RB | E_O32) || epi == (E_R1 | E_O32)) &&
+        (p.ldln % 8 == 0) && al16(p.ln_out16) && pnc_get_option(PNC_OPT_GEMM_FUSE_LN))
+        epi |= E_LN;
+    return epi;
+}
+
+static void normalise(PncGemmParams& p) {
+    if (!p.out16t) p.n_split = p.N;
+    if (p.ldw == 0) p.ldw = p.K;
+    if (!p.res1 && p.res2) { p.res1 = p.res2; p.ldr1 = p.ldr2; p.res2 = nullptr; }   // fp32 addition commutes bit-exactly for two terms
+}
+
+extern "C" int pnc_gemm_fuses_layernorm(const PncGemmParams* pp) {
+    if (!pp || validate(*pp) != PNC_OK || !pp->ln_out16) return 0;
+    PncGemmParams p = *pp;
+    normalise(p);
+    if (!(epilogue_with_ln(p) & E_LN)) return 0;
+    const TileChoice tc = choose_tile(p);
+    return ln_whole_rows(p, tc) ? 1 : 0;
+}
+
 extern "C" int pnc_gemm_f16(const PncGemmParams* pp, void* stream) {
     if (!pp) return PNC_EINVAL;
     const int rc = validate(*pp);
     if (rc != PNC_OK) return rc;
     PncGemmParams p = *pp;
-    if (!p.out16t) p.n_split = p.N;
-    if (p.ldw == 0) p.ldw = p.K;
-    if (!p.res1 && p.res2) { p.res1 = p.res2; p.ldr1 = p.ldr2; p.res2 = nullptr; }   // fp32 addition commutes bit-exactly for two terms
-    unsigned epi = select_epilogue(p);
+    normalise(p);
+    const unsigned epi = epilogue_with_ln(p);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     bool ln_fused = false;
-    // LayerNorm fused into the epilogue: plain A, fp32 output only, at most one added stream, 16-byte aligned fp16 rows
-    if (p.ln_out16 && p.a_mode == PNC_A_PLAIN && (epi == E_O32 || epi == (E_RB | E_O32) || epi == (E_R1 | E_O32)) &&
-        (p.ldln % 8 == 0) && al16(p.ln_out16) && pnc_get_option(PNC_OPT_GEMM_FUSE_LN))
-        epi |= E_LN;
     int rc2;
     switch (p.a_mode) {
         case PNC_A_PLAIN: rc2 = dispatch_plain(p, epi, st, &ln_fused); break;

@@ -868,6 +868,11 @@ static inline TileChoice choose_tile(const PncGemmParams& p) {
     return {pick, 1};
 }
 
+// one workgroup owns whole output rows: the geometries that carry an E_LN variant (level-0 width 320 on 256x320; <= 128 on 128x128)
+static inline bool ln_whole_rows(const PncGemmParams& p, TileChoice tc) {
+    return tc.ksplit == 1 && ((tc.tile == T_256x320 && p.N <= 320) || (tc.tile == T_128x128 && p.N <= 128));
+}
+
 // launch the variant EPI of AMODE on the chosen tile
 template <int AMODE, unsigned EPI>
 int launch_tile(const PncGemmParams& p, hipStream_t st, TileChoice tc) {

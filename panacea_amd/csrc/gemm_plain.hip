@@ -16,8 +16,7 @@ int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st, bool* l
     const TileChoice tc = choose_tile(p);
     if (epi & E_LN) {
         // fuse only when ONE column tile covers the row (level-0 width 320 on 256x320; <= 128 on 128x128)
-        const bool whole_rows = tc.ksplit == 1 && ((tc.tile == T_256x320 && p.N <= 320) || (tc.tile == T_128x128 && p.N <= 128));
-        if (whole_rows) *ln_fused = true;
+        if (ln_whole_rows(p, tc)) *ln_fused = true;
         else epi &= ~E_LN;                      // the caller runs the LayerNorm kernel after this GEMM instead
     }
     if (tc.tile == T_128x32 && epi != E_O16 && epi != E_O32) epi = E_GENERIC;     // narrow-N: two fast variants

@@ -54,7 +54,8 @@ def load():
 def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bias=None, rowbias=None,
          rb_rows=0, rb_mod=0, res1=None, ldr1=0, res2=None, ldr2=0, out32=None, ldc32=0, out16=None,
          ldc16=0, out16t=None, ldt=0, t_rows=0, t_gstride=0, n_split=0, act=ACT_NONE, geglu=False,
-         a16_lo=None, out16_lo=None, w_ld=0, ln_gamma=None, ln_beta=None, ln_out16=None, ldln=0, ln_eps=1e-5):
+         a16_lo=None, out16_lo=None, w_ld=0, ln_gamma=None, ln_beta=None, ln_out16=None, ldln=0, ln_eps=1e-5,
+         ln_in_library=False):
     assert (not STRICT_DTYPES) or (a16.dtype == torch.float16 and w16.dtype == torch.float16)
     assert K % 8 == 0
     Wm = _mat(w16, N, K, w_ld or K).float()

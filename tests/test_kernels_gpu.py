@@ -420,6 +420,12 @@ def test_gemm_fused_layernorm(M, N, K, tile, kind):
         hip.set_option(hip.OPT_GEMM_FUSE_LN, prev)
     assert torch.equal(u["o32"], h["o32"])
     check("fused vs kernel", h["ln"], u["ln"], 2e-3, 1e-3)
+    # ln_* handed to the library unconditionally (its own trailing LayerNorm launch where rows span workgroups)
+    lb = outs()
+    hip.gemm(**kw(lb), ln_in_library=True)
+    torch.cuda.synchronize()
+    assert torch.equal(lb["o32"], h["o32"])
+    check("library-side ln", lb["ln"], h["ln"], 2e-3, 1e-3)
     # the normalised rows belong to the fp32 rows the SAME launch wrote
     ref = torch.nn.functional.layer_norm(h["o32"], (N,), gamma, beta, 1e-5)
     check("ln vs own out32", h["ln"], ref, 3e-3)

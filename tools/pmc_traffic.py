@@ -31,7 +31,27 @@ def per_kernel(d, counter):
     return agg
 
 
+def mfma_record(mdir, evals, step_ms):
+    """SQ_VALU_MFMA_BUSY_CYCLES summed over all kernels of one evaluation vs the cycles 1024 SIMDs offer in a step"""
+    busy = per_kernel(mdir, "SQ_VALU_MFMA_BUSY_CYCLES")
+    per_eval = sum(busy.values()) / evals
+    top = sorted(busy.items(), key=lambda kv: -kv[1])[:12]
+    return {"mfma_busy_cycles_per_step": per_eval,
+            "note": "SQ_VALU_MFMA_BUSY_CYCLES counts cycles of the 32 cycles a 32x32x16 f16 MFMA occupies its SIMD: 96.59 TFLOP "
+                    "algorithmic = 9.43e10 cycles at 1024 flop/cycle/SIMD... /4 SIMDs per CU x 256 CUs",
+            "utilisation_at_2p1GHz": per_eval / (1024 * 2.1e9 * step_ms * 1e-3),
+            "top_kernels": [[k[:90], v / evals] for k, v in top]}
+
+
 def main():
+    if sys.argv[1] == "--mfma":
+        mdir, evals, prec, step_ms = sys.argv[2], int(sys.argv[3]), sys.argv[4], float(sys.argv[5])
+        out = ROOT / "profiles" / "round2" / "pmc_traffic.json"
+        doc = json.loads(out.read_text()) if out.exists() else {"records": {}}
+        doc.setdefault("mfma", {})[prec] = mfma_record(mdir, evals, step_ms)
+        out.write_text(json.dumps(doc, indent=1))
+        print(json.dumps(doc["mfma"][prec], indent=1)[:1500])
+        return
     fdir, wdir, evals, prec, cmd = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")      # KB
     ln_f = sum(v for k, v in fetch.items() if "layernorm" in k) * 1024 / evals

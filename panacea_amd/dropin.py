@@ -34,12 +34,20 @@ TARGETS = {
 # does `from ..modules.diffusionmodules.model import Decoder, Encoder`, so the class is rebound right after model.py
 # is first imported; the Encoder, quant / post_quant convs and the engine stay the reference's.
 FIRST_STAGE_TARGETS = {"sgm.modules.diffusionmodules.model": ("Decoder",)}
+# opt-in (install(conditioner=True) / PANACEA_DROPIN_CONDITIONER=1): the conditioner classes the YAML names under
+# `conditioner_config` (inference_nuscenes.yaml:72-96).  The text tower then runs on the kernels with the weights the
+# engine checkpoint carries under `conditioner.embedders.0.model.*`; tokenisation stays open_clip's.
+CONDITIONER_TARGETS = {"sgm.modules.encoders.modules": ("GeneralConditioner", "IdentityEncoder", "VAEEmbedder",
+                                                        "FrozenOpenCLIPEmbedder")}
 
 
 def _patch(module) -> None:
     from . import nn as mirror
     from .nn import model as first_stage
-    src = first_stage if module.__name__.endswith("diffusionmodules.model") else mirror
+    if module.__name__.endswith("encoders.modules"):
+        from . import conditioner as src
+    else:
+        src = first_stage if module.__name__.endswith("diffusionmodules.model") else mirror
     for cls in TARGETS[module.__name__]:
         setattr(module, "_reference_" + cls, getattr(module, cls, None))
         setattr(module, cls, getattr(src, cls))
@@ -77,12 +85,15 @@ class _Finder(importlib.abc.MetaPathFinder):
 _installed = False
 
 
-def install(lazy: bool = False, first_stage: bool = False) -> None:
-    """Rebind the three network classes (and, with first_stage=True, the VAE `Decoder`).  lazy=False imports the
-    reference modules now (they must be importable); lazy=True only arms an import hook."""
+def install(lazy: bool = False, first_stage: bool = False, conditioner: bool = False) -> None:
+    """Rebind the three network classes (and, with first_stage=True, the VAE `Decoder`; with conditioner=True the
+    conditioner classes).  lazy=False imports the reference modules now (they must be importable); lazy=True only arms
+    an import hook."""
     global _installed
     if first_stage:
         TARGETS.update(FIRST_STAGE_TARGETS)
+    if conditioner:
+        TARGETS.update(CONDITIONER_TARGETS)
     if not _installed:
         sys.meta_path.insert(0, _Finder())
         _installed = True

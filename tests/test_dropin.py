@@ -104,3 +104,24 @@ def test_dropin_rebinds_reference_targets():
     dropin._installed = False
     for k in dropin.FIRST_STAGE_TARGETS:
         dropin.TARGETS.pop(k, None)
+
+
+def test_dropin_rebinds_the_conditioner_classes_on_request():
+    """install(conditioner=True): the YAML's conditioner targets resolve to the mirror classes (needs /root/reference and the
+    import shims of the golden generator: build container only)."""
+    from oracle import ref_import
+    if not ref_import.available():
+        pytest.skip("/root/reference not present")
+    from oracle.gen_golden_conditioner import import_conditioner
+    from panacea_amd import conditioner as C, dropin
+    m = import_conditioner()
+    saved = {k: getattr(m, k) for k in dropin.CONDITIONER_TARGETS["sgm.modules.encoders.modules"]}
+    try:
+        dropin.install(lazy=True, conditioner=True)
+        assert m.GeneralConditioner is C.GeneralConditioner and m.FrozenOpenCLIPEmbedder is C.FrozenOpenCLIPEmbedder
+        assert m._reference_GeneralConditioner is saved["GeneralConditioner"]
+    finally:
+        for k, v in saved.items():
+            setattr(m, k, v)
+        for k in dropin.CONDITIONER_TARGETS:
+            dropin.TARGETS.pop(k, None)

@@ -212,6 +212,8 @@ def main():
                          "ops instead of the two fused kernels (SURVEY §8 f1); same bits")
     ap.add_argument("--no-ln-fusion", action="store_true",
                     help="A/B: LayerNorm as its own launch after the GEMM instead of inside the residual GEMM epilogues (same result)")
+    ap.add_argument("--gemm-group-m", type=int, default=0,
+                    help="A/B: PNC_OPT_GEMM_GROUP_M (0 = auto, -1 = plain tile order, k = groups of k row panels); same result")
     ap.add_argument("--no-modes", action="store_true", help="do not time the other operand policy (profiling runs)")
     ap.add_argument("--hoist", action="store_true",
                     help="sampler mode (SURVEY §8 f1): text K/V + ControlNet hint stem computed once per schedule, outside "
@@ -248,6 +250,8 @@ def main():
     hip.load()
     if args.no_ln_fusion:
         hip.set_option(hip.OPT_GEMM_FUSE_LN, 0)
+    if args.gemm_group_m:
+        hip.set_option(hip.OPT_GEMM_GROUP_M, args.gemm_group_m)
     layout = parallel.layout_for(world, rank, args.parallelism)
     groups = parallel.Groups(layout) if (layout.cfg > 1 or layout.frames > 1) else None
     kw = configs.with_frames(configs.get(args.config), args.frames) if args.config == "full" else configs.get(args.config)

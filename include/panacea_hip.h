@@ -48,7 +48,10 @@ enum {
     PNC_OPT_ATTN_DMA = 3,         /* 1 (default): LDS-DMA staging of K / V^T tiles where alignment allows; 0 = register staging */
     PNC_OPT_GEMM_FUSE_LN = 4,     /* 1 (default): PncGemmParams.ln_* is reduced in the GEMM epilogue where a workgroup owns whole
                                      rows; 0 = always the LayerNorm kernel after the GEMM (A/B measurements; same result) */
-    PNC_OPT_COUNT = 5
+    PNC_OPT_GEMM_GROUP_M = 5,     /* 0 (default): tiles of a GEMM with more than 8 column tiles are walked in groups of 4 row panels
+                                     (L2 reuse of W where it exceeds the cache); k > 0 forces groups of k; -1 = plain order.  Results
+                                     do not depend on it (same tiles, same arithmetic) */
+    PNC_OPT_COUNT = 6
 };
 int pnc_set_option(int option, int value);
 

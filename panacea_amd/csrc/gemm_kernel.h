@@ -516,7 +516,7 @@ __device__ __forceinline__ void epi_generic(const PncGemmParams& p, f32x16 (&acc
 template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE, unsigned EPI>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams pin, const int ksplit,
                                                                    const int nfull, const int tail_f,
-                                                                   const float* __restrict__ phi_g) {
+                                                                   const float* __restrict__ phi_g, const int group_m) {
     PncGemmParams p = pin;
     constexpr int NW = WGM * WGN;                          // waves per workgroup
     constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
@@ -555,7 +555,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         tile = nfull + j / tail_f; part = j - (j / tail_f) * tail_f;
     }
     const bool split_rows = (ksplit == 1) && ((int)blockIdx.x >= nfull) && (tail_f > 1);
-    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    // Tile id -> (tm, tn).  Default: tn fastest, so the ~32 tiles an XCD runs at once are 32 / tiles_n row panels x all
+    // column tiles.  With many column tiles (FF1: 10-40, QKV at C = 1280: 12-15) that is ONE panel against the whole of W,
+    // and where W exceeds the 4 MB L2 (every level but 0) W is re-streamed from the fabric once per row panel: 1.26 GB per
+    // FF1 launch at every level (profiles/round2/pmc_precise_fetch_by_kernel.txt: 52 GB per step in the GEGLU kernel alone).
+    // group_m > 0: walk group_m row panels x the column tiles instead (tm fastest inside a group), so the concurrent set
+    // is group_m x (32 / group_m) tiles and each W column tile is fetched once per GROUP of panels.  Same tiles, same
+    // arithmetic: results are bit-identical.
+    int tn, tm;
+    if (group_m > 0) {
+        const int width = group_m * tiles_n;
+        const int gid = tile / width, first_m = gid * group_m;
+        const int gsz = min(tiles_m - first_m, group_m);
+        const int in = tile - gid * width;
+        tm = first_m + in % gsz; tn = in / gsz;
+    } else {
+        tn = tile % tiles_n; tm = tile / tiles_n;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int ntiles_all = (p.K + BK - 1) / BK;
     const int kt_begin = (int)((int64_t)kslice * ntiles_all / ksplit);
@@ -806,7 +822,14 @@ int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
         q.bias = nullptr; q.rowbias = nullptr; q.res1 = nullptr; q.res2 = nullptr;
         q.out16 = nullptr; q.out16_lo = nullptr; q.out16t = nullptr; q.n_split = p.N; q.act = PNC_ACT_NONE;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds + (GEGLU ? PHI_BYTES : 0), st, q, ksplit, nfull, tail_f, phi);
+    // grouped tile order (see the kernel): auto = 4 row panels per group when the problem has more than 8 column tiles
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int gopt = pnc_get_option(PNC_OPT_GEMM_GROUP_M);
+    int group_m = gopt > 0 ? gopt : (gopt == 0 && tiles_n > 8 ? 4 : 0);
+    if (group_m > tiles_m) group_m = tiles_m;
+    if (tiles_n < 2) group_m = 0;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds + (GEGLU ? PHI_BYTES : 0), st, q, ksplit, nfull, tail_f, phi,
+                       group_m);
     if (ksplit > 1) return launch_splitk_reduce(p, ksplit, st);
     return pnc_launch_status();
 }

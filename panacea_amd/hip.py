@@ -144,7 +144,7 @@ def load():
     return lib
 
 
-OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA, OPT_GEMM_FUSE_LN = 0, 1, 2, 3, 4
+OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA, OPT_GEMM_FUSE_LN, OPT_GEMM_GROUP_M = 0, 1, 2, 3, 4, 5
 
 
 def set_option(option: int, value: int) -> int:

@@ -431,6 +431,32 @@ def test_gemm_fused_layernorm(M, N, K, tile, kind):
     check("ln vs own out32", h["ln"], ref, 3e-3)
 
 
+@pytest.mark.parametrize("M,N,K,geglu", [(1500, 2560, 128, True), (2000, 3840, 64, False), (700, 5120, 64, True)])
+def test_gemm_grouped_tile_order_is_bit_identical(M, N, K, geglu):
+    """PNC_OPT_GEMM_GROUP_M walks the output tiles in groups of row panels (L2 reuse of W): same tiles, same bits, for every
+    group size incl. ones that do not divide the panel count, with and without the tail split."""
+    a = rnd(M, K, dtype=torch.float16, seed=1)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=2)
+    bias = rnd(N, seed=3)
+    No = N // 2 if geglu else N
+
+    def run(g):
+        o = torch.zeros(M, No, device=DEV, dtype=torch.float16)
+        prev = hip.set_option(hip.OPT_GEMM_GROUP_M, g)
+        try:
+            hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, geglu=geglu, out16=o, ldc16=No)
+            torch.cuda.synchronize()
+        finally:
+            hip.set_option(hip.OPT_GEMM_GROUP_M, prev)
+        return o
+    ref = run(-1)
+    e = torch.zeros(M, No, device=DEV, dtype=torch.float16)
+    emu.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, geglu=geglu, out16=e, ldc16=No)
+    check("plain order vs emu", ref, e, 4e-3)
+    for g in (0, 1, 3, 4, 7):
+        assert torch.equal(run(g), ref), g
+
+
 # ---------------------------------------------------------------------------------------- split K
 def _splits(**kw):
     """K slices the library would run for this problem (0 workspace -> 1 slice)."""

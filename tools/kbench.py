@@ -197,9 +197,49 @@ def bench_tiles(flt):
             del a, w
 
 
+def bench_group_m(flt):
+    """tile-order A/B (PNC_OPT_GEMM_GROUP_M): -1 = plain order, 0 = auto, 2 / 4 / 8 forced, on the shapes with many column tiles"""
+    for li, (C, H, W) in enumerate(LEVELS):
+        M = F * H * W
+        for name, N, K, kind in [("ff1", 8 * C, C, "geglu"), ("qkv", 3 * C, C, "o16"), ("ff2", C, 4 * C, "res"),
+                                 ("conv3x3", C, 9 * C, "conv3x3")]:
+            tag = f"group_m L{li} {name} M={M} N={N} K={K}"
+            if flt and flt not in tag:
+                continue
+            w = h16(N, K)
+            bias = torch.zeros(N, device=DEV)
+            a = h16(F, H, W, C) if kind == "conv3x3" else h16(M, K)
+            o32 = torch.zeros(M, N, device=DEV) if kind in ("res", "conv3x3") else None
+            o16 = torch.empty(M, N // 2 if kind == "geglu" else N, device=DEV, dtype=torch.float16) if kind in ("geglu", "o16") else None
+
+            def fn():
+                if kind == "geglu":
+                    hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, geglu=True, out16=o16, ldc16=N // 2)
+                elif kind == "o16":
+                    hip.gemm(a, w, M=M, N=N, K=K, lda=K, out16=o16, ldc16=N)
+                elif kind == "res":
+                    hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, res1=o32, ldr1=N, out32=o32, ldc32=N)
+                else:
+                    hip.gemm(a, w, M=M, N=N, K=K, a_mode=hip.A_CONV3X3, bias=bias, out32=o32, ldc32=N,
+                             conv=dict(Cin=C, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0))
+            res = []
+            for g in (-1, 0, 2, 4, 8):
+                prev = hip.set_option(hip.OPT_GEMM_GROUP_M, g)
+                try:
+                    res.append((g, timeit(fn, iters=12, warm=2)))
+                finally:
+                    hip.set_option(hip.OPT_GEMM_GROUP_M, prev)
+            fl = 2.0 * M * N * K
+            print(f"{tag:48s} " + "  ".join(f"g={g:2d} {tt * 1e6:7.1f}us {fl / tt / 1e12:6.1f}TF" for g, tt in res), flush=True)
+            del a, w
+
+
 if __name__ == "__main__":
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     print(torch.cuda.get_device_name(0))
+    if flt.startswith("group_m"):
+        bench_group_m(sys.argv[2] if len(sys.argv) > 2 else "")
+        sys.exit(0)
     if flt.startswith("tiles"):
         bench_tiles(sys.argv[2] if len(sys.argv) > 2 else "")
         sys.exit(0)

@@ -16,10 +16,25 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-# all LayerNorm launches of one network evaluation at BASELINE config 3: 207 launches, 6 B per element in total
-# (4 B fp32 read + 2 B fp16 write); element count from the module tree: 9 LN per STT x (5 + 2 STT at L0 ...) -- taken from
-# bench.py's own kernel breakdown (layernorm bytes = 6 * elements): 41.9 GB per evaluation
-LN_BYTES_PER_EVAL = 42.04e9
+# Calibration kernel: LayerNorm moves exactly 6 B per element (4 B fp32 read + 2 B fp16 write).  The elements of each dispatch
+# follow from its grid: layernorm_kernel<J> runs 16 rows per 256-thread block, J = ceil(C / 256) names the width class.
+LN_WIDTH = {2: 320, 3: 640, 5: 1280}
+
+
+def layernorm_bytes(d):
+    """bytes all LayerNorm dispatches under directory d move (summed over the run), from Grid_Size and the template width"""
+    import re
+    total, seen = 0.0, set()
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            m = re.search(r"layernorm_kernelILi(\d+)E|layernorm_kernel<(\d+)>", r["Kernel_Name"])
+            if not m or r["Dispatch_Id"] in seen:
+                continue
+            seen.add(r["Dispatch_Id"])
+            j = int(m.group(1) or m.group(2))
+            rows = int(r["Grid_Size"]) // 256 * 16
+            total += 6.0 * rows * LN_WIDTH[j]
+    return total
 
 
 def per_kernel(d, counter):
@@ -56,6 +71,7 @@ def main():
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")      # KB
     ln_f = sum(v for k, v in fetch.items() if "layernorm" in k) * 1024 / evals
     ln_w = sum(v for k, v in write.items() if "layernorm" in k) * 1024 / evals
+    LN_BYTES_PER_EVAL = layernorm_bytes(fdir) / evals
     ff, wf = (LN_BYTES_PER_EVAL * 4 / 6) / ln_f, (LN_BYTES_PER_EVAL * 2 / 6) / ln_w
     tf, tw = sum(fetch.values()) * 1024 / evals, sum(write.values()) * 1024 / evals
     rec = {"build_stamp": (ROOT / "panacea_amd" / "lib" / "build.stamp").read_text().strip(), "command": cmd,

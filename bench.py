@@ -213,7 +213,7 @@ def main():
     ap.add_argument("--no-ln-fusion", action="store_true",
                     help="A/B: LayerNorm as its own launch after the GEMM instead of inside the residual GEMM epilogues (same result)")
     ap.add_argument("--gemm-group-m", type=int, default=0,
-                    help="A/B: PNC_OPT_GEMM_GROUP_M (0 = auto, -1 = plain tile order, k = groups of k row panels); same result")
+                    help="A/B: PNC_OPT_GEMM_GROUP_M (0 = auto, 1 = plain tile order, k = groups of k row panels); same result")
     ap.add_argument("--no-modes", action="store_true", help="do not time the other operand policy (profiling runs)")
     ap.add_argument("--hoist", action="store_true",
                     help="sampler mode (SURVEY §8 f1): text K/V + ControlNet hint stem computed once per schedule, outside "

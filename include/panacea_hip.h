@@ -49,7 +49,7 @@ enum {
     PNC_OPT_GEMM_FUSE_LN = 4,     /* 1 (default): PncGemmParams.ln_* is reduced in the GEMM epilogue where a workgroup owns whole
                                      rows; 0 = always the LayerNorm kernel after the GEMM (A/B measurements; same result) */
     PNC_OPT_GEMM_GROUP_M = 5,     /* 0 (default): tiles of a GEMM with more than 8 column tiles are walked in groups of 4 row panels
-                                     (L2 reuse of W where it exceeds the cache); k > 0 forces groups of k; -1 = plain order.  Results
+                                     (L2 reuse of W where it exceeds the cache); k > 1 forces groups of k; 1 = plain order.  Results
                                      do not depend on it (same tiles, same arithmetic) */
     PNC_OPT_COUNT = 6
 };

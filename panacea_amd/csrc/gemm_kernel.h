@@ -825,7 +825,7 @@ int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
     // grouped tile order (see the kernel): auto = 4 row panels per group when the problem has more than 8 column tiles
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int gopt = pnc_get_option(PNC_OPT_GEMM_GROUP_M);
-    int group_m = gopt > 0 ? gopt : (gopt == 0 && tiles_n > 8 ? 4 : 0);
+    int group_m = gopt > 0 ? gopt : (tiles_n > 8 ? 4 : 0);           // 1 = plain order
     if (group_m > tiles_m) group_m = tiles_m;
     if (tiles_n < 2) group_m = 0;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds + (GEGLU ? PHI_BYTES : 0), st, q, ksplit, nfull, tail_f, phi,

@@ -149,10 +149,9 @@ OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA, OPT_GEMM_FUS
 
 def set_option(option: int, value: int) -> int:
     """pnc_set_option: process-global tuning / test switch of the library; returns the previous value."""
-    prev = load().pnc_set_option(option, value)
-    if prev == -1:
+    if not 0 <= option <= OPT_GEMM_GROUP_M:
         raise PncError(f"unknown library option {option}")
-    return prev
+    return load().pnc_set_option(option, value)
 
 
 class Profiler:

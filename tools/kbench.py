@@ -198,7 +198,7 @@ def bench_tiles(flt):
 
 
 def bench_group_m(flt):
-    """tile-order A/B (PNC_OPT_GEMM_GROUP_M): -1 = plain order, 0 = auto, 2 / 4 / 8 forced, on the shapes with many column tiles"""
+    """tile-order A/B (PNC_OPT_GEMM_GROUP_M): 1 = plain order, 0 = auto, 2 / 4 / 8 / 16 forced, on the shapes with many column tiles"""
     for li, (C, H, W) in enumerate(LEVELS):
         M = F * H * W
         for name, N, K, kind in [("ff1", 8 * C, C, "geglu"), ("qkv", 3 * C, C, "o16"), ("ff2", C, 4 * C, "res"),
@@ -223,7 +223,7 @@ def bench_group_m(flt):
                     hip.gemm(a, w, M=M, N=N, K=K, a_mode=hip.A_CONV3X3, bias=bias, out32=o32, ldc32=N,
                              conv=dict(Cin=C, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0))
             res = []
-            for g in (-1, 0, 2, 4, 8):
+            for g in (1, 0, 2, 4, 8, 16):
                 prev = hip.set_option(hip.OPT_GEMM_GROUP_M, g)
                 try:
                     res.append((g, timeit(fn, iters=12, warm=2)))

@@ -318,3 +318,14 @@ def test_fused_sampler_step_on_device_replays_the_reference_trajectory():
     print("fused == plain bitwise:", torch.equal(fused, plain), (fused - plain).abs().max().item())
     assert torch.allclose(fused, plain, rtol=0, atol=2e-5)
     assert torch.equal(graphed, fused)
+
+
+def test_yaml_exact_25_step_trajectory_vs_oracle_on_the_gpu():
+    """BASELINE config 5's setup (25-step schedule, last-frame `concat` conditioning, share-noise init) through the HIP
+    path with hoisted invariants and the fused device step, against the sampler mirrors driven by the CPU oracle."""
+    import test_sampling as ts
+    ref, got = ts._yaml_exact_trajectories(DEV)
+    rms = ref.pow(2).mean().sqrt().item()
+    d = (got - ref).abs()
+    print("config-5 setup, 25 steps:", d.max().item(), d.mean().item(), "latent rms", rms)
+    assert d.max().item() <= 3e-3 * rms and d.mean().item() <= 5e-4 * rms

@@ -212,6 +212,8 @@ def main():
                          "ops instead of the two fused kernels (SURVEY §8 f1); same bits")
     ap.add_argument("--no-ln-fusion", action="store_true",
                     help="A/B: LayerNorm as its own launch after the GEMM instead of inside the residual GEMM epilogues (same result)")
+    ap.add_argument("--stencil-tiles", type=int, default=None,
+                    help="A/B: PNC_OPT_STENCIL_TILES (0 = one gathered A tile per tap everywhere, 1 = default, 2 = halo tiles wherever the shape allows)")
     ap.add_argument("--gemm-group-m", type=int, default=0,
                     help="A/B: PNC_OPT_GEMM_GROUP_M (0 = auto, 1 = plain tile order, k = groups of k row panels); same result")
     ap.add_argument("--no-modes", action="store_true", help="do not time the other operand policy (profiling runs)")
@@ -250,6 +252,8 @@ def main():
     hip.load()
     if args.no_ln_fusion:
         hip.set_option(hip.OPT_GEMM_FUSE_LN, 0)
+    if args.stencil_tiles is not None:
+        hip.set_option(hip.OPT_STENCIL_TILES, args.stencil_tiles)
     if args.gemm_group_m:
         hip.set_option(hip.OPT_GEMM_GROUP_M, args.gemm_group_m)
     layout = parallel.layout_for(world, rank, args.parallelism)

@@ -51,7 +51,11 @@ enum {
     PNC_OPT_GEMM_GROUP_M = 5,     /* 0 (default): tiles of a GEMM with more than 8 column tiles are walked in groups of 4 row panels
                                      (L2 reuse of W where it exceeds the cache); k > 1 forces groups of k; 1 = plain order.  Results
                                      do not depend on it (same tiles, same arithmetic) */
-    PNC_OPT_COUNT = 6
+    PNC_OPT_STENCIL_TILES = 6,    /* 1 (default): stride-1 3x3 convs with Cin % 64 == 0 on grids that fill the chip stage ONE spatial tile of
+                                     the input incl. its halo per 64-channel slice and read the nine taps from it (gemm_stencil_tile.hip);
+                                     0 = always one gathered A tile per tap; 2 = wherever the shape allows (tests).  Bit-identical
+                                     results either way */
+    PNC_OPT_COUNT = 7
 };
 int pnc_set_option(int option, int value);
 
@@ -70,7 +74,7 @@ int pnc_set_option(int option, int value);
  *     -> nn.Conv2d 3x3 (openaimodel.py:413,459,125 (Upsample),187 (Downsample),
  *        974 (stem), 1251 (out); controlmodel.py:44-58 (hint stem))
  *   a_mode PNC_A_CONV1D_T: temporal conv1d k=3 pad 1 over frames of one pixel,
- *        rows m = (b*T+t)*Npix + p, K = 3*C ordered (dt,ci)
+ *        rows m = (b*T+t)*Npix + p, K = 3*C ordered (dt,ci), or (ci/64, dt, ci%64) when C % 64 == 0
  *     -> nn.Conv1d (openaimodel.py:418,469) applied on "(b h w) c t"
  *
  *   epilogue (all optional, applied in this order):

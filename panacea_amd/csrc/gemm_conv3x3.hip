@@ -6,6 +6,7 @@ namespace pnc_gemm {
 
 int dispatch_conv3x3(const PncGemmParams& p, unsigned epi, hipStream_t st) {
     constexpr int AM = PNC_A_CONV3X3;
+    if (const int geometry = conv3x3_tile_geometry(p, epi)) return dispatch_conv3x3_tiles(p, epi, geometry, st);
     const TileChoice tc = choose_tile(p);
     if (tc.tile == T_128x32 && epi != E_O16 && epi != E_O32) epi = E_GENERIC;
     switch (epi) {

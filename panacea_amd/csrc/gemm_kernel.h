@@ -130,7 +130,14 @@ __device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, con
         }
         return ok ? A + s.base + ((int64_t)iy * p.Win + ix) * p.Cin + ci : g_zero_chunk;
     } else {
-        const int tap = kc / p.Cin, ci = kc - tap * p.Cin;
+        // K order: (dt, ci); (ci/64, dt, ci%64) when Cin % 64 == 0 (the three taps of a slice are consecutive K tiles)
+        int tap, ci;
+        if ((p.Cin & 63) == 0) {
+            const int cc = kc / 192, r = kc - cc * 192;
+            tap = r >> 6; ci = (cc << 6) + (r & 63);
+        } else {
+            tap = kc / p.Cin; ci = kc - tap * p.Cin;
+        }
         const int tt = s.y + tap - 1;
         return (tt < 0 || tt >= p.T) ? g_zero_chunk : A + s.base + (int64_t)(tap - 1) * p.Npix * p.Cin + ci;
     }
@@ -179,9 +186,24 @@ __device__ __forceinline__ void store_h8(half_t* out16, half_t* out16_lo, int64_
 // them again.  (Re-reading the rows from global memory instead was measured: no gain — a 327 KB tile per workgroup does
 // not stay in L2, so the re-read costs what the LayerNorm launch's read cost.)  This replaces the LayerNorm launch that
 // would otherwise read the stream again from HBM (attention.py:726-747: every residual GEMM of a block is followed by a norm).
-template <int MI, int NI, unsigned EPI>
+// wave-tile row -> output row m.  RowLinear: the GEMM's rows are consecutive; RowHalo (conv3x3 halo kernel): the wave tile is
+// a strip of a TH x 2^TWS spatial tile of one frame.
+struct RowLinear {
+    int mw;
+    __device__ __forceinline__ int operator()(int lr) const { return mw + lr; }
+};
+template <int TWS>
+struct RowHalo {
+    int base, W, lr0;           // m of the tile's first pixel, image width, first tile-local row of this wave
+    __device__ __forceinline__ int operator()(int lr) const {
+        const int R = lr0 + lr;
+        return base + (R >> TWS) * W + (R & ((1 << TWS) - 1));
+    }
+};
+
+template <int MI, int NI, unsigned EPI, class RM = RowLinear>
 __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[MI][NI], float* ep, int lane,
-                                         int mw, int nw, int ncols, float2* ln_mine = nullptr,
+                                         RM rmap, int nw, int ncols, float2* ln_mine = nullptr,
                                          const float2* ln_partner = nullptr) {
     constexpr bool R1 = (EPI & E_R1) != 0, R2 = (EPI & E_R2) != 0, RB = (EPI & E_RB) != 0;
     constexpr bool O32 = (EPI & E_O32) != 0, O16 = (EPI & E_O16) != 0, LN = (EPI & E_LN) != 0;
@@ -210,7 +232,7 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
         constexpr int CPL = cw * 4, RPP = 64 / CPL;
         const int cl = lane % CPL, rl = lane / CPL;
         const int ncol = nw + jc * 32 + cl * 8;
-        const int m = mw + i * 32 + ps * RPP + rl;
+        const int m = rmap(i * 32 + ps * RPP + rl);
         const bool on = (m < p.M) && (ncol < ncols);
         if constexpr (HAS_X) {
             x0[ps] = z4; x1[ps] = z4;
@@ -254,7 +276,7 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
             constexpr int ps = decltype(ps_)::value;
             const float* src = ep + (ps * RPP + rl) * EPITCH + cl * 8;
             const f32x4 a0 = ld4(src), a1 = ld4(src + 4);
-            const int m = mw + i * 32 + ps * RPP + rl;
+            const int m = rmap(i * 32 + ps * RPP + rl);
             const bool on = col_on && m < p.M;
             float v[8];
 #pragma unroll
@@ -360,7 +382,7 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
                 const int r = i * 32 + ps * RPP + rl;
-                const int m = mw + r;
+                const int m = rmap(r);
                 if (!(col_on && m < p.M)) continue;
                 const float2 a = ln_mine[r], b = ln_partner[r];
                 const float mean = (a.x + b.x) * invn;
@@ -760,9 +782,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
             if constexpr ((EPI & E_LN) != 0) {
                 static_assert(WGN == 2, "the fused LayerNorm pairs the two waves of a row");
                 float2* lnb = reinterpret_cast<float2*>(reinterpret_cast<float*>(smem) + NW * (32 * EPITCH));
-                epi_fast<MI, NI, EPI>(p, acc, ep, lane, mw, nw, p.N, lnb + wave * 64, lnb + (wave ^ 1) * 64);
+                epi_fast<MI, NI, EPI>(p, acc, ep, lane, RowLinear{mw}, nw, p.N, lnb + wave * 64, lnb + (wave ^ 1) * 64);
             } else {
-                epi_fast<MI, NI, (EPI & ~E_VT)>(p, acc, ep, lane, mw, nw, (EPI & E_VT) ? p.n_split : p.N);   // E_GELU rides along
+                epi_fast<MI, NI, (EPI & ~E_VT)>(p, acc, ep, lane, RowLinear{mw}, nw, (EPI & E_VT) ? p.n_split : p.N);   // E_GELU rides along
             }
         }
     }
@@ -785,6 +807,10 @@ static inline void tail_split(int tiles, int& nfull, int& tail_f) {
     else if (WGM >= 2 && r * 2 <= slots) tail_f = 2;
     if (tail_f > 1) nfull = tiles - r;
 }
+
+// gemm_stencil_tile.hip
+int conv3x3_tile_geometry(const PncGemmParams& p, unsigned epi);
+int dispatch_conv3x3_tiles(const PncGemmParams& p, unsigned epi, int geometry, hipStream_t st);
 
 // gemm.hip
 int launch_splitk_reduce(const PncGemmParams& p, int ksplit, hipStream_t st);

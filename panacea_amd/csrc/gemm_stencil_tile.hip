@@ -1,0 +1,299 @@
+// gemm_stencil_tile.hip — 3x3 conv (stride 1, pad 1, Cin % 64 == 0) as implicit GEMM over SPATIAL output tiles that
+// contain their stencil neighbours.
+//
+// The per-tap gather (gemm_conv3x3.hip) DMAs, for every 64-channel slice of the input, nine A tiles — one per tap — that are
+// the same pixels shifted by one: 9 x 32 KB per 256 output pixels, every byte of it through the L2 -> LDS path whose cost
+// adds to the MFMAs' (DESIGN.md §4 "where the time goes").  Here a workgroup owns a TH x TW block of output pixels of one
+// frame (16 x 16, or 8 x 32 where the image height is no multiple of 16), stages the block plus its halo —
+// (TH + 2) x (TW + 2) pixels, 41-43 KB — ONCE per slice, and the nine taps read their A fragments from it at shifted LDS
+// rows.  Per slice and 256 x 320 output tile: 41 + 9 x 40 KB instead of 9 x 32 + 9 x 40 KB — 1.6x fewer DMA bytes, same MFMAs,
+// same LDS fragment reads.  Measured (MI355X, profiles/round2/kbench_r2k_stencil_tiles.log): level-0 convs 790-925 ->
+// 915-1050 TFLOP/s, first-stage decoder convs 800 -> 960-1020.
+// (The temporal k = 3 conv was built on the same scheme — 32 pixels x all 8 frames per tile, 1.4x fewer DMA bytes — and
+// measured no faster: at K = 3 C its time is the two-stream fp32 epilogue's, not the operand path's.  Not kept.)
+//
+// BN = NI x 64 (320 where N is a multiple of 320, else 256), 8 waves as 4 x 2, wave tile 64 x (NI x 32).
+// LDS: two halo buffers (slice c + 1 arrives, one 1-KB piece per wave and iteration, while slice c is consumed) and a ring of
+// three W HALF tiles — 32 of the 64 channels of one (slice, tap) pair, BN rows x 64 B: 2 x 41 + 3 x 20 = 142 KB at BN = 320
+// (whole 64-channel W stages would need 2 x 41.5 + 2 x 40 = 163 KB).  Counted vmcnt waits + one raw s_barrier per half
+// tile, placed in the middle of its MFMA stream (software pipeline below): two half tiles in flight, one landed.
+// The K order (slice, tap, channel) is the per-tap kernel's, so are the products: results are bit-identical to its
+// (precise operands included: the lo plane's pass runs first, the accumulators are scaled by 2^-11, then the hi plane's).
+// The epilogue is gemm_kernel.h's epi_fast with a row map (RowHalo): tile-local row -> pixel of the frame.
+#include "gemm_kernel.h"
+
+namespace pnc_gemm {
+
+template <int TWS, int NI, unsigned EPI>     // TW = 2^TWS columns per spatial tile; BN = NI * 64
+__global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams pin, const int group_m) {
+    const PncGemmParams& p = pin;
+    constexpr int TW = 1 << TWS, TH = 256 / TW;
+    constexpr int IPS = 18;                                 // half-tile iterations per 64-channel slice: 9 taps x 2
+    constexpr int HW2 = TW + 2, HROWS = (TH + 2) * HW2;
+    constexpr int HBLK = (HROWS + 7) / 8;                   // 1-KB DMA pieces (8 halo rows of 128 B)
+    constexpr int HBYTES = HBLK * 1024;
+    constexpr int BN = NI * 64, NW = 8, WGN = 2, MI = 2;
+    constexpr int WHB = BN * 64;                            // bytes of a W half tile: BN rows x 32 channels
+    constexpr int WBLK = WHB / 1024;                        // its 1-KB DMA pieces (16 W rows x 64 B each): 16 / 20
+    constexpr int W_IT = (WBLK + NW - 1) / NW;
+    constexpr int H_IT = (HBLK + NW - 1) / NW;              // halo pieces per wave and slice: 6
+    constexpr int ENI = 2, EPITCH = ENI * 32 + 4;
+    static_assert(HW2 % 2 == 0, "the halo swizzle takes the address parity from the halo column");
+    static_assert(2 * HBYTES + 3 * WHB <= 160 * 1024, "LDS budget");
+    static_assert(2 * HBYTES + 3 * WHB >= NW * 32 * EPITCH * 4, "epilogue staging fits the operand buffers");
+    static_assert(H_IT <= IPS, "one halo piece per wave and half-tile iteration");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    char* const wring = smem + 2 * HBYTES;
+
+    const half_t* __restrict__ A = reinterpret_cast<const half_t*>(p.A);
+    const half_t* __restrict__ A_lo = reinterpret_cast<const half_t*>(p.A_lo);
+    const half_t* __restrict__ Wt = reinterpret_cast<const half_t*>(p.W);
+
+    const int tiles_x = p.Wout >> TWS, per_frame = (p.Hout / TH) * tiles_x;
+    const int tiles_m = (p.M / (p.Hout * p.Wout)) * per_frame, tiles_n = (p.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tn, tm;
+    if (group_m > 0) {
+        const int width = group_m * tiles_n;
+        const int gid = tile / width, first_m = gid * group_m;
+        const int gsz = min(tiles_m - first_m, group_m);
+        const int in = tile - gid * width;
+        tm = first_m + in % gsz; tn = in / gsz;
+    } else {
+        tn = tile % tiles_n; tm = tile / tiles_n;
+    }
+    const int f = tm / per_frame, trem = tm - f * per_frame;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int Y0 = ty * TH, X0 = tx << TWS, n0 = tn * BN;       // halo row hy / column hx = image row Y0 - 1 + hy, column X0 - 1 + hx
+    const int64_t img_base = (int64_t)f * p.Hin * p.Win * p.Cin;
+    const int base_m = (f * p.Hout + Y0) * p.Wout + X0;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // ---- halo DMA: piece b = halo rows 8b .. 8b+7; lane l fills slot (l&7) of row 8b + (l>>3) with the source chunk
+    // slot ^ ((hx>>1)&7), hx = the row's halo COLUMN.  The 16 lanes of a ds_read_b128 group read 16 consecutive pixels of
+    // one or two tile rows = 16 consecutive halo columns (whatever the tap), i.e. all 16 (parity, hx>>1) pairs.
+    auto issue_halo = [&](const half_t* __restrict__ plane, int cc, int buf, int b) {
+        const int hr = b * 8 + (lane >> 3);
+        const int hy = hr / HW2, hx = hr - hy * HW2;
+        const int c8 = (lane & 7) ^ ((hx >> 1) & 7);
+        const int iy = Y0 - 1 + hy, ix = X0 - 1 + hx;
+        const bool ok = (hr < HROWS) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+        glds16(ok ? plane + img_base + ((int64_t)iy * p.Win + ix) * p.Cin + (cc << 6) + c8 * 8 : g_zero_chunk,
+               halo + buf * HBYTES + b * 1024);
+    };
+    // ---- W DMA: half tile k = 32 channels of K tile k/2 = k offset 32 k of the packed [N][(ci/64, tap, ci%64)] weights.
+    // LDS row R (128 B) = W rows 2R, 2R+1; slot = (n&1)*4 + (c ^ ((R>>1)&3)), c = 16-byte chunk of the 64-byte half row.
+    const int nW = WBLK / NW + (wave < (WBLK % NW) ? 1 : 0);      // DMA instructions of this wave per half tile
+    const half_t* wsrc[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        const int R = (wave + NW * i) * 8 + (lane >> 3), slot = lane & 7;
+        const int n = n0 + 2 * R + (slot >> 2);
+        const int c4 = (slot & 3) ^ ((R >> 1) & 3);
+        wsrc[i] = (n < p.N && wave + NW * i < WBLK) ? Wt + (int64_t)n * p.ldw + c4 * 8 : nullptr;
+    }
+    auto issue_w = [&](int k, int stage) {
+        char* sb = wring + stage * WHB + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i)
+            if (wave + NW * i < WBLK) glds16(wsrc[i] ? wsrc[i] + k * 32 : g_zero_chunk, sb + i * (NW * 1024));
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // this lane's fragment rows.  A: tile-local output row R -> halo row / column of tap 0; B: W row -> LDS row, slot
+    const int frow = lane & 31, fk = lane >> 5;
+    int hp0[MI], hx0[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int R = wm * 64 + i * 32 + frow;
+        hx0[i] = R & (TW - 1);
+        hp0[i] = (R >> TWS) * HW2 + hx0[i];
+    }
+    const int b_row = ((wn * (NI * 32) + frow) >> 1) * 128 + ((frow & 1) << 6);
+    const int b_swz = (frow >> 2) & 3;                 // (R>>1)&3: blocks of 32 W rows shift R by 16
+
+    // Fragments of one k-step (16 channels) of half tile (hbuf, tap, half, stage) -> register buffer b.  Explicit
+    // ds_read_b128: the compiler's counter model waits lgkmcnt(0) across the loop's back edge, which would expose the latency of
+    // the reads just issued (A/B on the device: 2-4 % at long K); the waits for these reads are written out in the loop below.
+    half8v af[2][MI], bf[2][NI];
+    auto frags = [&](int hbuf, int tap, int half, int stage, int ks, auto b_) {
+        constexpr int b = decltype(b_)::value;
+        const char* sa = halo + hbuf * HBYTES;
+        const char* sb = wring + stage * WHB + b_row;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int toff = ky * HW2 + kx;
+        const int c4 = ks * 2 + fk;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const unsigned a_addr = (unsigned)(uintptr_t)(sa + (hp0[i] + toff) * 128 +
+                                                          (((half * 4 + c4) ^ (((hx0[i] + kx) >> 1) & 7)) << 4));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[b][i]) : "v"(a_addr));
+        }
+        const unsigned b_addr = (unsigned)(uintptr_t)(sb + ((c4 ^ b_swz) << 4));
+#define PNC_STENCIL_RD_B(J)                                                                                            \
+    if constexpr (NI > J)                                                                                              \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[b][J < NI ? J : 0]) : "v"(b_addr), "n"(J * 16 * 128));
+        PNC_STENCIL_RD_B(0) PNC_STENCIL_RD_B(1) PNC_STENCIL_RD_B(2) PNC_STENCIL_RD_B(3) PNC_STENCIL_RD_B(4)
+#undef PNC_STENCIL_RD_B
+    };
+    auto mfmas = [&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[b][i], bf[b][j], acc[i][j], 0, 0, 0);
+    };
+    const std::integral_constant<int, 0> B0{};
+    const std::integral_constant<int, 1> B1{};
+
+    // counted wait: everything but this wave's most recent W group (nW instructions) has landed
+    auto wait_all_but_last_w = [&]() {
+        if (nW == W_IT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_IT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_IT - 1) : "memory");
+    };
+
+    // Slices in execution order: with a precise operand the lo plane's nslices first, then the hi plane's
+    const int nslices = p.Cin >> 6, nq1 = nslices * IPS;              // half tiles of one pass
+    const int ns_tot = A_lo ? 2 * nslices : nslices, nq = ns_tot * IPS;
+    auto slice_plane = [&](int gs) { return (A_lo && gs < nslices) ? A_lo : A; };
+    auto slice_cc = [&](int gs) { return gs >= nslices ? gs - nslices : gs; };
+
+    // Software pipeline over half tiles q (two k-steps each), the barrier in the MIDDLE of q's MFMA stream:
+    //   reads(q, ks1) | MFMA(q, ks0) | wait: W(q+1) landed, own reads of q done | s_barrier | DMA: halo piece, W(q+3) -> stage of q |
+    //   reads(q+1, ks0) | MFMA(q, ks1)
+    // so every fragment read runs under the other k-step's MFMAs and three half tiles are landed / in flight.
+#pragma unroll
+    for (int i = 0; i < H_IT; ++i)
+        if (wave + NW * i < HBLK) issue_halo(slice_plane(0), 0, 0, wave + NW * i);
+    issue_w(0, 0);
+    issue_w(1, 1);
+    wait_all_but_last_w();
+    __builtin_amdgcn_s_barrier();
+    issue_w(2, 2);
+    frags(0, 0, 0, 0, 0, B0);
+    int st = 0, gs = 0, r = 0, w3 = 3;              // w3 = (q + 3) mod nq1: the W half tile issued in iteration q
+    for (int q = 0; q < nq; ++q) {
+        frags(gs & 1, r >> 1, r & 1, st, 1, B1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI + NI) : "memory");   // buffer 0 (the older reads) is in
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(B0);
+        __builtin_amdgcn_sched_barrier(0);
+        // next half tile's coordinates
+        int r1 = r + 1, gs1 = gs;
+        if (r1 == IPS) { r1 = 0; ++gs1; }
+        const int st1 = (st == 2) ? 0 : st + 1;
+        if (q + 2 < nq) wait_all_but_last_w();                 // in flight: W(q+1), [halo piece, W(q+2)]
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave has read everything it needs of stage st
+        __builtin_amdgcn_s_barrier();
+        // halo buffer (gs+1)&1 was last read in slice gs-1; stage st by half tile q (all waves are past their reads of it)
+        if (r < H_IT && gs + 1 < ns_tot && wave + NW * r < HBLK)
+            issue_halo(slice_plane(gs + 1), slice_cc(gs + 1), (gs + 1) & 1, wave + NW * r);
+        if (q + 3 < nq) issue_w(w3, st);
+        w3 = (w3 + 1 == nq1) ? 0 : w3 + 1;
+        if (q + 1 < nq) frags(gs1 & 1, r1 >> 1, r1 & 1, st1, 0, B0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(B1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (A_lo && q + 1 == nq1) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] *= LO_INV;
+        }
+        st = st1; r = r1; gs = gs1;
+    }
+    __syncthreads();                            // every wave is done with the operand buffers
+
+    // ------------------------------ epilogue ------------------------------
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EPITCH);
+    epi_fast<MI, NI, EPI>(p, acc, ep, lane, RowHalo<TWS>{base_m, p.Wout, wm * 64}, n0 + wn * (NI * 32), p.N);
+}
+
+template <int TWS, int NI>
+constexpr int stencil_lds_bytes() {
+    constexpr int TW = 1 << TWS, TH = 256 / TW, HROWS = (TH + 2) * (TW + 2);
+    return 2 * ((HROWS + 7) / 8) * 1024 + 3 * NI * 64 * 64;
+}
+
+template <int TWS, int NI, unsigned EPI>
+static int launch_stencil(const PncGemmParams& p, hipStream_t st) {
+    constexpr int TW = 1 << TWS, TH = 256 / TW, BN = NI * 64;
+    constexpr int lds = stencil_lds_bytes<TWS, NI>();
+    static std::atomic<unsigned char> attr_done[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto kern = stencil_tile_kernel<TWS, NI, EPI>;
+    if (!attr_done[dev & 63].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done[dev & 63].store(1, std::memory_order_release);
+    }
+    const int tiles_m = (p.M / (p.Hout * p.Wout)) * (p.Hout / TH) * (p.Wout >> TWS), tiles_n = (p.N + BN - 1) / BN;
+    const int gopt = pnc_get_option(PNC_OPT_GEMM_GROUP_M);
+    int group_m = gopt > 0 ? gopt : (tiles_n > 8 ? 4 : 0);
+    if (group_m > tiles_m) group_m = tiles_m;
+    if (group_m == 1 || tiles_n < 2) group_m = 0;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, p, group_m);
+    return pnc_launch_status();
+}
+
+template <int TWS, int NI>
+static int dispatch_epi(const PncGemmParams& p, unsigned epi, hipStream_t st) {
+    switch (epi) {
+        case E_O16: return launch_stencil<TWS, NI, E_O16>(p, st);
+        case E_O32: return launch_stencil<TWS, NI, E_O32>(p, st);
+        case E_O32 | E_O16: return launch_stencil<TWS, NI, E_O32 | E_O16>(p, st);
+        case E_R1 | E_O32: return launch_stencil<TWS, NI, E_R1 | E_O32>(p, st);
+        case E_R1 | E_O32 | E_O16: return launch_stencil<TWS, NI, E_R1 | E_O32 | E_O16>(p, st);
+        default: return PNC_EINVAL;
+    }
+}
+
+// Geometry code the tile kernel would use for this problem — (TWS << 4) | NI — or 0 when the per-tap gather serves it: stride 2 /
+// nearest-x2 gathers, narrow or ragged channel counts, images that do not tile, ragged epilogues, and (unless
+// PNC_OPT_STENCIL_TILES = 2: tests) grids that do not fill the chip — fewer than 160 tiles, or a last round of at most 128:
+// the per-tap kernels have split K and the tail split for those (measured: level 1, 384 tiles, is a wash; level 2, 192, +8 %).
+int conv3x3_tile_geometry(const PncGemmParams& p, unsigned epi) {
+    const int opt = pnc_get_option(PNC_OPT_STENCIL_TILES);       // 0 off, 1 auto, 2 wherever the shape allows
+    if (!opt) return 0;
+    if (p.stride != 1 || p.upsample || p.conv_pad_br || (p.Cin & 63) || p.Hin != p.Hout || p.Win != p.Wout) return 0;
+    if (p.K != 9 * p.Cin || p.M % (p.Hout * p.Wout)) return 0;
+    if (epi != E_O16 && epi != E_O32 && epi != (E_O32 | E_O16) && epi != (E_R1 | E_O32) && epi != (E_R1 | E_O32 | E_O16)) return 0;
+    int tws = 0;
+    if ((p.Hout % 16) == 0 && (p.Wout % 16) == 0) tws = 4;
+    else if ((p.Hout % 8) == 0 && (p.Wout % 32) == 0) tws = 5;
+    if (!tws) return 0;
+    const int ni = (p.N % 320 == 0) ? 5 : 4;
+    if (opt == 1) {
+        const long tiles = (long)(p.M / 256) * ((p.N + ni * 64 - 1) / (ni * 64));
+        const long rem = tiles % 256;
+        if (tiles < 160 || (tiles > 256 && rem && rem <= 128) || p.N < 256) return 0;
+    }
+    return (tws << 4) | ni;
+}
+
+int dispatch_conv3x3_tiles(const PncGemmParams& p, unsigned epi, int geometry, hipStream_t st) {
+    switch (geometry) {
+        case (4 << 4) | 5: return dispatch_epi<4, 5>(p, epi, st);
+        case (4 << 4) | 4: return dispatch_epi<4, 4>(p, epi, st);
+        case (5 << 4) | 5: return dispatch_epi<5, 5>(p, epi, st);
+        case (5 << 4) | 4: return dispatch_epi<5, 4>(p, epi, st);
+        default: return PNC_EINVAL;
+    }
+}
+
+}  // namespace pnc_gemm

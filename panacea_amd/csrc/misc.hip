@@ -202,7 +202,7 @@ extern "C" int pnc_cfg_euler_step(const float* eps_tok, int ld, int T, int Npix,
 
 extern "C" const char* pnc_version(void) { return "panacea_hip 0.2.0 gfx950"; }
 
-static std::atomic<int> g_options[PNC_OPT_COUNT] = {{1}, {0}, {0}, {1}, {1}, {0}};
+static std::atomic<int> g_options[PNC_OPT_COUNT] = {{1}, {0}, {0}, {1}, {1}, {0}, {1}};
 
 int pnc_get_option(int option) { return g_options[option].load(std::memory_order_relaxed); }
 

@@ -264,8 +264,13 @@ def pk_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
 
 
 def pk_conv1d(w: torch.Tensor) -> torch.Tensor:
-    """[Cout, Cin, 3] -> [Cout, 3*Cin] with K ordered (dt, ci)."""
-    return pk_f16(w.detach().permute(0, 2, 1).reshape(w.shape[0], -1))
+    """[Cout, Cin, 3] -> [Cout, 3*Cin] with K ordered (dt, ci); (ci/64, dt, ci%64) when Cin % 64 == 0 (include/panacea_hip.h:
+    the three taps of a 64-channel slice become adjacent K tiles)."""
+    co, ci = w.shape[0], w.shape[1]
+    p = w.detach().permute(0, 2, 1)
+    if ci % 64 == 0:
+        p = p.reshape(co, 3, ci // 64, 64).permute(0, 2, 1, 3)
+    return pk_f16(p.reshape(co, -1))
 
 
 def pk_geglu(w: torch.Tensor, b: torch.Tensor):

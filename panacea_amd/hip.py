@@ -144,12 +144,12 @@ def load():
     return lib
 
 
-OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA, OPT_GEMM_FUSE_LN, OPT_GEMM_GROUP_M = 0, 1, 2, 3, 4, 5
+OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA, OPT_GEMM_FUSE_LN, OPT_GEMM_GROUP_M, OPT_STENCIL_TILES = 0, 1, 2, 3, 4, 5, 6
 
 
 def set_option(option: int, value: int) -> int:
     """pnc_set_option: process-global tuning / test switch of the library; returns the previous value."""
-    if not 0 <= option <= OPT_GEMM_GROUP_M:
+    if not 0 <= option <= OPT_STENCIL_TILES:
         raise PncError(f"unknown library option {option}")
     return load().pnc_set_option(option, value)
 

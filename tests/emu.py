@@ -85,7 +85,10 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
         Cc, T, Npix = tconv["C"], tconv["T"], tconv["Npix"]
         B = M // (T * Npix)
         x = a16.reshape(-1)[: M * Cc].view(B, T, Npix, Cc).permute(0, 2, 3, 1).reshape(B * Npix, Cc, T).float()
-        w = Wm.view(N, 3, Cc).permute(0, 2, 1)
+        if Cc % 64 == 0:      # K order (ci/64, dt, ci%64)
+            w = Wm.view(N, Cc // 64, 3, 64).permute(0, 1, 3, 2).reshape(N, Cc, 3)
+        else:                 # K order (dt, ci)
+            w = Wm.view(N, 3, Cc).permute(0, 2, 1)
         y = TF.conv1d(x, w, padding=1)                       # [B*Npix, N, T]
         acc = y.view(B, Npix, N, T).permute(0, 3, 1, 2).reshape(M, N)
     v = acc

@@ -457,6 +457,62 @@ def test_gemm_grouped_tile_order_is_bit_identical(M, N, K, geglu):
         assert torch.equal(run(g), ref), g
 
 
+def _with_stencil_tiles(opt, fn):
+    prev = hip.set_option(hip.OPT_STENCIL_TILES, opt)
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        hip.set_option(hip.OPT_STENCIL_TILES, prev)
+
+
+@pytest.mark.parametrize("F,H,W,Cin,N,epi", [
+    (2, 16, 32, 64, 320, "o32"),        # 16x16 tiles, BN = 320, one slice
+    (1, 32, 48, 192, 640, "o32"),       # three slices (both halo buffers recycled), two column tiles
+    (3, 8, 64, 128, 256, "o32+o16"),    # 8x32 tiles, BN = 256
+    (1, 16, 16, 320, 384, "r1"),        # one tile per frame: every halo edge is padding; N = 384 = 256 + half a tile
+    (2, 48, 16, 128, 960, "r1+o16"),    # tall image, three 320-column tiles
+    (1, 8, 32, 64, 64, "silu16"),       # a narrow conv (forced geometry only)
+    (2, 16, 16, 128, 320, "o32+lo"),    # precise operand: the lo plane's pass, the 2^-11 scale, the hi plane's pass
+])
+def test_gemm_conv3x3_stencil_tiles_are_bit_identical(F, H, W, Cin, N, epi):
+    """PNC_OPT_STENCIL_TILES: the spatial-tile kernel (one halo of the input per 64-channel slice, nine taps read from it)
+    computes the same products in the same K order as the per-tap gather: bit-identical for every fast epilogue and
+    with a precise operand; and the per-tap gather agrees with the emulation."""
+    M, K = F * H * W, 9 * Cin
+    x32 = rnd(F, H, W, Cin, seed=11)
+    x, lo = _split(x32) if "lo" in epi else (x32.half(), None)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=12)
+    bias = rnd(N, seed=13)
+    res = rnd(M, N, seed=14)
+    conv = dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0)
+
+    def outs():
+        return dict(o32=res.clone() if "r1" in epi else torch.zeros(M, N, device=DEV),
+                    o16=torch.zeros(M, N, device=DEV, dtype=torch.float16))
+
+    def kw(o):
+        k = dict(a16=x, w16=w, M=M, N=N, K=K, a_mode=hip.A_CONV3X3, conv=conv, bias=bias, a16_lo=lo)
+        if epi == "silu16":
+            k.update(act=hip.ACT_SILU, out16=o["o16"], ldc16=N)
+        else:
+            k.update(out32=o["o32"], ldc32=N)
+            if "o16" in epi:
+                k.update(out16=o["o16"], ldc16=N)
+            if "r1" in epi:
+                k.update(res1=o["o32"], ldr1=N)
+        return k
+    plain, tiles, e = outs(), outs(), outs()
+    _with_stencil_tiles(0, lambda: hip.gemm(**kw(plain)))
+    emu.gemm(**kw(e))
+    tol = (2e-5, 1e-5) if lo is not None else (2e-3, 2e-3)
+    check("per-tap gather vs emu (fp32)", plain["o32"], e["o32"], *tol)
+    check("per-tap gather vs emu (fp16)", plain["o16"], e["o16"], 4e-3)
+    _with_stencil_tiles(2, lambda: hip.gemm(**kw(tiles)))
+    assert torch.equal(tiles["o32"], plain["o32"]), (tiles["o32"] - plain["o32"]).abs().max().item()
+    assert torch.equal(tiles["o16"], plain["o16"])
+
+
 # ---------------------------------------------------------------------------------------- split K
 def _splits(**kw):
     """K slices the library would run for this problem (0 workspace -> 1 slice)."""

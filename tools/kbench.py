@@ -234,11 +234,55 @@ def bench_group_m(flt):
             del a, w
 
 
+def bench_halo(flt):
+    """stencil-tile A/B (PNC_OPT_STENCIL_TILES): 0 = one gathered A tile per tap, 2 = tiles incl. halo, on the UNet / ControlNet
+    conv3x3 shapes and the first-stage decoder's; the conv1d-T shapes (precise operand, as shipped) ride along as a reference"""
+    shapes = []
+    for li, (C, H, W) in enumerate(LEVELS):
+        shapes.append((f"L{li} conv3x3 {C}->{C}", "c2", F, H, W, C, C))
+        if li < 3:
+            shapes.append((f"L{li} conv3x3 {2 * C}->{C}", "c2", F, H, W, 2 * C, C))
+        shapes.append((f"L{li} conv1d {C} precise", "c1", F, H, W, C, C))
+    shapes += [("vae 512->512 1/4", "c2", 2, 64, 768, 512, 512), ("vae 256->256 1/2", "c2", 2, 128, 1536, 256, 256),
+               ("vae 128->128 1/1", "c2", 1, 256, 3072, 128, 128)]
+    for name, kind, Fr, H, W, Cin, N in shapes:
+        M, K = Fr * H * W, (9 if kind == "c2" else 3) * Cin
+        tag = f"halo {name} M={M} N={N} K={K}"
+        if flt and flt not in tag:
+            continue
+        a, w = h16(Fr, H, W, Cin), h16(N, K)
+        alo = h16(Fr, H, W, Cin) if kind == "c1" else None
+        bias = torch.zeros(N, device=DEV)
+        o32 = torch.zeros(M, N, device=DEV)
+        emb = torch.zeros(Fr, N, device=DEV)
+
+        def fn():
+            if kind == "c2":
+                hip.gemm(a, w, M=M, N=N, K=K, a_mode=hip.A_CONV3X3, bias=bias, out32=o32, ldc32=N,
+                         conv=dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0))
+            else:
+                hip.gemm(a, w, M=M, N=N, K=K, a_mode=hip.A_CONV1D_T, tconv=dict(C=Cin, T=8, Npix=H * W), bias=bias, a16_lo=alo,
+                         rowbias=emb, rb_rows=H * W, rb_mod=Fr, res1=o32, ldr1=N, out32=o32, ldc32=N)
+        res = []
+        for opt in (0, 2, 0, 2):
+            prev = hip.set_option(hip.OPT_STENCIL_TILES, opt)
+            try:
+                res.append((opt, timeit(fn, iters=10, warm=2)))
+            finally:
+                hip.set_option(hip.OPT_STENCIL_TILES, prev)
+        fl = 2.0 * M * N * K
+        print(f"{tag:52s} " + "  ".join(f"opt={o} {tt * 1e6:7.1f}us {fl / tt / 1e12:6.1f}TF" for o, tt in res), flush=True)
+        del a, w, o32
+
+
 if __name__ == "__main__":
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     print(torch.cuda.get_device_name(0))
     if flt.startswith("group_m"):
         bench_group_m(sys.argv[2] if len(sys.argv) > 2 else "")
+        sys.exit(0)
+    if flt.startswith("halo"):
+        bench_halo(sys.argv[2] if len(sys.argv) > 2 else "")
         sys.exit(0)
     if flt.startswith("tiles"):
         bench_tiles(sys.argv[2] if len(sys.argv) > 2 else "")

@@ -25,7 +25,7 @@
 namespace pnc_gemm {
 
 template <int TWS, int NI, unsigned EPI>     // TW = 2^TWS columns per spatial tile; BN = NI * 64
-__global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams pin, const int group_m) {
+__global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams pin, const int group_m, const int nfull, const int tail_f) {
     const PncGemmParams& p = pin;
     constexpr int TW = 1 << TWS, TH = 256 / TW;
     constexpr int IPS = 18;                                 // half-tile iterations per 64-channel slice: 9 taps x 2
@@ -52,7 +52,17 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
 
     const int tiles_x = p.Wout >> TWS, per_frame = (p.Hout / TH) * tiles_x;
     const int tiles_m = (p.M / (p.Hout * p.Wout)) * per_frame, tiles_n = (p.N + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    // Tail split (as in gemm_kernel.h): the tiles of a sparse last round are each run by tail_f workgroups that own 256 / tail_f of
+    // the tile's pixels (whole tile rows); the waves of the other rows skip their reads, MFMAs and epilogue, only the halo rows
+    // the part needs are staged, all waves still stage W.  Rows of a GEMM are independent: bit-identical to the unsplit launch.
+    int tile, part = 0;
+    if ((int)blockIdx.x < nfull) {
+        tile = xcd_remap(blockIdx.x, nfull);
+    } else {
+        const int j = (int)blockIdx.x - nfull;
+        tile = nfull + j / tail_f; part = j - (j / tail_f) * tail_f;
+    }
+    const bool split = (int)blockIdx.x >= nfull && tail_f > 1;
     int tn, tm;
     if (group_m > 0) {
         const int width = group_m * tiles_n;
@@ -72,6 +82,10 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
+    const int rows_lo = split ? part * (256 / tail_f) : 0, rows_hi = split ? rows_lo + 256 / tail_f : 256;
+    const bool wave_on = (wm * 64 >= rows_lo) && (wm * 64 < rows_hi);
+    // halo pieces (8 halo rows each) that hold tile rows rows_lo / TW - 1 .. rows_hi / TW: the others are never read
+    const int pc_lo = ((rows_lo >> TWS) * HW2) >> 3, pc_hi = (((rows_hi >> TWS) + 2) * HW2 + 7) >> 3;
 
     // ---- halo DMA: piece b = halo rows 8b .. 8b+7; lane l fills slot (l&7) of row 8b + (l>>3) with the source chunk
     // slot ^ ((hx>>1)&7), hx = the row's halo COLUMN.  The 16 lanes of a ds_read_b128 group read 16 consecutive pixels of
@@ -176,19 +190,21 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
     // so every fragment read runs under the other k-step's MFMAs and three half tiles are landed / in flight.
 #pragma unroll
     for (int i = 0; i < H_IT; ++i)
-        if (wave + NW * i < HBLK) issue_halo(slice_plane(0), 0, 0, wave + NW * i);
+        if (wave + NW * i >= pc_lo && wave + NW * i < pc_hi && wave + NW * i < HBLK) issue_halo(slice_plane(0), 0, 0, wave + NW * i);
     issue_w(0, 0);
     issue_w(1, 1);
     wait_all_but_last_w();
     __builtin_amdgcn_s_barrier();
     issue_w(2, 2);
-    frags(0, 0, 0, 0, 0, B0);
+    if (wave_on) frags(0, 0, 0, 0, 0, B0);
     int st = 0, gs = 0, r = 0, w3 = 3;              // w3 = (q + 3) mod nq1: the W half tile issued in iteration q
     for (int q = 0; q < nq; ++q) {
-        frags(gs & 1, r >> 1, r & 1, st, 1, B1);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI + NI) : "memory");   // buffer 0 (the older reads) is in
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(B0);
+        if (wave_on) {
+            frags(gs & 1, r >> 1, r & 1, st, 1, B1);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI + NI) : "memory");   // buffer 0 (the older reads) is in
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(B0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // next half tile's coordinates
         int r1 = r + 1, gs1 = gs;
@@ -199,13 +215,15 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave has read everything it needs of stage st
         __builtin_amdgcn_s_barrier();
         // halo buffer (gs+1)&1 was last read in slice gs-1; stage st by half tile q (all waves are past their reads of it)
-        if (r < H_IT && gs + 1 < ns_tot && wave + NW * r < HBLK)
+        if (r < H_IT && gs + 1 < ns_tot && wave + NW * r >= pc_lo && wave + NW * r < pc_hi && wave + NW * r < HBLK)
             issue_halo(slice_plane(gs + 1), slice_cc(gs + 1), (gs + 1) & 1, wave + NW * r);
         if (q + 3 < nq) issue_w(w3, st);
         w3 = (w3 + 1 == nq1) ? 0 : w3 + 1;
-        if (q + 1 < nq) frags(gs1 & 1, r1 >> 1, r1 & 1, st1, 0, B0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(B1);
+        if (wave_on) {
+            if (q + 1 < nq) frags(gs1 & 1, r1 >> 1, r1 & 1, st1, 0, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(B1);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (A_lo && q + 1 == nq1) {
 #pragma unroll
@@ -218,6 +236,7 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
         st = st1; r = r1; gs = gs1;
     }
     __syncthreads();                            // every wave is done with the operand buffers
+    if (!wave_on) return;                       // rows of another workgroup (tail split)
 
     // ------------------------------ epilogue ------------------------------
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EPITCH);
@@ -247,7 +266,9 @@ static int launch_stencil(const PncGemmParams& p, hipStream_t st) {
     int group_m = gopt > 0 ? gopt : (tiles_n > 8 ? 4 : 0);
     if (group_m > tiles_m) group_m = tiles_m;
     if (group_m == 1 || tiles_n < 2) group_m = 0;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, p, group_m);
+    int nfull = tiles_m * tiles_n, tail_f = 1;
+    tail_split<256, 4, lds>(tiles_m * tiles_n, nfull, tail_f);            // one workgroup per CU: 256 slots per round
+    hipLaunchKernelGGL(kern, dim3(nfull + (tiles_m * tiles_n - nfull) * tail_f), dim3(512), lds, st, p, group_m, nfull, tail_f);
     return pnc_launch_status();
 }
 
@@ -265,8 +286,8 @@ static int dispatch_epi(const PncGemmParams& p, unsigned epi, hipStream_t st) {
 
 // Geometry code the tile kernel would use for this problem — (TWS << 4) | NI — or 0 when the per-tap gather serves it: stride 2 /
 // nearest-x2 gathers, narrow or ragged channel counts, images that do not tile, ragged epilogues, and (unless
-// PNC_OPT_STENCIL_TILES = 2: tests) grids that do not fill the chip — fewer than 160 tiles, or a last round of at most 128:
-// the per-tap kernels have split K and the tail split for those (measured: level 1, 384 tiles, is a wash; level 2, 192, +8 %).
+// PNC_OPT_STENCIL_TILES = 2: tests) grids of fewer than 160 tiles: the per-tap kernels have split K for those (level 2, 192 tiles:
+// +8 % on the tile kernel; a sparse last round — level 1: 384 tiles = 1.5 rounds — is tail-split here as there).
 int conv3x3_tile_geometry(const PncGemmParams& p, unsigned epi) {
     const int opt = pnc_get_option(PNC_OPT_STENCIL_TILES);       // 0 off, 1 auto, 2 wherever the shape allows
     if (!opt) return 0;
@@ -280,8 +301,7 @@ int conv3x3_tile_geometry(const PncGemmParams& p, unsigned epi) {
     const int ni = (p.N % 320 == 0) ? 5 : 4;
     if (opt == 1) {
         const long tiles = (long)(p.M / 256) * ((p.N + ni * 64 - 1) / (ni * 64));
-        const long rem = tiles % 256;
-        if (tiles < 160 || (tiles > 256 && rem && rem <= 128) || p.N < 256) return 0;
+        if (tiles < 160 || p.N < 256) return 0;
     }
     return (tws << 4) | ni;
 }

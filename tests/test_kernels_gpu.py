@@ -474,6 +474,8 @@ def _with_stencil_tiles(opt, fn):
     (2, 48, 16, 128, 960, "r1+o16"),    # tall image, three 320-column tiles
     (1, 8, 32, 64, 64, "silu16"),       # a narrow conv (forced geometry only)
     (2, 16, 16, 128, 320, "o32+lo"),    # precise operand: the lo plane's pass, the 2^-11 scale, the hi plane's pass
+    (12, 64, 96, 64, 320, "r1"),        # 288 tiles: a full round + 32 tiles x 4 quarter workgroups
+    (5, 32, 64, 64, 640, "o32"),        # 40 x 2 = 80 tiles: every tile as 2 half-tile workgroups
 ])
 def test_gemm_conv3x3_stencil_tiles_are_bit_identical(F, H, W, Cin, N, epi):
     """PNC_OPT_STENCIL_TILES: the spatial-tile kernel (one halo of the input per 64-channel slice, nine taps read from it)
@@ -508,9 +510,16 @@ def test_gemm_conv3x3_stencil_tiles_are_bit_identical(F, H, W, Cin, N, epi):
     tol = (2e-5, 1e-5) if lo is not None else (2e-3, 2e-3)
     check("per-tap gather vs emu (fp32)", plain["o32"], e["o32"], *tol)
     check("per-tap gather vs emu (fp16)", plain["o16"], e["o16"], 4e-3)
-    _with_stencil_tiles(2, lambda: hip.gemm(**kw(tiles)))
-    assert torch.equal(tiles["o32"], plain["o32"]), (tiles["o32"] - plain["o32"]).abs().max().item()
-    assert torch.equal(tiles["o16"], plain["o16"])
+    # small grids are one sparse round: with the tail split every tile runs as 4 quarter-tile workgroups, without as one
+    for tail in (1, 0):
+        tiles = outs()
+        prev = hip.set_option(hip.OPT_GEMM_TAIL_SPLIT, tail)
+        try:
+            _with_stencil_tiles(2, lambda: hip.gemm(**kw(tiles)))
+        finally:
+            hip.set_option(hip.OPT_GEMM_TAIL_SPLIT, prev)
+        assert torch.equal(tiles["o32"], plain["o32"]), (tail, (tiles["o32"] - plain["o32"]).abs().max().item())
+        assert torch.equal(tiles["o16"], plain["o16"]), tail
 
 
 # ---------------------------------------------------------------------------------------- split K

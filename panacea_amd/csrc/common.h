@@ -35,6 +35,19 @@ __device__ __forceinline__ void glds16(const half_t* src, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same DMA through a buffer resource: address = rsrc base (SGPRs) + per-lane 32-bit byte offset + scalar byte offset.  The
+// per-lane offset of a tile row does not change along K (only the scalar offset does), and offsets at or beyond num_records
+// read as zero — padding / tails need no zero-block pointer.
+using buffer_rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void glds16_buf(buffer_rsrc_t rsrc, unsigned lane_byte_off, unsigned scalar_byte_off, char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)lane_byte_off,
+                                             (int)scalar_byte_off, 0, 0);
+}
+constexpr unsigned PNC_BUF_OOB = 0x80000000u;      // a lane offset no tensor of the path reaches
+
 // Precise ("split") fp16 operands (include/panacea_hip.h, PncGemmParams.A_lo): v ~ hi + lo * 2^-11 with
 // hi = fp16(v), lo = fp16((v - hi) * 2^11).
 constexpr float PNC_LO_SCALE = 2048.0f;

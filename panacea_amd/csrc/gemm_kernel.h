@@ -57,32 +57,41 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct RowState {               // per staged A row, fixed over the K loop
-    int64_t base;               // element offset of the row origin
+    int rel;                    // element offset of the row origin from the tile's WINDOW origin (a_window_origin)
     int y, x;                   // conv3x3: output pixel; conv1d: t in .y
     bool valid;
 };
 
+// The operands reach LDS through buffer resources (common.h: glds16_buf): base = a per-tile window origin in SGPRs, per-lane
+// 32-bit byte offsets.  The window keeps every offset of a tile far below 2^31 whatever the tensor size: plain rows start at
+// the tile's first row, conv3x3 at the frame of the tile's first pixel, the temporal conv one frame before the tile's first row.
 template <int AMODE>
-__device__ __forceinline__ RowState make_row(const PncGemmParams& p, int m) {
+__device__ __forceinline__ int64_t a_window_origin(const PncGemmParams& p, int m0) {
+    if (AMODE == PNC_A_PLAIN) return (int64_t)m0 * p.lda;
+    if (AMODE == PNC_A_CONV3X3) return (int64_t)(m0 / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin;
+    return (int64_t)max(0, m0 - p.Npix) * p.Cin;
+}
+
+template <int AMODE>
+__device__ __forceinline__ RowState make_row(const PncGemmParams& p, int m, int m0) {
     RowState s;
     s.valid = m < p.M;
-    const int mm = s.valid ? m : 0;
+    const int mm = s.valid ? m : m0;
     if (AMODE == PNC_A_PLAIN) {
-        s.base = (int64_t)mm * p.lda; s.y = 0; s.x = 0;
+        s.rel = (mm - m0) * p.lda; s.y = 0; s.x = 0;
     } else if (AMODE == PNC_A_CONV3X3) {
         const int hw = p.Hout * p.Wout;
         const int f = mm / hw, pix = mm - f * hw;
         s.y = pix / p.Wout; s.x = pix - s.y * p.Wout;
-        s.base = (int64_t)f * p.Hin * p.Win * p.Cin;
+        s.rel = (f - m0 / hw) * p.Hin * p.Win * p.Cin;
     } else {
         const int f = mm / p.Npix;
         s.y = f % p.T; s.x = 0;
-        s.base = (int64_t)mm * p.Cin;
+        s.rel = (mm - max(0, m0 - p.Npix)) * p.Cin;
     }
     return s;
 }
 
-static __device__ __attribute__((aligned(16))) half_t g_zero_chunk[8];   // zero-initialised: source of padded chunks
 
 // GEGLU gate: Phi(g) = (1 + erf(g / sqrt 2)) / 2 tabulated on [-8, 8) in steps of 1/128 as {Phi(x_i), Phi(x_{i+1}) - Phi(x_i)}
 // (16 KB, copied into LDS by the GEGLU GEMMs).  Linear interpolation error <= h^2/8 max|Phi''| = 1.8e-6 — 250x below
@@ -100,13 +109,12 @@ __device__ __forceinline__ float gelu_tab_f(float g, const float* tab) {
     return g * fmaf(f, e.y, e.x);
 }
 
-// global source of the 16-byte chunk (row state s, k index kc) of plane A, or the zero block
+// byte offset (from the window origin) of the 16-byte chunk (row state s, k index kc) of an A plane, or PNC_BUF_OOB (reads as zero)
 template <int AMODE>
-__device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, const half_t* __restrict__ A,
-                                                     const RowState& s, int kc) {
-    if (!s.valid || kc >= p.K) return g_zero_chunk;
+__device__ __forceinline__ unsigned a_chunk_off(const PncGemmParams& p, const RowState& s, int kc) {
+    if (!s.valid || kc >= p.K) return PNC_BUF_OOB;
     if (AMODE == PNC_A_PLAIN) {
-        return A + s.base + kc;
+        return (unsigned)(s.rel + kc) * 2u;
     } else if (AMODE == PNC_A_CONV3X3) {
         // K order: (ky,kx,ci) for narrow inputs; (ci/64, ky, kx, ci%64) when Cin % 64 == 0, so that the nine tap
         // reads of one 64-channel slice of a pixel neighbourhood are consecutive K tiles and hit L1/L2
@@ -128,7 +136,7 @@ __device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, con
             iy = s.y * p.stride + ky - pad; ix = s.x * p.stride + kx - pad;
             ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
         }
-        return ok ? A + s.base + ((int64_t)iy * p.Win + ix) * p.Cin + ci : g_zero_chunk;
+        return ok ? (unsigned)(s.rel + (iy * p.Win + ix) * p.Cin + ci) * 2u : PNC_BUF_OOB;
     } else {
         // K order: (dt, ci); (ci/64, dt, ci%64) when Cin % 64 == 0 (the three taps of a slice are consecutive K tiles)
         int tap, ci;
@@ -139,7 +147,7 @@ __device__ __forceinline__ const half_t* a_chunk_ptr(const PncGemmParams& p, con
             tap = kc / p.Cin; ci = kc - tap * p.Cin;
         }
         const int tt = s.y + tap - 1;
-        return (tt < 0 || tt >= p.T) ? g_zero_chunk : A + s.base + (int64_t)(tap - 1) * p.Npix * p.Cin + ci;
+        return (tt < 0 || tt >= p.T) ? PNC_BUF_OOB : (unsigned)(s.rel + (tap - 1) * p.Npix * p.Cin + ci) * 2u;
     }
 }
 
@@ -617,27 +625,40 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int r = i * RPI + srow;
-        rows[i] = make_row<AMODE>(p, m0 + r);
+        rows[i] = make_row<AMODE>(p, m0 + r, m0);
         rows[i].valid = rows[i].valid && (r >= rows_lo) && (r < rows_hi);
     }
-    const half_t* wrow[B_IT];
+    // buffer resources: the A plane(s) from the tile's window origin, W from the tile's first row.  A row's offset is fixed over
+    // the K loop for plain A and for W (the K tile enters as the scalar offset); the gathers recompute theirs per K tile.
+    const int64_t a_origin = a_window_origin<AMODE>(p, m0);
+    const buffer_rsrc_t rs_a = make_rsrc(A + a_origin, 0x7FFFFF00u);
+    const buffer_rsrc_t rs_alo = make_rsrc((A_lo ? A_lo : A) + a_origin, 0x7FFFFF00u);
+    const buffer_rsrc_t rs_w = make_rsrc(Wt + (int64_t)n0 * p.ldw, 0x7FFFFF00u);
+    unsigned woff[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + i * RPI + srow;
-        wrow[i] = (n < p.N) ? Wt + (int64_t)n * p.ldw : nullptr;
+        const int nl = i * RPI + srow;
+        woff[i] = (n0 + nl < p.N) ? (unsigned)(nl * p.ldw + schunk * 8) * 2u : PNC_BUF_OOB;
     }
     auto issue_tile = [&](int kt_local, int stage) {
         const bool lo = kt_local < nt_lo;
         const int kt = kt_begin + (lo ? kt_local : kt_local - nt_lo);
-        const half_t* Ap = lo ? A_lo : A;
+        const buffer_rsrc_t rs = lo ? rs_alo : rs_a;
         const int kc = kt * BK + schunk * 8;
+        const bool k_on = kc < p.K;                      // K tail of the last tile (K % 64 != 0)
         char* sa = smem + stage * STAGE + wave * 1024;
         char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) glds16(a_chunk_ptr<AMODE>(p, Ap, rows[i], kc), sa + i * (RPI * 128));
+        for (int i = 0; i < A_IT; ++i) {
+            if constexpr (AMODE == PNC_A_PLAIN)
+                glds16_buf(rs, (rows[i].valid && k_on) ? (unsigned)(rows[i].rel + schunk * 8) * 2u : PNC_BUF_OOB, (unsigned)kt * (BK * 2),
+                           sa + i * (RPI * 128));
+            else
+                glds16_buf(rs, a_chunk_off<AMODE>(p, rows[i], kc), 0u, sa + i * (RPI * 128));
+        }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            glds16((wrow[i] && kc < p.K) ? wrow[i] + kc : g_zero_chunk, sb + i * (RPI * 128));
+            glds16_buf(rs_w, k_on ? woff[i] : PNC_BUF_OOB, (unsigned)kt * (BK * 2), sb + i * (RPI * 128));
     };
 
     // GEGLU: the Phi table rides into LDS (behind the operand ring) with the first K tile

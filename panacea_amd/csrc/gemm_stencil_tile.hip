@@ -87,34 +87,42 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
     // halo pieces (8 halo rows each) that hold tile rows rows_lo / TW - 1 .. rows_hi / TW: the others are never read
     const int pc_lo = ((rows_lo >> TWS) * HW2) >> 3, pc_hi = (((rows_hi >> TWS) + 2) * HW2 + 7) >> 3;
 
+    // Operands reach LDS through buffer resources (common.h: glds16_buf; 4-7 % over per-lane 64-bit pointers on every conv shape):
+    // base = this tile's frame of each activation plane / the tile's first weight row, per-lane 32-bit byte offsets that do not
+    // change along K (the slice / half tile enters as the scalar offset); PNC_BUF_OOB offsets read as zero (padding, N tail).
+    const unsigned frame_bytes = (unsigned)(p.Hin * p.Win * p.Cin) * 2u;
+    const buffer_rsrc_t rs_a = make_rsrc(A + img_base, frame_bytes);
+    const buffer_rsrc_t rs_lo = make_rsrc((A_lo ? A_lo : A) + img_base, frame_bytes);
+    const buffer_rsrc_t rs_w = make_rsrc(Wt + (int64_t)n0 * p.ldw, 0x7FFFFF00u);
+
     // ---- halo DMA: piece b = halo rows 8b .. 8b+7; lane l fills slot (l&7) of row 8b + (l>>3) with the source chunk
     // slot ^ ((hx>>1)&7), hx = the row's halo COLUMN.  The 16 lanes of a ds_read_b128 group read 16 consecutive pixels of
     // one or two tile rows = 16 consecutive halo columns (whatever the tap), i.e. all 16 (parity, hx>>1) pairs.
-    auto issue_halo = [&](const half_t* __restrict__ plane, int cc, int buf, int b) {
+    auto issue_halo = [&](bool lo_plane, int cc, int buf, int b) {
         const int hr = b * 8 + (lane >> 3);
         const int hy = hr / HW2, hx = hr - hy * HW2;
         const int c8 = (lane & 7) ^ ((hx >> 1) & 7);
         const int iy = Y0 - 1 + hy, ix = X0 - 1 + hx;
         const bool ok = (hr < HROWS) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
-        glds16(ok ? plane + img_base + ((int64_t)iy * p.Win + ix) * p.Cin + (cc << 6) + c8 * 8 : g_zero_chunk,
-               halo + buf * HBYTES + b * 1024);
+        const unsigned off = ok ? (unsigned)((iy * p.Win + ix) * p.Cin + c8 * 8) * 2u : PNC_BUF_OOB;     // out of the image: zeros
+        glds16_buf(lo_plane ? rs_lo : rs_a, off, (unsigned)cc << 7, halo + buf * HBYTES + b * 1024);
     };
     // ---- W DMA: half tile k = 32 channels of K tile k/2 = k offset 32 k of the packed [N][(ci/64, tap, ci%64)] weights.
     // LDS row R (128 B) = W rows 2R, 2R+1; slot = (n&1)*4 + (c ^ ((R>>1)&3)), c = 16-byte chunk of the 64-byte half row.
     const int nW = WBLK / NW + (wave < (WBLK % NW) ? 1 : 0);      // DMA instructions of this wave per half tile
-    const half_t* wsrc[W_IT];
+    unsigned woff[W_IT];
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
         const int R = (wave + NW * i) * 8 + (lane >> 3), slot = lane & 7;
-        const int n = n0 + 2 * R + (slot >> 2);
+        const int nl = 2 * R + (slot >> 2);
         const int c4 = (slot & 3) ^ ((R >> 1) & 3);
-        wsrc[i] = (n < p.N && wave + NW * i < WBLK) ? Wt + (int64_t)n * p.ldw + c4 * 8 : nullptr;
+        woff[i] = (n0 + nl < p.N) ? (unsigned)(nl * p.ldw + c4 * 8) * 2u : PNC_BUF_OOB;
     }
     auto issue_w = [&](int k, int stage) {
         char* sb = wring + stage * WHB + wave * 1024;
 #pragma unroll
         for (int i = 0; i < W_IT; ++i)
-            if (wave + NW * i < WBLK) glds16(wsrc[i] ? wsrc[i] + k * 32 : g_zero_chunk, sb + i * (NW * 1024));
+            if (wave + NW * i < WBLK) glds16_buf(rs_w, woff[i], (unsigned)k << 6, sb + i * (NW * 1024));
     };
 
     f32x16 acc[MI][NI];
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
     // Slices in execution order: with a precise operand the lo plane's nslices first, then the hi plane's
     const int nslices = p.Cin >> 6, nq1 = nslices * IPS;              // half tiles of one pass
     const int ns_tot = A_lo ? 2 * nslices : nslices, nq = ns_tot * IPS;
-    auto slice_plane = [&](int gs) { return (A_lo && gs < nslices) ? A_lo : A; };
+    auto slice_plane = [&](int gs) { return A_lo && gs < nslices; };      // true: the lo plane
     auto slice_cc = [&](int gs) { return gs >= nslices ? gs - nslices : gs; };
 
     // Software pipeline over half tiles q (two k-steps each), the barrier in the MIDDLE of q's MFMA stream:

@@ -511,11 +511,11 @@ def test_gemm_conv3x3_stencil_tiles_are_bit_identical(F, H, W, Cin, N, epi):
     check("per-tap gather vs emu (fp32)", plain["o32"], e["o32"], *tol)
     check("per-tap gather vs emu (fp16)", plain["o16"], e["o16"], 4e-3)
     # small grids are one sparse round: with the tail split every tile runs as 4 quarter-tile workgroups, without as one
-    for tail in (1, 0):
+    for tail, forced in ((1, 2), (0, 2)):
         tiles = outs()
         prev = hip.set_option(hip.OPT_GEMM_TAIL_SPLIT, tail)
         try:
-            _with_stencil_tiles(2, lambda: hip.gemm(**kw(tiles)))
+            _with_stencil_tiles(forced, lambda: hip.gemm(**kw(tiles)))
         finally:
             hip.set_option(hip.OPT_GEMM_TAIL_SPLIT, prev)
         assert torch.equal(tiles["o32"], plain["o32"]), (tail, (tiles["o32"] - plain["o32"]).abs().max().item())

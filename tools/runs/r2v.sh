@@ -1,0 +1,22 @@
+#!/bin/bash
+# final GPU pass of round 2 on the final build: full gpu suite, default bench line, rocprofv3 stats, PMC passes (traffic + MFMA busy)
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -q --timeout=600 2>&1 | tail -8 > gpurun_out/r2v_pytest.log
+tail -3 gpurun_out/r2v_pytest.log
+timeout 400 python bench.py --steps 10 --warmup 2 --cpu-baseline none > gpurun_out/r2v_bench.json 2> gpurun_out/r2v_bench.err
+python -c "import json;d=json.loads(open('gpurun_out/r2v_bench.json').read().strip().splitlines()[-1]);print(d['value'],d['ms_per_step'],d['parity']['eps_max_abs_err'],d['modes']['fast']['ms_per_step'], d['roofline']['dominant_kernel']['avg_launch_us'])"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --one-stream --cpu-baseline none --no-kernel-breakdown --no-modes"
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r2v_prof -- $BENCH > $GRAFT_REPO_ROOT/gpurun_out/r2v_prof.log 2>&1)
+find gpurun_out/r2v_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r2v_kernel_stats.csv
+rm -rf gpurun_out/r2v_prof
+BENCH1="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --one-stream --cpu-baseline none --no-kernel-breakdown --no-modes"
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
+  (cd /tmp && timeout 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- $BENCH1 > $GRAFT_REPO_ROOT/gpurun_out/r2v_pmc_$c.log 2>&1)
+done
+python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE 3 precise "bench.py --steps 1 --warmup 1 --one-stream --cpu-baseline none --no-kernel-breakdown --no-modes" > gpurun_out/r2v_pmc.log 2>&1
+python tools/pmc_traffic.py --mfma /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES 3 precise 190.0 >> gpurun_out/r2v_pmc.log 2>&1
+mkdir -p gpurun_out/r2v_pmc && cp profiles/round2/pmc_* gpurun_out/r2v_pmc/ 2>/dev/null
+tail -30 gpurun_out/r2v_pmc.log
+timeout 300 python tools/sample.py --steps 25 --out gpurun_out/r2v_sample > gpurun_out/r2v_sample.log 2>&1; tail -5 gpurun_out/r2v_sample.log; rm -rf gpurun_out/r2v_sample

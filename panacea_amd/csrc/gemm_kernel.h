@@ -8,9 +8,10 @@
 //   PNC_A_CONV1D_T  temporal k=3 conv over the frames of one pixel       (gemm_conv1d.hip)
 //
 // Tile: BM x BN block, BK = 64, WGM x WGN waves, each wave owns MI x NI blocks of 32x32.  Operands go HBM -> LDS
-// directly (global_load_lds_dwordx4), 16-B chunks in XOR-swizzled 128-B rows; the LDS image of the DMA is lane-linear,
-// so the swizzle is applied to the per-lane SOURCE address and again on the ds_read side.  Out-of-range chunks (conv
-// padding, K/M/N tails) are sourced from a 16-byte zero block.
+// directly (buffer_load_dwordx4 ... lds through a per-tile buffer resource: 32-bit lane offsets, the K tile as scalar offset),
+// 16-B chunks in XOR-swizzled 128-B rows; the LDS image of the DMA is lane-linear, so the swizzle is applied to the per-lane
+// SOURCE offset and again on the ds_read side.  Out-of-range chunks (conv padding, K/M/N tails) carry the offset
+// PNC_BUF_OOB, which the resource's bound turns into zeros without a memory access.
 //
 // The EPILOGUE is a compile-time parameter (EPI bit set): which fp32 streams are added (res1, res2, row bias), which
 // outputs are written (fp32, fp16, channel-major fp16 "V^T"), GEGLU.  The fast variants assume the vector contract
@@ -194,7 +195,7 @@ __device__ __forceinline__ void store_h8(half_t* out16, half_t* out16_lo, int64_
 // them again.  (Re-reading the rows from global memory instead was measured: no gain — a 327 KB tile per workgroup does
 // not stay in L2, so the re-read costs what the LayerNorm launch's read cost.)  This replaces the LayerNorm launch that
 // would otherwise read the stream again from HBM (attention.py:726-747: every residual GEMM of a block is followed by a norm).
-// wave-tile row -> output row m.  RowLinear: the GEMM's rows are consecutive; RowHalo (conv3x3 halo kernel): the wave tile is
+// wave-tile row -> output row m.  RowLinear: the GEMM's rows are consecutive; RowHalo (gemm_stencil_tile.hip): the wave tile is
 // a strip of a TH x 2^TWS spatial tile of one frame.
 struct RowLinear {
     int mw;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     // splitk_reduce_kernel sums the slices in order and applies the epilogue.
     // Tail split (tail_f = 2 or 4): the last (ntile_mn - nfull) output tiles - the partial round that would leave most
     // CUs idle - are each run by tail_f workgroups that own BM / tail_f rows of the tile: the waves of the other row
-    // groups skip their MFMAs and epilogue (their A rows are DMA'd as zero chunks), all waves still stage W.  Rows are
+    // groups skip their MFMAs and epilogue (their A rows are DMA'd as out-of-bounds offsets = zeros), all waves still stage W.  Rows are
     // independent in a GEMM, so the result does not depend on the split.
     const int ntile_mn = tiles_m * tiles_n;
     int kslice = 0, tile, part = 0;

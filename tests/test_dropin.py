@@ -43,6 +43,35 @@ def test_ctypes_structs_match_the_header_as_gcc_lays_it_out(tmp_path):
     assert ctypes.sizeof(hip.GemmParams) == 280
 
 
+def test_enum_constants_match_the_header_as_gcc_reads_it(tmp_path):
+    """PNC_OPT_* / PNC_A_* / PNC_ACT_* / error codes: the values a C caller gets from the header against the Python constants,
+    and every option index accepted (and restored) by pnc_set_option on a box without a GPU."""
+    import subprocess
+    names = {"PNC_OPT_GEMM_TAIL_SPLIT": hip.OPT_GEMM_TAIL_SPLIT, "PNC_OPT_GEMM_TILE": hip.OPT_GEMM_TILE,
+             "PNC_OPT_ATTN_VARIANT": hip.OPT_ATTN_VARIANT, "PNC_OPT_ATTN_DMA": hip.OPT_ATTN_DMA,
+             "PNC_OPT_GEMM_FUSE_LN": hip.OPT_GEMM_FUSE_LN, "PNC_OPT_GEMM_GROUP_M": hip.OPT_GEMM_GROUP_M,
+             "PNC_OPT_STENCIL_TILES": hip.OPT_STENCIL_TILES, "PNC_A_PLAIN": hip.A_PLAIN, "PNC_A_CONV3X3": hip.A_CONV3X3,
+             "PNC_A_CONV1D_T": hip.A_CONV1D_T, "PNC_ACT_NONE": hip.ACT_NONE, "PNC_ACT_SILU": hip.ACT_SILU, "PNC_ACT_GELU": hip.ACT_GELU}
+    src = ['#include <stdio.h>', f'#include "{hip.HEADER}"', 'int main(void) {']
+    src += [f'printf("{n} %d\\n", (int){n});' for n in list(names) + ["PNC_OPT_COUNT"]]
+    src.append('return 0; }')
+    c = tmp_path / "enums.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "enums"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", str(c), "-o", str(exe)])
+    got = {k: int(v) for k, v in (ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())}
+    for n, v in names.items():
+        assert got[n] == v, n
+    n_opt = got["PNC_OPT_COUNT"]
+    assert n_opt == 1 + max(v for n, v in names.items() if n.startswith("PNC_OPT_"))      # every option has a Python name
+    hip.load()
+    for opt in range(n_opt):
+        before = hip.set_option(opt, 0)
+        assert hip.set_option(opt, before) == 0
+    with pytest.raises(Exception):
+        hip.set_option(n_opt, 1)
+
+
 def test_argument_validation_without_gpu():
     """Entry points validate before launching: bad arguments return PNC_E* codes even with no device."""
     lib = hip.load()

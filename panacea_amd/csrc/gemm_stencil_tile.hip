@@ -306,7 +306,13 @@ int conv3x3_tile_geometry(const PncGemmParams& p, unsigned epi) {
     if ((p.Hout % 16) == 0 && (p.Wout % 16) == 0) tws = 4;
     else if ((p.Hout % 8) == 0 && (p.Wout % 32) == 0) tws = 5;
     if (!tws) return 0;
-    const int ni = (p.N % 320 == 0) ? 5 : 4;
+    int ni = (p.N % 320 == 0) ? 5 : 4;
+    if (ni == 5 && (p.N & 255) == 0) {
+        // a grid that fits one round either way: 256-column tiles fill more of the chip (level 2: 48 x 5 = 240 workgroups of
+        // 256x256 instead of 48 x 4 = 192 of 256x320)
+        const long t5 = (long)(p.M / 256) * (p.N / 320), t4 = (long)(p.M / 256) * (p.N / 256);
+        if (t5 < 256 && t4 <= 256) ni = 4;
+    }
     if (opt == 1) {
         const long tiles = (long)(p.M / 256) * ((p.N + ni * 64 - 1) / (ni * 64));
         if (tiles < 160 || p.N < 256) return 0;

@@ -1,6 +1,6 @@
 """Error budget of the fp16 operand roundings (CPU, torch emulation of the C-ABI — tests/emu.py).
 
-    python tools/exp/error_budget.py [tiny|full16] [--modes ...]
+    python tools/exp/error_budget.py [tiny|full16] [--only] [class=mode,class=mode ...]
 
 Every activation rounding of the path goes through `emu.r16(value, entry_point)`.  This tool classifies each
 rounding by (entry point, calling host function) into operand classes and re-runs the network with a chosen rounding
@@ -8,6 +8,7 @@ per class:
     h   = fp16 (what the kernels do today)
     s   = split fp16 pair hi + lo*2^-11 (22-bit operand, the "precise" mode of DESIGN §6)
     x   = exact (fp32 kept)
+    m   = split pair whose lo plane is MX block-scaled fp8 (e4m3, one 2^k scale per 32 channels); m2 = one mantissa bit less
 Activations are kept in fp32 buffers so that a class set to s/x really carries the extra bits to its consumer.
 Prints max-abs / mean-abs of eps against the oracle (tiny: reference golden) per experiment.
 """
@@ -89,6 +90,33 @@ def rounder(mode: str):
             lo = ((v - hi) * 2048.0).half().float() / 2048.0
             return hi + lo
         return split
+    if mode in ("m", "m2", "m4"):
+        # split pair whose lo plane is an MX block-scaled fp8 (e4m3, one power-of-two scale per 32 channels) — the operand of a
+        # lo pass on the scaled 32x32x64 f8f6f4 MFMA (2x the fp16 rate, half the operand bytes).  "m2" drops one more mantissa
+        # bit of the lo plane: a stand-in for the fp8 rounding of the WEIGHTS in that pass (same relative size, independent).
+        def split_mx(v):
+            hi = v.half().float()
+            lo = (v - hi) * 2048.0
+            shp = lo.shape
+            C = shp[-1]
+            pad = (-C) % 32
+            b = torch.nn.functional.pad(lo.reshape(-1, C), (0, pad)).reshape(-1, (C + pad) // 32, 32)
+            amax = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+            if mode == "m4":                                            # MX fp4 (e2m1: 0, .5, 1, 1.5, 2, 3, 4, 6), block max in [4, 8) -> clamp 6
+                e = torch.floor(torch.log2(amax)) - 2.0
+                x = (b / torch.exp2(e)).clamp(-6.0, 6.0)
+                grid = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+                idx = (x.abs().unsqueeze(-1) - grid).abs().argmin(dim=-1)
+                q = grid[idx] * torch.sign(x)
+            else:
+                e = torch.floor(torch.log2(amax)) - 7.0                 # block max lands in [128, 256) < 448 = e4m3 max
+                q = (b / torch.exp2(e)).to(torch.float8_e4m3fn).float()
+            if mode == "m2":                                            # keep 2 of e4m3's 3 mantissa bits
+                ex = torch.floor(torch.log2(q.abs().clamp_min(1e-30)))
+                q = torch.round(q / torch.exp2(ex - 2.0)) * torch.exp2(ex - 2.0)
+            lo_q = (q * torch.exp2(e)).reshape(-1, C + pad)[:, :C].reshape(shp)
+            return hi + lo_q / 2048.0
+        return split_mx
     return lambda v: v
 
 
@@ -138,6 +166,8 @@ def main():
         inp = step_inputs("full", kw, "cpu", shape=(1, 2, 16, 192))
         ref = po.wrapper_forward(sd, oracle_cfg(kw), inp["x"], inp["t"], cond(inp))
 
+    w.diffusion_model.precision = "fast"      # the hook decides every rounding: the product's own split planes stay off
+
     def run(modes, label):
         with Experiment(modes) as ex, E.use_backend(emu):
             eps = w(inp["x"], inp["t"], cond(inp))
@@ -145,13 +175,17 @@ def main():
         print(f"{label:60s} max {st['max_abs']:.3e}  mean {st['mean_abs']:.3e}", flush=True)
         return st, ex
 
+    only = "--only" in sys.argv          # just the mixes given on the command line (+ the all-fp16 line)
+    if only:
+        sys.argv.remove("--only")
     st, ex = run({"*": "h"}, "all fp16 (today)")
     print("elements rounded per class:", {k: v for k, v in ex.count.items() if v})
-    run({"*": "x"}, "no activation rounding")
-    run({"*": "s"}, "all split")
+    if not only:
+        run({"*": "x"}, "no activation rounding")
+        run({"*": "s"}, "all split")
     base = st["mean_abs"] ** 2
     for c in CLASSES:
-        if ex.count[c]:
+        if ex.count[c] and not only:
             s1, _ = run({"*": "h", c: "x"}, f"fp16 except {c} exact")
             print(f"    -> {c}: {100 * (1 - s1['mean_abs'] ** 2 / base):5.1f} % of the error variance")
     for extra in sys.argv[2:]:

@@ -42,6 +42,35 @@ def _join(hi: torch.Tensor, lo) -> torch.Tensor:
     return hi.float() if lo is None else hi.float() + lo.float() / LO_SCALE
 
 
+# ---- MX block-scaled fp8 lo plane (the format of the NEXT round's lo pass; nothing in the library
+# produces or consumes it yet — this is the reference the producers / the scaled-MFMA lo pass will be checked against).
+# A block is 32 consecutive channels of one row; its scale is one E8M0 byte (2^(byte - 127)); elements are OCP e4m3 bytes.
+MX_BLOCK = 32
+
+
+def mx8_quant(r: torch.Tensor):
+    """fp32 [..., C] (C % 32 == 0) -> (e4m3 bytes uint8 [..., C], E8M0 scale bytes uint8 [..., C / 32]).  The scale puts the block
+    maximum in [128, 256) (e4m3 tops out at 448: no saturation, at most one binade of head room lost); an all-zero block gets
+    scale byte 0 and zero elements."""
+    shp = r.shape
+    b = r.float().reshape(-1, shp[-1] // MX_BLOCK, MX_BLOCK)
+    amax = b.abs().amax(dim=-1, keepdim=True)
+    e = torch.where(amax > 0, torch.floor(torch.log2(amax.clamp_min(1e-38))) - 7.0, torch.full_like(amax, -127.0)).clamp(-127.0, 127.0)
+    q = (b / torch.exp2(e)).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).reshape(shp), (e + 127.0).to(torch.uint8).reshape(*shp[:-1], shp[-1] // MX_BLOCK)
+
+
+def mx8_dequant(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    shp = q.shape
+    v = q.view(torch.float8_e4m3fn).float().reshape(-1, shp[-1] // MX_BLOCK, MX_BLOCK)
+    return (v * torch.exp2(scale.float().reshape(-1, shp[-1] // MX_BLOCK, 1) - 127.0)).reshape(shp)
+
+
+def _lo_mx8(v: torch.Tensor, hi: torch.Tensor):
+    """MX fp8 lo plane of a split operand: (v - hi) * 2^11, block-scaled"""
+    return mx8_quant((v.float() - hi.float()) * LO_SCALE)
+
+
 def _mat(t: torch.Tensor, rows: int, cols: int, ld: int) -> torch.Tensor:
     """[rows, cols] strided view (row stride ld) of the flat storage of t."""
     return torch.as_strided(t.reshape(-1), (rows, cols), (ld, 1))

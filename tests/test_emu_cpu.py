@@ -114,3 +114,30 @@ def test_emu_geglu_and_transposed_split():
     full = (a.float() @ w3.float().t()).half()
     assert torch.equal(qk, full[:, :128])
     assert torch.equal(vt[:, :, :32], full[:, 128:].view(2, 32, 64).permute(0, 2, 1))
+
+
+def test_mx8_lo_plane_format_reference():
+    """The MX fp8 lo plane: block maxima land in [128, 256) of e4m3, the round trip is exact for values
+    e4m3 holds, relative error of any element <= 2^-4 of its block maximum... and a split operand carrying it is ~2^-15 accurate:
+    8x closer to the fp32 value than the plain fp16 rounding, which is what the error budget needs (tools/exp/error_budget.py)."""
+    import torch
+    g = torch.Generator().manual_seed(5)
+    v = torch.randn(64, 320, generator=g) * torch.logspace(-3, 2, 320)[None, :]            # wide per-channel range
+    hi = v.half()
+    q, sc = emu._lo_mx8(v, hi)
+    assert q.dtype == torch.uint8 and sc.dtype == torch.uint8 and sc.shape == (64, 10)
+    r = (v - hi.float()) * emu.LO_SCALE
+    back = emu.mx8_dequant(q, sc)
+    blk = r.reshape(64, 10, 32).abs().amax(-1, keepdim=True)
+    assert ((back - r).reshape(64, 10, 32).abs() <= blk * 2.0 ** -4 + 1e-30).all()
+    scaled_max = blk / torch.exp2(sc.float().reshape(64, 10, 1) - 127.0)
+    assert ((scaled_max >= 128.0) & (scaled_max < 256.0) | (blk == 0)).all()
+    err16 = (hi.float() - v).abs()
+    err_mx = (hi.float() + back / emu.LO_SCALE - v).abs()
+    assert err_mx.max() <= err16.max() / 8.0
+    # exactly representable values survive: integers up to 16 times a power of two
+    x = (torch.arange(-16, 16).float() * 0.25).repeat(2, 1)
+    qq, ss = emu.mx8_quant(x)
+    assert torch.equal(emu.mx8_dequant(qq, ss), x)
+    z, zs = emu.mx8_quant(torch.zeros(1, 32))
+    assert z.eq(0).all() and zs.item() == 0

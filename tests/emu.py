@@ -80,16 +80,11 @@ def load():
     return None
 
 
-def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bias=None, rowbias=None,
-         rb_rows=0, rb_mod=0, res1=None, ldr1=0, res2=None, ldr2=0, out32=None, ldc32=0, out16=None,
-         ldc16=0, out16t=None, ldt=0, t_rows=0, t_gstride=0, n_split=0, act=ACT_NONE, geglu=False,
-         a16_lo=None, out16_lo=None, w_ld=0, ln_gamma=None, ln_beta=None, ln_out16=None, ldln=0, ln_eps=1e-5,
-         ln_in_library=False):
-    assert (not STRICT_DTYPES) or (a16.dtype == torch.float16 and w16.dtype == torch.float16)
-    assert K % 8 == 0
-    Wm = _mat(w16, N, K, w_ld or K).float()
-    if a16_lo is not None:       # precise operand: A = hi + lo * 2^-11 (the kernel sums the two planes' products in fp32)
-        a16 = _join(a16.reshape(-1), a16_lo.reshape(-1)[: a16.numel()])
+ACC_HOOK = None
+
+
+def _contract(a16, Wm, M, N, K, lda, a_mode, conv, tconv):
+    """gatherA[M, K] @ Wm[N, K]^T in fp32: the contraction of every GEMM mode (Wm already a float [N, K] matrix)"""
     if a_mode == A_PLAIN:
         A = _mat(a16, M, K, lda).float()
         acc = A @ Wm.t()
@@ -120,6 +115,22 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
             w = Wm.view(N, 3, Cc).permute(0, 2, 1)
         y = TF.conv1d(x, w, padding=1)                       # [B*Npix, N, T]
         acc = y.view(B, Npix, N, T).permute(0, 3, 1, 2).reshape(M, N)
+    return acc
+
+
+def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bias=None, rowbias=None,
+         rb_rows=0, rb_mod=0, res1=None, ldr1=0, res2=None, ldr2=0, out32=None, ldc32=0, out16=None,
+         ldc16=0, out16t=None, ldt=0, t_rows=0, t_gstride=0, n_split=0, act=ACT_NONE, geglu=False,
+         a16_lo=None, out16_lo=None, w_ld=0, ln_gamma=None, ln_beta=None, ln_out16=None, ldln=0, ln_eps=1e-5,
+         ln_in_library=False):
+    assert (not STRICT_DTYPES) or (a16.dtype == torch.float16 and w16.dtype == torch.float16)
+    assert K % 8 == 0
+    Wm = _mat(w16, N, K, w_ld or K).float()
+    if a16_lo is not None:       # precise operand: A = hi + lo * 2^-11 (the kernel sums the two planes' products in fp32)
+        a16 = _join(a16.reshape(-1), a16_lo.reshape(-1)[: a16.numel()])
+    acc = _contract(a16, Wm, M, N, K, lda, a_mode, conv, tconv)
+    if ACC_HOOK is not None:     # numerics experiments (tools/exp/error_budget.py): e.g. the weight side of an MX lo pass
+        acc = ACC_HOOK(acc, a16, Wm, dict(M=M, N=N, K=K, lda=lda, a_mode=a_mode, conv=conv, tconv=tconv))
     v = acc
     if bias is not None:
         v = v + bias.reshape(-1)[:N].float()

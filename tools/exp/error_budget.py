@@ -8,7 +8,8 @@ per class:
     h   = fp16 (what the kernels do today)
     s   = split fp16 pair hi + lo*2^-11 (22-bit operand, the "precise" mode of DESIGN §6)
     x   = exact (fp32 kept)
-    m   = split pair whose lo plane is MX block-scaled fp8 (e4m3, one 2^k scale per 32 channels); m2 = one mantissa bit less
+    m   = split pair whose lo plane is MX block-scaled fp8 (e4m3, one 2^k scale per 32 channels); m2 = one mantissa bit less;
+          m4 = MX fp4 (e2m1) lo plane;  M / M4 = m / m4 with the WEIGHTS of the lo pass in the same MX format (the real thing)
 Activations are kept in fp32 buffers so that a class set to s/x really carries the extra bits to its consumer.
 Prints max-abs / mean-abs of eps against the oracle (tiny: reference golden) per experiment.
 """
@@ -90,7 +91,7 @@ def rounder(mode: str):
             lo = ((v - hi) * 2048.0).half().float() / 2048.0
             return hi + lo
         return split
-    if mode in ("m", "m2", "m4"):
+    if mode in ("m", "m2", "m4", "M", "M4"):
         # split pair whose lo plane is an MX block-scaled fp8 (e4m3, one power-of-two scale per 32 channels) — the operand of a
         # lo pass on the scaled 32x32x64 f8f6f4 MFMA (2x the fp16 rate, half the operand bytes).  "m2" drops one more mantissa
         # bit of the lo plane: a stand-in for the fp8 rounding of the WEIGHTS in that pass (same relative size, independent).
@@ -102,7 +103,7 @@ def rounder(mode: str):
             pad = (-C) % 32
             b = torch.nn.functional.pad(lo.reshape(-1, C), (0, pad)).reshape(-1, (C + pad) // 32, 32)
             amax = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
-            if mode == "m4":                                            # MX fp4 (e2m1: 0, .5, 1, 1.5, 2, 3, 4, 6), block max in [4, 8) -> clamp 6
+            if mode in ("m4", "M4"):                                    # MX fp4 (e2m1: 0, .5, 1, 1.5, 2, 3, 4, 6), block max in [4, 8) -> clamp 6
                 e = torch.floor(torch.log2(amax)) - 2.0
                 x = (b / torch.exp2(e)).clamp(-6.0, 6.0)
                 grid = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
@@ -118,6 +119,23 @@ def rounder(mode: str):
             return hi + lo_q / 2048.0
         return split_mx
     return lambda v: v
+
+
+def _mx_weights(Wm: torch.Tensor, fp4: bool) -> torch.Tensor:
+    """Wm [N, K] as the lo pass of modes M / M4 sees it: MX block-scaled fp8 / fp4 along K (blocks of 32)"""
+    N, K = Wm.shape
+    pad = (-K) % 32
+    b = torch.nn.functional.pad(Wm, (0, pad)).reshape(N, (K + pad) // 32, 32)
+    amax = b.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    if fp4:
+        e = torch.floor(torch.log2(amax)) - 2.0
+        x = (b / torch.exp2(e)).clamp(-6.0, 6.0)
+        grid = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+        q = grid[(x.abs().unsqueeze(-1) - grid).abs().argmin(dim=-1)] * torch.sign(x)
+    else:
+        e = torch.floor(torch.log2(amax)) - 7.0
+        q = (b / torch.exp2(e)).to(torch.float8_e4m3fn).float()
+    return (q * torch.exp2(e)).reshape(N, K + pad)[:, :K]
 
 
 class Experiment:
@@ -147,10 +165,29 @@ class Experiment:
             c[:, :n] = rounder(exp.modes["ctx"])(context.float())
             rt.ctx16 = c.view(B * E.TEXT_PAD, D)
         E.Runtime.set_context = set_context
+        # modes M / M4: the WEIGHTS of the lo pass are MX fp8 / fp4 too.  The A operand arrives as hi + lo_q (fp32 buffer); its lo
+        # part is what fp16 rounding leaves, and the lo pass contributes lo_q . (W_mx - W) on top of the exact product.
+        big = {m for m in self.modes.values() if m in ("M", "M4")}
+        self._hook = emu.ACC_HOOK
+        if big:
+            fp4 = "M4" in big
+            cache = {}
+
+            def hook(acc, a16, Wm, kw):
+                a = a16.float()
+                lo = a - a.half().float()
+                if not bool(lo.abs().max() > 0):
+                    return acc
+                key = (Wm.data_ptr(), tuple(Wm.shape))
+                if key not in cache:
+                    cache[key] = _mx_weights(Wm, fp4) - Wm
+                return acc + emu._contract(lo, cache[key], kw["M"], kw["N"], kw["K"], kw["lda"], kw["a_mode"], kw["conv"], kw["tconv"])
+            emu.ACC_HOOK = hook
         return self
 
     def __exit__(self, *a):
         emu.r16, emu.STRICT_DTYPES = self._r16, self._strict
+        emu.ACC_HOOK = self._hook
         E.Runtime.empty, E.Runtime.zeros, E.Runtime.set_context = self._empty, self._zeros, self._ctx
 
 

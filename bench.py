@@ -38,6 +38,8 @@ sys.path.insert(0, str(ROOT))
 ALGO_TFLOP_PER_STEP = 96.59        # SURVEY.md §8(d), (B, T) = (2, 8), 6 views, 256x512
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16, MI355X_MICROARCH.md
 GOLDEN_FULL = ROOT / "tests" / "golden" / "full_cfg3.npz"
+# the reference's own fp32 forward at BASELINE config 3 (oracle/gen_golden_full.py): (file, timestep index, input salt)
+GOLDEN_PINS = [("full_cfg3.npz", 999, 0), ("full_cfg3_t500.npz", 500, 0), ("full_cfg3_t39_s1.npz", 39, 1)]
 
 
 def log(*a):
@@ -188,7 +190,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "step", "sample", "none"],
                     help="CPU oracle leg (N = 1 only): auto = bounded sample, then ONE whole step when it fits ~8 min")
-    ap.add_argument("--precision", default="precise", choices=["fast", "precise", "precise-all", "precise-lite"],
+    ap.add_argument("--precision", default="precise", choices=["fast", "precise", "precise-all", "precise-lite", "precise-f16lo"],
                     help="operand policy of the timed region (DESIGN §6).  precise (default) meets eps max-abs < 1e-3; the "
                          "other of fast / precise is timed too and reported under `modes`")
     ap.add_argument("--parallelism", default="replica", choices=["replica", "cfg", "cfg+frames", "frames"],
@@ -326,19 +328,31 @@ def main():
         del sd                         # only the N = 1 cpu_baseline leg needs the fp32 state dict again
 
     def parity_of(prec):
-        """eps of one network call at BASELINE config 3 vs the REFERENCE's own fp32 forward (committed golden)"""
+        """eps of one network call at BASELINE config 3 vs the REFERENCE's own fp32 forward, at every committed pin (three noise
+        levels, two input seeds); the headline numbers are the WORST over the pins"""
         if not (args.config == "full" and T == 8 and rank == 0 and GOLDEN_FULL.exists()) or shard is not None:
             return None          # (a frame-sharded network runs collectives: no single-rank evaluation)
         import numpy as np
-        gold = np.load(GOLDEN_FULL)
         net.diffusion_model.precision = prec
-        gi = {k: v.to(dev) for k, v in synth.synth_inputs(2, T, h, w, context_dim=kw["context_dim"]).items()}
-        eps = net(gi["x"], gi["t"], {k: gi[k] for k in ("concat", "crossattn", "cond_feat")})
+        pins = []
+        for fname, t_index, salt in GOLDEN_PINS:
+            f = ROOT / "tests" / "golden" / fname
+            if not f.exists():
+                continue
+            gold = np.load(f)
+            gi = {k: v.to(dev) for k, v in synth.synth_inputs(2, T, h, w, context_dim=kw["context_dim"], t_index=t_index,
+                                                               salt=salt).items()}
+            eps = net(gi["x"], gi["t"], {k: gi[k] for k in ("concat", "crossattn", "cond_feat")})
+            d = (eps.reshape(-1)[::7].float().cpu() - torch.from_numpy(gold["eps_s7"])).abs()
+            pins.append({"golden": fname, "t_index": t_index, "input_salt": salt, "eps_max_abs_err": d.max().item(),
+                         "eps_mean_abs_err": d.mean().item(), "eps_ref_rms": float(gold["eps_rms"])})
+            del gi, eps
         net.diffusion_model.precision = args.precision
-        d = (eps.reshape(-1)[::7].float().cpu() - torch.from_numpy(gold["eps_s7"])).abs()
-        return {"eps_max_abs_err": d.max().item(), "eps_mean_abs_err": d.mean().item(), "eps_ref_rms": float(gold["eps_rms"]),
-                "tolerance": 1e-3, "within_tolerance": bool(d.max().item() < 1e-3), "precision": prec,
-                "against": "reference fp32 CPU forward (tests/golden/full_cfg3.npz)"}
+        worst = max(pins, key=lambda q: q["eps_max_abs_err"])
+        return {"eps_max_abs_err": worst["eps_max_abs_err"], "eps_mean_abs_err": max(q["eps_mean_abs_err"] for q in pins),
+                "eps_ref_rms": worst["eps_ref_rms"], "tolerance": 1e-3, "within_tolerance": bool(worst["eps_max_abs_err"] < 1e-3),
+                "precision": prec, "pins": pins,
+                "against": "reference fp32 CPU forward (tests/golden/full_cfg3*.npz), worst of the pins"}
 
     with torch.no_grad():
         # parity guard inside the bench run: eps of the very first network call vs the reference's own output
@@ -393,11 +407,11 @@ def main():
         ach = ALGO_TFLOP_PER_STEP * (value / world) if T == 8 else None     # per GPU
         # HBM-side bytes per step come from separate rocprofv3 --pmc passes of this same command (they cannot be collected
         # inside a timed run).  The record names the build it was measured on: a stale record reports null, not a number.
-        traffic, tnote = None, "no PMC record for this build (tools/pmc_traffic.py writes profiles/round2/pmc_traffic.json)"
-        pmc, stamp = ROOT / "profiles" / "round2" / "pmc_traffic.json", ROOT / "panacea_amd" / "lib" / "build.stamp"
-        if pmc.exists() and stamp.exists() and T == 8:
+        traffic, tnote = None, "no PMC record for this build (tools/pmc_traffic.py writes profiles/round3/pmc_traffic.json)"
+        pmc = ROOT / "profiles" / "round3" / "pmc_traffic.json"
+        if pmc.exists() and T == 8:
             rec = json.loads(pmc.read_text())
-            cur = stamp.read_text().strip()
+            cur = hip.build_digest()               # the digest compiled into the loaded library
             ent = rec.get("records", {}).get(args.precision)
             if ent and ent.get("build_stamp") == cur:
                 traffic = ent["traffic_GB_calibrated"] * 1e9
@@ -456,7 +470,7 @@ def main():
                 "note": "one-stream instrumented step (HIP events on the launch stream); rocprofv3 --kernel-trace --stats of "
                         "`bench.py --one-stream` is committed under profiles/ for the same build"}
     # the other operand policy, same steps: the judge and the reader see what the tolerance costs
-    if rank == 0 and world == 1 and args.config == "full" and args.precision in ("fast", "precise") and not args.no_modes:
+    if rank == 0 and world == 1 and args.config == "full" and args.precision in ("fast", "precise") and not args.no_modes and T == 8:
         other = "fast" if args.precision == "precise" else "precise"
         net.diffusion_model.precision = other
         with torch.no_grad():

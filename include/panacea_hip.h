@@ -33,9 +33,13 @@ extern "C" {
 
 /* library / build identification: returns "panacea_hip <version> gfx950" */
 const char* pnc_version(void);
-/* ABI revision of this header (bumped whenever a parameter struct or a prototype changes): 2 */
-#define PNC_ABI_VERSION 2
+/* ABI revision of this header (bumped whenever a parameter struct or a prototype changes): 3 */
+#define PNC_ABI_VERSION 3
 int pnc_abi_version(void);
+/* hex SHA-256 of the sources + compile flags the library was built from (panacea_amd/build.py computes the same digest over
+ * the checkout): a loader compares the two and refuses a library built from other sources instead of calling it with
+ * shifted argument lists */
+const char* pnc_build_digest(void);
 
 /* Tuning / test switches (process-global, read with one relaxed atomic load per launch; results never depend on them
  * beyond what each option states).  Returns the previous value, or PNC_EINVAL for an unknown option. */
@@ -87,6 +91,13 @@ int pnc_set_option(int option, int value);
  *     out16t[(m/t_rows)*t_gstride + (n-n_split)*ldt + m%t_rows] = (fp16)v for n >= n_split
  * ------------------------------------------------------------------------- */
 enum { PNC_A_PLAIN = 0, PNC_A_CONV3X3 = 1, PNC_A_CONV1D_T = 2 };
+/* Storage format of the lo plane of a precise ("split") operand, r = (v - fp16(v)) * 2^11  (PncGemmParams.A_lo):
+ *   PNC_LO_F16  : fp16(r), two bytes per element, same leading dimension as the hi plane
+ *   PNC_LO_E4M3 : OCP fp8 e4m3 of r clamped to +-448, ONE byte per element, same leading dimension IN ELEMENTS.  |r| <= |v|, so
+ *                 no block scale is needed: e4m3 resolves r to 2^-4, i.e. the pair to ~2^-15 of v, and what falls below its
+ *                 smallest subnormal (2^-9) is below 2^-20 absolute.  The consumer GEMM runs the lo K loop on the block-scaled
+ *                 fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 rate on half the bytes) with the 2^-11 as the A scale */
+enum { PNC_LO_F16 = 0, PNC_LO_E4M3 = 1 };
 enum { PNC_ACT_NONE = 0, PNC_ACT_SILU = 1, PNC_ACT_GELU = 2 /* erf GELU: open_clip text-tower MLP */ };
 
 typedef struct PncGemmParams {
@@ -122,7 +133,7 @@ typedef struct PncGemmParams {
      * (sgm/modules/diffusionmodules/model.py:108-112) */
     int32_t conv_pad_br;
     /* sizeof(PncGemmParams) as the CALLER compiled it.  pnc_gemm_f16 / pnc_gemm_workspace_floats return PNC_EABI when
-     * it differs from the library's, instead of reading past a shorter struct (ABI version 2: 280 bytes). */
+     * it differs from the library's, instead of reading past a shorter struct (ABI version 3: 304 bytes). */
     int32_t struct_bytes;
     /* Precise ("split") activation operands.  An fp16 operand v is carried as two fp16 planes,
      *     hi = fp16(v),   lo = fp16((v - hi) * 2^11)        (a 22-bit operand; the 2^11 keeps lo out of the subnormals)
@@ -148,6 +159,16 @@ typedef struct PncGemmParams {
     const float* ln_beta;
     void* ln_out16;
     int32_t ldln;
+    /* formats of A_lo / out16_lo (PNC_LO_*).  a_lo_fmt = PNC_LO_E4M3 needs the weight side of the lo pass as well:
+     *   W_lo     : e4m3 [N][ldw_lo] bytes, W_lo[n][k] = e4m3(W[n][k] * 2^(127 - w_lo_exp)) in the K order of W
+     *   w_lo_exp : E8M0 exponent byte of the tensor, 1..254 (W ~ W_lo * 2^(w_lo_exp - 127)); the packer picks it so that the
+     *              tensor maximum lands in [224, 448] — e4m3's 17 binades below that cover every weight that matters
+     * and 16-byte chunks of 16 consecutive k: PNC_A_PLAIN lda % 16 == 0 and K % 16 == 0; the conv gathers Cin % 64 == 0. */
+    int32_t a_lo_fmt;
+    int32_t out_lo_fmt;
+    int32_t ldw_lo;             /* bytes between rows of W_lo (0 = K) */
+    const void* W_lo;
+    int32_t w_lo_exp;
     int32_t reserved1;
 } PncGemmParams;
 
@@ -199,7 +220,7 @@ int pnc_attn_temporal_f16(const void* q, int ldq, const void* k, int ldk,
 
 /* ------------------------------------------------------------------------- *
  * 3. Normalisations (fp32 stream in, fp16 operand out).  y16_lo (may be NULL) receives the lo plane of a precise
- *    operand, same layout as y16 (see PncGemmParams.A_lo).
+ *    operand, same layout as y16 (see PncGemmParams.A_lo), in the format lo_fmt (PNC_LO_*; pnc_layernorm: fp16 only).
  * ------------------------------------------------------------------------- */
 /* Spatial GroupNorm(32,C) over one frame's (H*W, C/32) slab, two launches.
  *   stats: partial[(f*nchunk + chunk)*32 + g] = {count, mean, M2}
@@ -210,12 +231,12 @@ int pnc_groupnorm_stats(const float* x, int ldx, int F, int Npix, int C,
 int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int C,
                         int pix_per_chunk, const float* partial,
                         const float* gamma, const float* beta, float eps, int silu,
-                        void* y16, int ldy, void* y16_lo, void* stream);
+                        void* y16, int ldy, void* y16_lo, int lo_fmt, void* stream);
 /* Temporal GroupNorm(32,C)+SiLU: statistics over the (C/32, T) slab of ONE pixel
  *    -> nn.GroupNorm applied on "(b h w) c t" (openaimodel.py:409-419,509-515) */
 int pnc_groupnorm_temporal_silu(const float* x, int B, int T, int Npix, int C,
                                 const float* gamma, const float* beta, float eps,
-                                void* y16, void* y16_lo, void* stream);
+                                void* y16, void* y16_lo, int lo_fmt, void* stream);
 /* LayerNorm over C (eps 1e-5) -> nn.LayerNorm (attention.py:699-701) */
 int pnc_layernorm(const float* x, int ldx, int M, int C,
                   const float* gamma, const float* beta, float eps,
@@ -255,13 +276,13 @@ int pnc_tokens_to_nchw_f32(const float* x, int ld, int F, int Npix, int C,
 /* out32[m][0:C1] = a[m][:], out32[m][C1:C1+C2] = s[m][:] + c[m][:]; optional fp16 copy
  *    -> th.cat([h, hs.pop() + control.pop()], dim=1)  (controlmodel.py:193-195) */
 int pnc_concat_add(const float* a, int C1, const float* s, const float* c, int C2,
-                   int64_t M, float* out32, void* out16, void* out16_lo, void* stream);
+                   int64_t M, float* out32, void* out16, void* out16_lo, int lo_fmt, void* stream);
 /* y = x + a (fp32, may be in place); optional fp16 copy of y
  *    -> h += guided_hint / h += control.pop()  (controlmodel.py:127,192) */
-int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16, void* y16_lo,
+int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16, void* y16_lo, int lo_fmt,
                 void* stream);
-/* fp32 -> fp16 */
-int pnc_cast_f16(const float* x, int64_t n, void* y16, void* y16_lo, void* stream);
+/* fp32 -> fp16 (+ lo plane in lo_fmt) */
+int pnc_cast_f16(const float* x, int64_t n, void* y16, void* y16_lo, int lo_fmt, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * 5. First-stage decoder: row softmax of a materialised score

@@ -41,12 +41,24 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def library_digest(lib: Path = LIB):
+    """The source digest compiled INTO a built library (pnc_build_digest()), or None when it cannot be read.  The digest
+    travels inside the .so, so a checkout that pulls new sources next to an old (git-ignored) build is detected whatever
+    side files say (a tracked build.stamp could match the new sources next to the old library)."""
+    import ctypes
+    try:
+        fn = ctypes.CDLL(str(lib)).pnc_build_digest
+    except (OSError, AttributeError):
+        return None
+    fn.restype = ctypes.c_char_p
+    return fn().decode()
+
+
 def build(force: bool = False, verbose: bool = True) -> Path:
     """Compile every HIP source for gfx950 and link the C-ABI shared library."""
     LIBDIR.mkdir(exist_ok=True)
-    stamp = LIBDIR / "build.stamp"
     dig = _digest()
-    if not force and LIB.exists() and stamp.exists() and stamp.read_text() == dig:
+    if not force and LIB.exists() and library_digest() == dig:
         return LIB
     hipcc = _hipcc()
     objs = []
@@ -54,6 +66,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     for s in SOURCES:
         obj = LIBDIR / (Path(s).stem + ".o")
         cmd = [hipcc, *FLAGS, "-c", str(CSRC / s), "-o", str(obj)]
+        if s == "misc.hip":          # pnc_build_digest() lives there
+            cmd.insert(1, f'-DPNC_BUILD_DIGEST="{dig}"')
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -72,7 +86,6 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    stamp.write_text(dig)
     return LIB
 
 

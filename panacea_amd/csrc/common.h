@@ -58,6 +58,24 @@ __device__ __forceinline__ half4v lo_plane4(const float (&v)[4], half4v hi) {
     return l;
 }
 
+// The same lo plane as OCP fp8 e4m3 (PNC_LO_E4M3): |r| <= |v|, clamped to the format's +-448; four consecutive channels -> one dword.
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+__device__ __forceinline__ unsigned lo_plane4_e4m3(const float (&v)[4], half4v hi) {
+    return pack4_e4m3((v[0] - (float)hi[0]) * PNC_LO_SCALE, (v[1] - (float)hi[1]) * PNC_LO_SCALE,
+                      (v[2] - (float)hi[2]) * PNC_LO_SCALE, (v[3] - (float)hi[3]) * PNC_LO_SCALE);
+}
+// lo plane of 4 consecutive channels at ELEMENT index idx of the plane `lo` in either format (fmt is launch-uniform)
+__device__ __forceinline__ void store_lo4(void* lo, int fmt, int64_t idx, const float (&v)[4], half4v hi) {
+    if (fmt == PNC_LO_E4M3) *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lo) + idx) = lo_plane4_e4m3(v, hi);
+    else *reinterpret_cast<half4v*>(reinterpret_cast<half_t*>(lo) + idx) = lo_plane4(v, hi);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -96,11 +96,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const PncGemmParams 
     if (p.out16) {
         half_t* op = reinterpret_cast<half_t*>(p.out16) + (int64_t)m * p.ldc16 + ncol;
         half_t* ol = reinterpret_cast<half_t*>(p.out16_lo);
+        float r[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const half_t h = (half_t)v[e];
             op[e] = h;
-            if (ol) ol[(int64_t)m * p.ldc16 + ncol + e] = (half_t)((v[e] - (float)h) * LO_SCALE);
+            r[e] = (v[e] - (float)h) * LO_SCALE;
+        }
+        if (ol && p.out_lo_fmt == PNC_LO_E4M3) {
+            unsigned char* o8 = reinterpret_cast<unsigned char*>(p.out16_lo) + (int64_t)m * p.ldc16 + ncol;
+            const unsigned w0 = pack4_e4m3(r[0], r[1], r[2], r[3]), w1 = pack4_e4m3(r[4], r[5], r[6], r[7]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o8[e] = (unsigned char)(w0 >> (8 * e)); o8[4 + e] = (unsigned char)(w1 >> (8 * e)); }
+        } else if (ol) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ol[(int64_t)m * p.ldc16 + ncol + e] = (half_t)r[e];
         }
     }
 }
@@ -175,6 +185,16 @@ static int validate(const PncGemmParams& p) {
     }
     if (p.out16t && ((p.n_split % 128) || p.t_rows <= 0 || p.N <= 32)) return PNC_EINVAL;
     if (p.out16_lo && !p.out16) return PNC_EINVAL;
+    if ((p.a_lo_fmt != PNC_LO_F16 && p.a_lo_fmt != PNC_LO_E4M3) || (p.out_lo_fmt != PNC_LO_F16 && p.out_lo_fmt != PNC_LO_E4M3))
+        return PNC_EINVAL;
+    if (p.out16_lo && p.out_lo_fmt == PNC_LO_E4M3 && p.geglu) return PNC_EINVAL;        // (the GEGLU hidden is never a split operand)
+    if (p.A_lo && p.a_lo_fmt == PNC_LO_E4M3) {
+        // e4m3 lo pass: 16-byte chunks of 16 consecutive k on both operands, and the weight side of the pass
+        if (!p.W_lo || p.w_lo_exp < 1 || p.w_lo_exp > 254) return PNC_EINVAL;
+        if ((uintptr_t)p.W_lo & 15) return PNC_EALIGN;
+        if (p.K % 16 || (p.ldw_lo != 0 && (p.ldw_lo < p.K || p.ldw_lo % 16))) return PNC_EALIGN;
+        if (p.a_mode == PNC_A_PLAIN ? (p.lda % 16 != 0) : (p.Cin % 64 != 0)) return PNC_EALIGN;
+    }
     if (!p.out32 && !p.out16 && !p.out16t) return PNC_EINVAL;
     if (p.ln_out16) {           // fused / trailing LayerNorm of the fp32 output rows (same limits as pnc_layernorm)
         if (!p.out32 || p.geglu || p.out16t || !p.ln_gamma || !p.ln_beta) return PNC_EINVAL;
@@ -207,6 +227,7 @@ static unsigned epilogue_with_ln(const PncGemmParams& p) {
 static void normalise(PncGemmParams& p) {
     if (!p.out16t) p.n_split = p.N;
     if (p.ldw == 0) p.ldw = p.K;
+    if (p.ldw_lo == 0) p.ldw_lo = p.K;
     if (!p.res1 && p.res2) { p.res1 = p.res2; p.ldr1 = p.ldr2; p.res2 = nullptr; }   // fp32 addition commutes bit-exactly for two terms
 }
 

@@ -33,6 +33,10 @@
 namespace pnc_gemm {
 
 constexpr int BK = 64;          // fp16 elements per K tile = 128 B per LDS row
+constexpr int BK8 = 128;        // e4m3 elements per K tile of an fp8 lo pass: the same 128-byte rows
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+constexpr int E8M0_LO_INV = 127 - 11;      // A scale of the fp8 lo pass: 2^-11 (PncGemmParams.A_lo)
 
 enum : unsigned {
     E_R1 = 1,        // += res1 (fp32 stream, may alias out32)
@@ -110,12 +114,13 @@ __device__ __forceinline__ float gelu_tab_f(float g, const float* tab) {
     return g * fmaf(f, e.y, e.x);
 }
 
-// byte offset (from the window origin) of the 16-byte chunk (row state s, k index kc) of an A plane, or PNC_BUF_OOB (reads as zero)
-template <int AMODE>
+// byte offset (from the window origin) of the 16-byte chunk (row state s, k index kc) of an A plane, or PNC_BUF_OOB (reads as zero).
+// ESZ = bytes per element: 2 (fp16 planes: 8 channels per chunk), 1 (e4m3 lo plane: 16 channels per chunk, Cin % 64 == 0)
+template <int AMODE, unsigned ESZ = 2u>
 __device__ __forceinline__ unsigned a_chunk_off(const PncGemmParams& p, const RowState& s, int kc) {
     if (!s.valid || kc >= p.K) return PNC_BUF_OOB;
     if (AMODE == PNC_A_PLAIN) {
-        return (unsigned)(s.rel + kc) * 2u;
+        return (unsigned)(s.rel + kc) * ESZ;
     } else if (AMODE == PNC_A_CONV3X3) {
         // K order: (ky,kx,ci) for narrow inputs; (ci/64, ky, kx, ci%64) when Cin % 64 == 0, so that the nine tap
         // reads of one 64-channel slice of a pixel neighbourhood are consecutive K tiles and hit L1/L2
@@ -137,7 +142,7 @@ __device__ __forceinline__ unsigned a_chunk_off(const PncGemmParams& p, const Ro
             iy = s.y * p.stride + ky - pad; ix = s.x * p.stride + kx - pad;
             ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
         }
-        return ok ? (unsigned)(s.rel + (iy * p.Win + ix) * p.Cin + ci) * 2u : PNC_BUF_OOB;
+        return ok ? (unsigned)(s.rel + (iy * p.Win + ix) * p.Cin + ci) * ESZ : PNC_BUF_OOB;
     } else {
         // K order: (dt, ci); (ci/64, dt, ci%64) when Cin % 64 == 0 (the three taps of a slice are consecutive K tiles)
         int tap, ci;
@@ -148,7 +153,7 @@ __device__ __forceinline__ unsigned a_chunk_off(const PncGemmParams& p, const Ro
             tap = kc / p.Cin; ci = kc - tap * p.Cin;
         }
         const int tt = s.y + tap - 1;
-        return (tt < 0 || tt >= p.T) ? PNC_BUF_OOB : (unsigned)(s.rel + (tap - 1) * p.Npix * p.Cin + ci) * 2u;
+        return (tt < 0 || tt >= p.T) ? PNC_BUF_OOB : (unsigned)(s.rel + (tap - 1) * p.Npix * p.Cin + ci) * ESZ;
     }
 }
 
@@ -159,17 +164,27 @@ __device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.0f +
 // the same out of line, for the generic epilogue / split-K reduce (keeps the erff expansion out of their unrolled loops)
 __device__ __attribute__((noinline)) static float gelu_erf_call(float v) { return gelu_erf_f(v); }
 
-// fp16 store of 8 consecutive columns, plus the lo plane of a precise operand when the caller asked for one
-__device__ __forceinline__ void store_h8(half_t* out16, half_t* out16_lo, int64_t off, const float (&v)[8]) {
+// fp16 store of 8 consecutive columns, plus the lo plane of a precise operand (fp16 or e4m3: lo_fmt) when the caller asked for one
+__device__ __forceinline__ void store_h8(half_t* out16, void* out16_lo, int64_t off, const float (&v)[8], int lo_fmt = PNC_LO_F16) {
     half8v o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
     *reinterpret_cast<half8v*>(out16 + off) = o;
     if (out16_lo) {
-        half8v l;
+        float r[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) l[e] = (half_t)((v[e] - (float)o[e]) * LO_SCALE);
-        *reinterpret_cast<half8v*>(out16_lo + off) = l;
+        for (int e = 0; e < 8; ++e) r[e] = (v[e] - (float)o[e]) * LO_SCALE;
+        if (lo_fmt == PNC_LO_E4M3) {
+            uint2 w;
+            w.x = pack4_e4m3(r[0], r[1], r[2], r[3]);
+            w.y = pack4_e4m3(r[4], r[5], r[6], r[7]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(out16_lo) + off) = w;
+        } else {
+            half8v l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) l[e] = (half_t)r[e];
+            *reinterpret_cast<half8v*>(reinterpret_cast<half_t*>(out16_lo) + off) = l;
+        }
     }
 }
 
@@ -225,7 +240,7 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
     constexpr int NJ = (NI + ENI - 1) / ENI, NS = NJ * MI;
     constexpr int NPMAX = ENI == 2 ? 4 : 2;
     half_t* out16 = reinterpret_cast<half_t*>(p.out16);
-    half_t* out16_lo = reinterpret_cast<half_t*>(p.out16_lo);
+    void* out16_lo = p.out16_lo;
     constexpr bool GELU = (EPI & E_GELU) != 0;
     const bool silu = (!HAS_X) && (p.act == PNC_ACT_SILU);
     const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -346,7 +361,7 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
                 *reinterpret_cast<f32x4*>(op) = o0;
                 *reinterpret_cast<f32x4*>(op + 4) = o1;
             }
-            if constexpr (O16) store_h8(out16, out16_lo, (int64_t)m * p.ldc16 + ncol, v);
+            if constexpr (O16) store_h8(out16, out16_lo, (int64_t)m * p.ldc16 + ncol, v, p.out_lo_fmt);
         });
         if constexpr (LN) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every lane's rows are back in the slab
@@ -420,7 +435,7 @@ __device__ __forceinline__ void epi_geglu(const PncGemmParams& p, f32x16 (&acc)[
     const int cl = lane % CPL, rl = lane / CPL;
     const int Nout = p.N >> 1;
     half_t* out16 = reinterpret_cast<half_t*>(p.out16);
-    half_t* out16_lo = reinterpret_cast<half_t*>(p.out16_lo);
+    void* out16_lo = p.out16_lo;
     const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
     static_for<NI / 2>([&](auto jc_) {
         constexpr int jc = decltype(jc_)::value * 2;
@@ -459,7 +474,7 @@ __device__ __forceinline__ void epi_geglu(const PncGemmParams& p, f32x16 (&acc)[
                     v[e] = (a0[ps][e] + b0[e]) * gelu_tab_f(g0[ps][e] + g0b[e], phi_tab);
                     v[e + 4] = (a1[ps][e] + b1[e]) * gelu_tab_f(g1[ps][e] + g1b[e], phi_tab);
                 }
-                store_h8(out16, out16_lo, (int64_t)m * p.ldc16 + ncol, v);
+                store_h8(out16, out16_lo, (int64_t)m * p.ldc16 + ncol, v, p.out_lo_fmt);
             }
         });
     });
@@ -538,7 +553,12 @@ __device__ __forceinline__ void epi_generic(const PncGemmParams& p, f32x16 (&acc
             if (out16) {
                 const half_t h = (half_t)v;
                 out16[(int64_t)m * p.ldc16 + n] = h;
-                if (out16_lo) out16_lo[(int64_t)m * p.ldc16 + n] = (half_t)((v - (float)h) * LO_SCALE);
+                if (out16_lo) {
+                    const float r = (v - (float)h) * LO_SCALE;
+                    if (p.out_lo_fmt == PNC_LO_E4M3)
+                        reinterpret_cast<unsigned char*>(p.out16_lo)[(int64_t)m * p.ldc16 + n] = (unsigned char)(pack4_e4m3(r, 0.0f, 0.0f, 0.0f) & 0xFFu);
+                    else out16_lo[(int64_t)m * p.ldc16 + n] = (half_t)r;
+                }
             }
         }
     });
@@ -608,8 +628,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     const int kt_begin = (int)((int64_t)kslice * ntiles_all / ksplit);
     const int ntiles = (int)((int64_t)(kslice + 1) * ntiles_all / ksplit) - kt_begin;
     if (ksplit > 1) p.out32 = p.ws + (int64_t)kslice * p.M * p.N;
-    // precise operand: the lo plane's K tiles run first, then the accumulators are scaled by 2^-11
-    const int nt_lo = A_lo ? ntiles : 0;
+    // precise operand: the lo plane's K tiles run first.  fp16 lo plane: the same K tiles as the hi plane, then the accumulators
+    // are scaled by 2^-11.  e4m3 lo plane (lo8): 128 k per 128-byte LDS row -> half the tiles, DMA pieces and barriers; the
+    // block-scaled fp8 MFMA carries the 2^-11 as its A scale and the weight row's exponent as its B scale, so the lo products
+    // land in the accumulators at their final weight and the hi pass simply continues.
+    const bool lo8 = A_lo && p.a_lo_fmt == PNC_LO_E4M3;
+    const int nlo_all = lo8 ? (p.K + BK8 - 1) / BK8 : ntiles_all;
+    const int kt_begin_lo = (int)((int64_t)kslice * nlo_all / ksplit);
+    const int nt_lo = A_lo ? (int)((int64_t)(kslice + 1) * nlo_all / ksplit) - kt_begin_lo : 0;
     const int ntot = ntiles + nt_lo;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -634,8 +660,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     // the K loop for plain A and for W (the K tile enters as the scalar offset); the gathers recompute theirs per K tile.
     const int64_t a_origin = a_window_origin<AMODE>(p, m0);
     const buffer_rsrc_t rs_a = make_rsrc(A + a_origin, 0x7FFFFF00u);
-    const buffer_rsrc_t rs_alo = make_rsrc((A_lo ? A_lo : A) + a_origin, 0x7FFFFF00u);
+    const buffer_rsrc_t rs_alo = make_rsrc(lo8 ? static_cast<const void*>(reinterpret_cast<const char*>(p.A_lo) + a_origin)
+                                               : static_cast<const void*>((A_lo ? A_lo : A) + a_origin), 0x7FFFFF00u);
     const buffer_rsrc_t rs_w = make_rsrc(Wt + (int64_t)n0 * p.ldw, 0x7FFFFF00u);
+    const buffer_rsrc_t rs_wlo = make_rsrc(lo8 ? static_cast<const void*>(reinterpret_cast<const char*>(p.W_lo) + (int64_t)n0 * p.ldw_lo)
+                                               : static_cast<const void*>(Wt + (int64_t)n0 * p.ldw), 0x7FFFFF00u);
     unsigned woff[B_IT], aoff[A_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -648,12 +677,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     const int kt_tail = (p.K & (BK - 1)) ? ntiles_all - 1 : -1;      // the one K tile with chunks beyond K, if any
     auto issue_tile = [&](int kt_local, int stage) {
         const bool lo = kt_local < nt_lo;
-        const int kt = kt_begin + (lo ? kt_local : kt_local - nt_lo);
+        char* sa = smem + stage * STAGE + wave * 1024;
+        char* sb = sa + A_BYTES;
+        if (lo && lo8) {                                 // (uniform) e4m3 tile: chunk = 16 k, byte offsets = element offsets
+            // The lane offsets of this branch are derived from the hi pass's on the spot.  Opaque copies of the two lane constants
+            // keep hipcc from hoisting them out of the K loop as a second set of loop invariants: next to 160 accumulator
+            // registers the kernel has ~12 VGPRs to spare, and 9-20 more invariants spilled 100-300 registers (round 3).
+            int schunk8 = schunk, srow8 = srow;
+            asm volatile("" : "+v"(schunk8), "+v"(srow8));
+            const int kt8 = kt_begin_lo + kt_local;
+            const int kc8 = kt8 * BK8 + schunk8 * 16;
+            const unsigned ks8 = (unsigned)kt8 * BK8;
+            const bool k_on = kc8 < p.K;                 // false only in the chunks of the last tile beyond K
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                if constexpr (AMODE == PNC_A_PLAIN)      // (rel + 8 schunk) * 2 -> rel + 16 schunk
+                    glds16_buf(rs_alo, (k_on && aoff[i] != PNC_BUF_OOB) ? (aoff[i] >> 1) + (unsigned)schunk8 * 8u : PNC_BUF_OOB, ks8,
+                               sa + i * (RPI * 128));
+                else glds16_buf(rs_alo, a_chunk_off<AMODE, 1u>(p, rows[i], kc8), 0u, sa + i * (RPI * 128));
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                glds16_buf(rs_wlo, (k_on && woff[i] != PNC_BUF_OOB) ? (unsigned)((i * RPI + srow8) * p.ldw_lo + schunk8 * 16) : PNC_BUF_OOB,
+                           ks8, sb + i * (RPI * 128));
+            return;
+        }
+        const int kt = (lo ? kt_begin_lo : kt_begin - nt_lo) + kt_local;
         const buffer_rsrc_t rs = lo ? rs_alo : rs_a;
         const int kc = kt * BK + schunk * 8;
         const unsigned ks = (unsigned)kt * (BK * 2);     // the K tile as the scalar byte offset of plain rows
-        char* sa = smem + stage * STAGE + wave * 1024;
-        char* sb = sa + A_BYTES;
         if (kt != kt_tail) {                             // (uniform) no per-lane predicate on the K index
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
@@ -744,6 +796,40 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
             }
         }
     };
+    // e4m3 lo tile: two MFMA windows of 64 k (the last tile of K = 320 holds one).  Lane (row r, group g) supplies bytes
+    // 32 g .. 32 g + 31 of the window for both operands (element j of a lane group pairs with element j of the same group of the
+    // other operand: tools/exp/mx_mfma_probe.hip) = chunks 2g, 2g+1 of the window: two ds_read_b128 per fragment, same swizzle.
+    auto compute8 = [&](int stage, int kt_local) {
+        const char* sa = smem + stage * STAGE;
+        const char* sb = sa + A_BYTES;
+        const int nwin = (p.K - (kt_begin_lo + kt_local) * BK8) > 64 ? 2 : 1;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            if (w < nwin) {
+                i32x8 af[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int row = wm * (MI * 32) + i * 32 + frow;
+                    const i32x4 a0 = *reinterpret_cast<const i32x4*>(sa + lds_off128(row, w * 4 + fk * 2));
+                    const i32x4 a1 = *reinterpret_cast<const i32x4*>(sa + lds_off128(row, w * 4 + fk * 2 + 1));
+                    af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int row = wn * (NI * 32) + j * 32 + frow;
+                    const i32x4 b0 = *reinterpret_cast<const i32x4*>(sb + lds_off128(row, w * 4 + fk * 2));
+                    const i32x4 b1 = *reinterpret_cast<const i32x4*>(sb + lds_off128(row, w * 4 + fk * 2 + 1));
+                    const i32x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf, acc[i][j], 0, 0, 0, E8M0_LO_INV, 0, p.w_lo_exp);
+                    // one B fragment (8 registers) in flight: hipcc otherwise hoists the reads of all NI column blocks (40 registers
+                    // at NI = 5) above the first MFMA and spills next to the 160 accumulator registers
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
     auto scale_lo = [&]() {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -765,12 +851,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         // (s_memtime timeline: 1870 vs 690 cycles per tile in the issue segment, with waves 0-3 then idling ~1400
         // cycles at the barrier): each SIMD then has one wave issuing DMA while the other runs MFMAs.
         const bool late = NW == 8 && wave >= 4 && wave_on && ntot >= 8;   // 2-5 % at long K
-        for (int kt = 0; kt < ntot; ++kt) {
+        // The e4m3 lo tiles run in a loop of their own (same pipeline, same tile counter): one MFMA kind per loop keeps the
+        // register allocator from moving accumulator blocks between the two passes (a shared loop spilled 170 registers).
+        const int n8 = lo8 ? nt_lo : 0;
+        for (int kt = 0; kt < n8; ++kt) {              // (no mid-stream DMA issue here: the lo pass is 3-20 short tiles)
+            if (kt + 1 < ntot) issue_tile(kt + 1, (kt + 1) & 1);
+            if (wave_on) compute8(kt & 1, kt);
+            __syncthreads();
+        }
+        for (int kt = n8; kt < ntot; ++kt) {
             const bool nxt = kt + 1 < ntot;
             if (nxt && !late) issue_tile(kt + 1, (kt + 1) & 1);
             if (wave_on) {
                 compute(kt & 1, (nxt && late) ? kt + 1 : -1);
-                if (kt + 1 == nt_lo) scale_lo();
+                if (!lo8 && kt + 1 == nt_lo) scale_lo();
             }
             __syncthreads();
         }
@@ -787,12 +881,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         }
         __builtin_amdgcn_s_barrier();
         int st = 0;
-        for (int kt = 0; kt < ntot; ++kt) {
+        const int n8 = lo8 ? nt_lo : 0;
+        for (int kt = 0; kt < n8; ++kt) {                             // e4m3 lo tiles (see the two-stage loop)
+            const bool ahead = (kt + 2) < ntot;
+            if (ahead) issue_tile(kt + 2, st == 0 ? 2 : st - 1);
+            if (wave_on) compute8(st, kt);
+            if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            st = (st == 2) ? 0 : st + 1;
+        }
+        for (int kt = n8; kt < ntot; ++kt) {
             const bool ahead = (kt + 2) < ntot;
             if (ahead) issue_tile(kt + 2, st == 0 ? 2 : st - 1);      // (kt + 2) % 3
             if (wave_on) {
                 compute(st);
-                if (kt + 1 == nt_lo) scale_lo();
+                if (!lo8 && kt + 1 == nt_lo) scale_lo();
             }
             if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

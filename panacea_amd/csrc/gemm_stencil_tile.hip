@@ -301,6 +301,7 @@ int conv3x3_tile_geometry(const PncGemmParams& p, unsigned epi) {
     if (!opt) return 0;
     if (p.stride != 1 || p.upsample || p.conv_pad_br || (p.Cin & 63) || p.Hin != p.Hout || p.Win != p.Wout) return 0;
     if (p.K != 9 * p.Cin || p.M % (p.Hout * p.Wout)) return 0;
+    if (p.A_lo && p.a_lo_fmt != PNC_LO_F16) return 0;            // the tile kernel's lo pass reads fp16 planes (same MFMA as the hi pass)
     if (epi != E_O16 && epi != E_O32 && epi != (E_O32 | E_O16) && epi != (E_R1 | E_O32) && epi != (E_R1 | E_O32 | E_O16)) return 0;
     int tws = 0;
     if ((p.Hout % 16) == 0 && (p.Wout % 16) == 0) tws = 4;

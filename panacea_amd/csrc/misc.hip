@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void concat_add_kernel(const float* __restrict
                                                          const float* __restrict__ s,
                                                          const float* __restrict__ c, int C2, int64_t M,
                                                          float* __restrict__ out32, half_t* __restrict__ out16,
-                                                         half_t* __restrict__ out16_lo) {
+                                                         void* __restrict__ out16_lo, int lo_fmt) {
     const int CT = C1 + C2, V = CT >> 2;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M * V) return;
@@ -128,14 +128,14 @@ __global__ __launch_bounds__(256) void concat_add_kernel(const float* __restrict
         *reinterpret_cast<half4v*>(out16 + m * CT + ch) = h;
         if (out16_lo) {
             const float o[4] = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<half4v*>(out16_lo + m * CT + ch) = lo_plane4(o, h);
+            store_lo4(out16_lo, lo_fmt, m * CT + ch, o, h);
         }
     }
 }
 
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, const float* __restrict__ a,
                                                   int64_t n4, float* __restrict__ y32, half_t* __restrict__ y16,
-                                                  half_t* __restrict__ y16_lo) {
+                                                  void* __restrict__ y16_lo, int lo_fmt) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, c
         *reinterpret_cast<half4v*>(y16 + i * 4) = h;
         if (y16_lo) {
             const float o[4] = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<half4v*>(y16_lo + i * 4) = lo_plane4(o, h);
+            store_lo4(y16_lo, lo_fmt, i * 4, o, h);
         }
     }
 }
@@ -200,7 +200,12 @@ extern "C" int pnc_cfg_euler_step(const float* eps_tok, int ld, int T, int Npix,
     return pnc_launch_status();
 }
 
-extern "C" const char* pnc_version(void) { return "panacea_hip 0.2.0 gfx950"; }
+extern "C" const char* pnc_version(void) { return "panacea_hip 0.3.0 gfx950"; }
+// the digest of the sources this object was compiled from (panacea_amd/build.py passes it to this translation unit)
+#ifndef PNC_BUILD_DIGEST
+#define PNC_BUILD_DIGEST "unstamped"
+#endif
+extern "C" const char* pnc_build_digest(void) { return PNC_BUILD_DIGEST; }
 
 static std::atomic<int> g_options[PNC_OPT_COUNT] = {{1}, {0}, {0}, {1}, {1}, {0}, {1}};
 
@@ -255,23 +260,25 @@ extern "C" int pnc_tokens_to_nchw_f32(const float* x, int ld, int F, int Npix, i
 }
 
 extern "C" int pnc_concat_add(const float* a, int C1, const float* s, const float* c, int C2,
-                              int64_t M, float* out32, void* out16, void* out16_lo, void* stream) {
+                              int64_t M, float* out32, void* out16, void* out16_lo, int lo_fmt, void* stream) {
     if (!a || !s || M < 1 || C1 % 4 || C2 % 4 || C1 < 4 || C2 < 4) return PNC_EINVAL;
+    if (lo_fmt != PNC_LO_F16 && lo_fmt != PNC_LO_E4M3) return PNC_EINVAL;
     if ((!out32 && !out16) || (out16_lo && !out16)) return PNC_EINVAL;
     const int64_t n = M * ((C1 + C2) / 4);
     hipLaunchKernelGGL(concat_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a, C1, s, c, C2, M, out32,
-                       reinterpret_cast<half_t*>(out16), reinterpret_cast<half_t*>(out16_lo));
+                       reinterpret_cast<half_t*>(out16), out16_lo, lo_fmt);
     return pnc_launch_status();
 }
 
-extern "C" int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16, void* y16_lo,
+extern "C" int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16, void* y16_lo, int lo_fmt,
                            void* stream) {
     if (!x || n < 4 || n % 4 || (!y32 && !y16) || (y16_lo && !y16)) return PNC_EINVAL;
+    if (lo_fmt != PNC_LO_F16 && lo_fmt != PNC_LO_E4M3) return PNC_EINVAL;
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), x, a, n4, y32, reinterpret_cast<half_t*>(y16),
-                       reinterpret_cast<half_t*>(y16_lo));
+                       y16_lo, lo_fmt);
     return pnc_launch_status();
 }
 
@@ -341,6 +348,6 @@ extern "C" int pnc_softmax_rows_f16(const float* s, int64_t lds, int M, int N, f
     return pnc_launch_status();
 }
 
-extern "C" int pnc_cast_f16(const float* x, int64_t n, void* y16, void* y16_lo, void* stream) {
-    return pnc_add_f32(x, nullptr, n, nullptr, y16, y16_lo, stream);
+extern "C" int pnc_cast_f16(const float* x, int64_t n, void* y16, void* y16_lo, int lo_fmt, void* stream) {
+    return pnc_add_f32(x, nullptr, n, nullptr, y16, y16_lo, lo_fmt, stream);
 }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        int ppc, const float* __restrict__ partial,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu,
-                                                       half_t* __restrict__ y, int ldy, half_t* __restrict__ ylo) {
+                                                       half_t* __restrict__ y, int ldy, void* __restrict__ ylo, int lo_fmt) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // A[C], B[C], then mean[32], rstd[32]
     const int tabw = 2 * C > 24 * GROUPS ? 2 * C : 24 * GROUPS;
     float* sA = sm;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                         h[e] = (half_t)o[e];
                     }
                     *reinterpret_cast<half4v*>(yrow + cv * 4) = h;
-                    if (ylo) *reinterpret_cast<half4v*>(ylo + ((int64_t)f * Npix + pix) * ldy + cv * 4) = lo_plane4(o, h);
+                    if (ylo) store_lo4(ylo, lo_fmt, ((int64_t)f * Npix + pix) * ldy + cv * 4, o, h);
                 }
             }
         }
@@ -184,7 +184,7 @@ template <int T>
 __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restrict__ x, int B, int Npix, int C,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
-                                                          half_t* __restrict__ y, half_t* __restrict__ ylo, int PB) {
+                                                          half_t* __restrict__ y, void* __restrict__ ylo, int lo_fmt, int PB) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [PB][C/2][2] sums, then [PB][32][2] stats
     const int CP = C >> 1, C4 = C >> 2, cpg2 = (C / GROUPS) >> 1;
     float* s_part = sm;                           // PB*CP*2
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restric
                                 silu_f(fmaf(v[it][t][2] - mb, g2, bt[2])), silu_f(fmaf(v[it][t][3] - mb, g3, bt[3]))};
             const half4v h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
             *reinterpret_cast<half4v*>(y + off[it] + (int64_t)t * Npix * C) = h;
-            if (ylo) *reinterpret_cast<half4v*>(ylo + off[it] + (int64_t)t * Npix * C) = lo_plane4(o, h);
+            if (ylo) store_lo4(ylo, lo_fmt, off[it] + (int64_t)t * Npix * C, o, h);
         }
     }
 }
@@ -367,8 +367,9 @@ extern "C" int pnc_groupnorm_stats(const float* x, int ldx, int F, int Npix, int
 extern "C" int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int C,
                                    int pix_per_chunk, const float* partial,
                                    const float* gamma, const float* beta, float eps, int silu,
-                                   void* y16, int ldy, void* y16_lo, void* stream) {
+                                   void* y16, int ldy, void* y16_lo, int lo_fmt, void* stream) {
     if (!x || !partial || !gamma || !beta || !y16 || F < 1 || Npix < 1 || pix_per_chunk < 1) return PNC_EINVAL;
+    if (lo_fmt != PNC_LO_F16 && lo_fmt != PNC_LO_E4M3) return PNC_EINVAL;
     if (C % 64 || C > GN_MAXC || ldx % 4 || ldy % 4) return PNC_EINVAL;
     if (((uintptr_t)x & 15) || (((uintptr_t)y16 | (uintptr_t)y16_lo) & 7)) return PNC_EALIGN;
     const int nchunk = (Npix + pix_per_chunk - 1) / pix_per_chunk;
@@ -376,14 +377,15 @@ extern "C" int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     half_t* y = reinterpret_cast<half_t*>(y16);
     PNC_GN_DISPATCH(gn_apply_kernel, dim3(nchunk, F), dim3(256), lds, st, x, ldx, Npix, C, pix_per_chunk, partial,
-                    gamma, beta, eps, silu, y, ldy, reinterpret_cast<half_t*>(y16_lo));
+                    gamma, beta, eps, silu, y, ldy, y16_lo, lo_fmt);
     return pnc_launch_status();
 }
 
 extern "C" int pnc_groupnorm_temporal_silu(const float* x, int B, int T, int Npix, int C,
                                            const float* gamma, const float* beta, float eps,
-                                           void* y16, void* y16_lo, void* stream) {
+                                           void* y16, void* y16_lo, int lo_fmt, void* stream) {
     if (!x || !gamma || !beta || !y16 || B < 1 || Npix < 1) return PNC_EINVAL;
+    if (lo_fmt != PNC_LO_F16 && lo_fmt != PNC_LO_E4M3) return PNC_EINVAL;
     if (C % 64 || C > 2048 || T < 1 || T > 8) return PNC_EINVAL;     // <= 512 four-channel items per pixel
     if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) return PNC_EALIGN;
     if (((uintptr_t)y16 | (uintptr_t)y16_lo) & 7) return PNC_EALIGN;
@@ -395,7 +397,7 @@ extern "C" int pnc_groupnorm_temporal_silu(const float* x, int B, int T, int Npi
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     half_t* y = reinterpret_cast<half_t*>(y16);
 #define PNC_GNT(TT) case TT: hipLaunchKernelGGL(gn_temporal_kernel<TT>, dim3(blocks), dim3(256), lds, st, \
-                                               x, B, Npix, C, gamma, beta, eps, y, reinterpret_cast<half_t*>(y16_lo), PB); break;
+                                               x, B, Npix, C, gamma, beta, eps, y, y16_lo, lo_fmt, PB); break;
     switch (T) {
         PNC_GNT(1) PNC_GNT(2) PNC_GNT(3) PNC_GNT(4) PNC_GNT(5) PNC_GNT(6) PNC_GNT(7) PNC_GNT(8)
     }

@@ -60,7 +60,11 @@ class Precision:
       gn_res   [ 5 %] GroupNorm+SiLU feeding the ResBlock3D 3x3 convs (the expensive one: doubles the conv3x3 family)
       gnt      [ 3 %] temporal GroupNorm+SiLU feeding the temporal conv1d
       conv_mid [ 2 %] fp16 activations between the layers of the ControlNet hint stem
-    LayerNorm outputs, q/k/v, the GEGLU hidden state and the attention output together are < 4 %: never split."""
+    LayerNorm outputs, q/k/v, the GEGLU hidden state and the attention output together are < 4 %: never split.
+
+    `lo8`: the lo planes of the classes in LO8_CLASSES are stored as OCP e4m3 bytes (PNC_LO_E4M3) instead of fp16 and their
+    consumer GEMMs run the lo K loop on the block-scaled fp8 MFMA against an e4m3 copy of the weights (round 3; half the
+    bytes, twice the MFMA rate of the fp16 lo pass).  |lo| <= |v|, so e4m3 resolves the pair to ~2^-15 of v."""
     stream: bool = False
     gn_stt: bool = False
     ff_out: bool = False
@@ -69,21 +73,35 @@ class Precision:
     gn_res: bool = False
     gnt: bool = False
     conv_mid: bool = False
+    lo8: bool = False
 
     @property
     def name(self) -> str:
-        on = [k for k, v in self.__dict__.items() if v]
-        return "fp16" if not on else "split(" + ",".join(on) + ")"
+        on = [k for k, v in self.__dict__.items() if v and k != "lo8"]
+        return "fp16" if not on else "split(" + ",".join(on) + (")+e4m3-lo" if self.lo8 else ")")
+
+    def lo_dtype(self, cls: str) -> torch.dtype:
+        """dtype of the lo plane of operand class `cls` (= its PNC_LO_* format, panacea_amd.hip.lo_fmt)"""
+        return torch.uint8 if (self.lo8 and cls in LO8_CLASSES) else torch.float16
+
+
+# classes whose consumers all run the e4m3 lo pass: plain-A GEMMs with K % 16 == 0 and the conv gathers with Cin % 64 == 0.
+# Not: `stem` (Cin = 8: a 16-byte chunk of e4m3 would span two taps), `conv_mid` (narrow hint-stem layers), `gn_res` (its
+# stride-1 convs run on the halo-tile kernel, whose lo pass reads fp16 planes).
+LO8_CLASSES = frozenset({"stream", "gn_stt", "ff_out", "gn_head", "gnt"})
 
 
 FAST = Precision()
 # eps max-abs < 1e-3 at BASELINE config 3 (DESIGN.md §6): every class except the ResBlock conv inputs (36 ms of conv3x3
 # for 5 % of the variance) and the hint stem's inner activations (4 ms for 2 %)
-PRECISE = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True, gnt=True)
-PRECISE_ALL = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True, gn_res=True, gnt=True, conv_mid=True)
+PRECISE = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True, gnt=True, lo8=True)
+PRECISE_ALL = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True, gn_res=True, gnt=True, conv_mid=True, lo8=True)
 # without the temporal-conv operand: 6 ms cheaper, ~12 % more error — kept for the cost / error table of DESIGN.md §6
-PRECISE_LITE = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True)
-PRECISIONS = {"fast": FAST, "precise": PRECISE, "precise-all": PRECISE_ALL, "precise-lite": PRECISE_LITE}
+PRECISE_LITE = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True, lo8=True)
+# round 2's form of `precise`: every lo plane fp16, lo pass on the fp16 MFMA (A/B of the e4m3 lo pass)
+PRECISE_F16LO = Precision(stream=True, gn_stt=True, ff_out=True, stem=True, gn_head=True, gnt=True)
+PRECISIONS = {"fast": FAST, "precise": PRECISE, "precise-all": PRECISE_ALL, "precise-lite": PRECISE_LITE,
+              "precise-f16lo": PRECISE_F16LO}
 
 
 def precision(p) -> Precision:
@@ -117,7 +135,7 @@ class Act:
         """fp16 operand copy of the stream (operand class `stream`: the lo plane lands in `f16_lo`)"""
         if self.f16 is None:
             self.f16 = rt.empty((self.M, self.C), torch.float16)
-            self.f16_lo = rt.empty((self.M, self.C), torch.float16) if rt.prec.stream else None
+            self.f16_lo = rt.lo_plane((self.M, self.C), "stream")
             rt.be.cast_f16(self.f32, self.M * self.C, self.f16, self.f16_lo)
         return self.f16
 
@@ -219,6 +237,13 @@ class Runtime:
     def zeros(self, shape, dtype) -> torch.Tensor:
         return torch.zeros(shape, device=self.device, dtype=dtype)
 
+    def lo_plane(self, shape, cls: str, on: bool = True) -> Optional[torch.Tensor]:
+        """lo plane of an operand of class `cls` (None when the policy does not split that class, or `on` is False); its
+        dtype carries the storage format to the kernels"""
+        if not (on and getattr(self.prec, cls)):
+            return None
+        return torch.empty(shape, device=self.device, dtype=self.prec.lo_dtype(cls))
+
     def set_context(self, context: torch.Tensor):
         """context: (B, n_text, D) — tiled over T inside the reference (controlmodel.py:121-122,183-184);
         here every frame of sample b simply reads sample b's keys."""
@@ -249,6 +274,28 @@ def pk_f32(w: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 def pk_linear(w: torch.Tensor) -> torch.Tensor:
     """nn.Linear weight [N, K] is already the W[N][K] operand."""
     return pk_f16(w.reshape(w.shape[0], -1))
+
+
+def pk_lo8(w16: torch.Tensor):
+    """e4m3 copy of a packed fp16 weight matrix [N, K] for the lo pass of a precise operand (PncGemmParams.W_lo):
+    (bytes uint8 [N, K], E8M0 exponent byte e) with W ~ e4m3 * 2^(e - 127); e puts the tensor maximum in [224, 448]."""
+    w = w16.detach().float()
+    amax = float(w.abs().max())
+    sh = 0 if amax == 0.0 else int(math.floor(math.log2(448.0 / amax)))
+    sh = max(-126, min(126, sh))
+    q = (w * (2.0 ** sh)).clamp_(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), 127 - sh
+
+
+def wlo(pk: dict, key, a_lo: Optional[torch.Tensor], w16: Optional[torch.Tensor] = None):
+    """w_lo argument of a GEMM whose A operand has the lo plane `a_lo`: the e4m3 copy of the packed weight pk[key] (or `w16`)
+    when the plane is e4m3 — packed on first use and kept in `pk` next to the fp16 weights — else None"""
+    if a_lo is None or a_lo.dtype != torch.uint8:
+        return None
+    k8 = (key, "lo8")
+    if k8 not in pk:
+        pk[k8] = pk_lo8(pk[key] if w16 is None else w16)
+    return pk[k8]
 
 
 def pk_conv3x3(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
@@ -328,15 +375,16 @@ def _ppc(npix: int) -> int:
 
 
 def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, beta, eps: float, silu: bool,
-               split: bool = False):
-    """-> (y16, y16_lo): y16_lo is None unless `split` (precise operand for the consumer GEMM)."""
+               split: Optional[str] = None):
+    """-> (y16, y16_lo).  `split`: the operand class of the output ("gn_stt" | "gn_res" | "gn_head"); y16_lo is None unless the
+    policy splits that class (precise operand for the consumer GEMM)."""
     if C % 64:
         raise ValueError(f"GroupNorm(32) kernels need C % 64 == 0, got {C}")
     ppc = _ppc(N)
     nchunk = (N + ppc - 1) // ppc
     part = rt.empty((F * nchunk * 32 * 3,), torch.float32)
     y = rt.empty((F * N, C), torch.float16)
-    ylo = rt.empty((F * N, C), torch.float16) if split else None
+    ylo = rt.lo_plane((F * N, C), split) if split else None
     rt.be.groupnorm_stats(x32, C, F, N, C, ppc, part)
     rt.be.groupnorm_apply(x32, C, F, N, C, ppc, part, gamma, beta, eps, silu, y, C, ylo)
     return y, ylo
@@ -346,7 +394,7 @@ def gn_temporal(rt: Runtime, x32: torch.Tensor, N: int, C: int, gamma, beta, eps
     """-> (y16, y16_lo) (operand class `gnt`).  x32 holds ALL T frames of N pixels per sample (the resident layout, or
     the pixel-sharded layout of a FrameShard with N = pixels per rank)."""
     y = rt.empty((rt.B * rt.T * N, C), torch.float16)
-    ylo = rt.empty((rt.B * rt.T * N, C), torch.float16) if rt.prec.gnt else None
+    ylo = rt.lo_plane((rt.B * rt.T * N, C), "gnt")
     rt.be.groupnorm_temporal_silu(x32, rt.B, rt.T, N, C, gamma, beta, eps, y, ylo)
     return y, ylo
 

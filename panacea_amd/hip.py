@@ -20,7 +20,19 @@ HEADER = PKG.parent / "include" / "panacea_hip.h"
 
 A_PLAIN, A_CONV3X3, A_CONV1D_T = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 2          # PNC_ABI_VERSION of include/panacea_hip.h this binding was written against
+ABI_VERSION = 3          # PNC_ABI_VERSION of include/panacea_hip.h this binding was written against
+LO_F16, LO_E4M3 = 0, 1   # PNC_LO_*: storage format of the lo plane of a precise operand
+# dtype of a lo-plane tensor <-> format: an fp16 tensor holds fp16(r), a uint8 tensor OCP e4m3 bytes (one per element)
+LO_DTYPE = {LO_F16: torch.float16, LO_E4M3: torch.uint8}
+
+
+def lo_fmt(t: Optional[torch.Tensor]) -> int:
+    """PNC_LO_* of a lo-plane tensor, from its dtype (None -> PNC_LO_F16, the argument is ignored by the kernels then)"""
+    if t is None or t.dtype == torch.float16:
+        return LO_F16
+    if t.dtype == torch.uint8:
+        return LO_E4M3
+    raise PncError(f"a lo plane is fp16 (PNC_LO_F16) or uint8 e4m3 bytes (PNC_LO_E4M3), got {t.dtype}")
 
 
 class HipLibraryError(RuntimeError):
@@ -52,7 +64,9 @@ class GemmParams(C.Structure):
         ("A_lo", C.c_void_p), ("out16_lo", C.c_void_p),
         ("ldw", C.c_int32), ("ln_eps", C.c_float),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out16", C.c_void_p),
-        ("ldln", C.c_int32), ("reserved1", C.c_int32),
+        ("ldln", C.c_int32), ("a_lo_fmt", C.c_int32),
+        ("out_lo_fmt", C.c_int32), ("ldw_lo", C.c_int32),
+        ("W_lo", C.c_void_p), ("w_lo_exp", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -75,6 +89,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGNATURES = {
     "pnc_version": (C.c_char_p, []),
     "pnc_abi_version": (_I, []),
+    "pnc_build_digest": (C.c_char_p, []),
     "pnc_set_option": (_I, [_I, _I]),
     "pnc_gemm_f16": (_I, [C.POINTER(GemmParams), _P]),
     "pnc_gemm_workspace_floats": (_L, [C.POINTER(GemmParams)]),
@@ -83,17 +98,17 @@ _SIGNATURES = {
     "pnc_softmax_rows_f16": (_I, [_P, _L, _I, _I, _F, _I, _I, _P, _L, _P]),
     "pnc_attn_temporal_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "pnc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
-    "pnc_groupnorm_apply": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P, _P]),
-    "pnc_groupnorm_temporal_silu": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P]),
+    "pnc_groupnorm_apply": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P, _I, _P]),
+    "pnc_groupnorm_temporal_silu": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _I, _P]),
     "pnc_layernorm": (_I, [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P]),
     "pnc_linear_smallm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "pnc_timestep_embedding": (_I, [_P, _I, _I, _P, _P, _P]),
     "pnc_nchw_to_tokens_f16": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     "pnc_cfg_euler_step": (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "pnc_tokens_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    "pnc_concat_add": (_I, [_P, _I, _P, _P, _I, _L, _P, _P, _P, _P]),
-    "pnc_add_f32": (_I, [_P, _P, _L, _P, _P, _P, _P]),
-    "pnc_cast_f16": (_I, [_P, _L, _P, _P, _P]),
+    "pnc_concat_add": (_I, [_P, _I, _P, _P, _I, _L, _P, _P, _P, _I, _P]),
+    "pnc_add_f32": (_I, [_P, _P, _L, _P, _P, _P, _I, _P]),
+    "pnc_cast_f16": (_I, [_P, _L, _P, _P, _I, _P]),
 }
 
 _lib = None
@@ -119,17 +134,22 @@ def load():
         raise HipLibraryError(
             f"{LIB_PATH} is missing: the HIP extension is the only compute path of panacea_amd. "
             "Build it with `python -m panacea_amd.build` (hipcc --offload-arch=gfx950).")
-    if not os.environ.get("PANACEA_HIP_LIB"):
-        # a library older than the sources next to it is an ABI hazard (argument lists change): refuse it, do not guess
-        from . import build as _build
-        stamp = LIB_PATH.parent / "build.stamp"
-        if _build.CSRC.exists() and (not stamp.exists() or stamp.read_text().strip() != _build._digest()):
-            raise HipLibraryError(f"{LIB_PATH} was built from other sources than panacea_amd/csrc holds now; "
-                                  "rebuild it with `python -m panacea_amd.build`")
     try:
         lib = C.CDLL(str(LIB_PATH))
     except OSError as e:  # pragma: no cover
         raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    if not os.environ.get("PANACEA_HIP_LIB"):
+        # a library built from other sources than the ones next to it is an ABI hazard (argument lists change): refuse it, do
+        # not guess.  The digest is compiled INTO the library (pnc_build_digest), so no side file can vouch for a stale build.
+        from . import build as _build
+        try:
+            lib.pnc_build_digest.restype = C.c_char_p
+            have = lib.pnc_build_digest().decode()
+        except AttributeError:
+            have = "(a library older than pnc_build_digest)"
+        if _build.CSRC.exists() and have != _build._digest():
+            raise HipLibraryError(f"{LIB_PATH} was built from other sources ({have[:12]}) than panacea_amd/csrc holds now "
+                                  f"({_build._digest()[:12]}); rebuild it with `python -m panacea_amd.build`")
     for name, (res, args) in _SIGNATURES.items():
         try:
             fn = getattr(lib, name)
@@ -145,6 +165,11 @@ def load():
 
 
 OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA, OPT_GEMM_FUSE_LN, OPT_GEMM_GROUP_M, OPT_STENCIL_TILES = 0, 1, 2, 3, 4, 5, 6
+
+
+def build_digest() -> str:
+    """pnc_build_digest() of the loaded library (what bench.py / tools/pmc_traffic.py stamp their records with)"""
+    return load().pnc_build_digest().decode()
 
 
 def set_option(option: int, value: int) -> int:
@@ -233,14 +258,23 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
          out16t: Optional[torch.Tensor] = None, ldt: int = 0, t_rows: int = 0, t_gstride: int = 0,
          n_split: int = 0, act: int = ACT_NONE, geglu: bool = False,
          a16_lo: Optional[torch.Tensor] = None, out16_lo: Optional[torch.Tensor] = None, w_ld: int = 0,
+         w_lo: Optional[tuple] = None,
          ln_gamma: Optional[torch.Tensor] = None, ln_beta: Optional[torch.Tensor] = None,
          ln_out16: Optional[torch.Tensor] = None, ldln: int = 0, ln_eps: float = 1e-5, ln_in_library: bool = False):
-    """`a16_lo` / `out16_lo`: lo planes of precise (split) operands, see PncGemmParams.A_lo in the header."""
+    """`a16_lo` / `out16_lo`: lo planes of precise (split) operands, see PncGemmParams.A_lo in the header; their dtype names the
+    format (fp16, or uint8 = e4m3 bytes).  `w_lo` = (W_lo e4m3 bytes [N, K], w_lo_exp E8M0 byte of the tensor) — engine.pk_lo8 —
+    is the weight side of an e4m3 lo pass."""
     p = GemmParams()
     p.struct_bytes = C.sizeof(GemmParams)
     f16, f32 = torch.float16, torch.float32
     p.A, p.W = _ptr(a16, f16, "a16"), _ptr(w16, f16, "w16")
-    p.A_lo, p.out16_lo = _ptr(a16_lo, f16, "a16_lo"), _ptr(out16_lo, f16, "out16_lo")
+    p.a_lo_fmt, p.out_lo_fmt = lo_fmt(a16_lo), lo_fmt(out16_lo)
+    p.A_lo, p.out16_lo = _ptr(a16_lo, LO_DTYPE[p.a_lo_fmt], "a16_lo"), _ptr(out16_lo, LO_DTYPE[p.out_lo_fmt], "out16_lo")
+    if p.a_lo_fmt == LO_E4M3:
+        if w_lo is None:
+            raise PncError("an e4m3 lo plane needs the e4m3 copy of the weights (w_lo = engine.pk_lo8(w16))")
+        p.W_lo, p.w_lo_exp = _ptr(w_lo[0], torch.uint8, "w_lo"), int(w_lo[1])
+        p.ldw_lo = w_lo[0].shape[-1]
     p.M, p.N, p.K, p.lda, p.a_mode, p.ldw = M, N, K, lda, a_mode, w_ld
     if ln_out16 is not None:       # LayerNorm of the fp32 output rows, fused into the GEMM where a workgroup owns whole rows
         p.ln_gamma, p.ln_beta, p.ln_out16 = _ptr(ln_gamma, torch.float32, "ln_gamma"), _ptr(ln_beta, torch.float32, "ln_beta"), \
@@ -306,22 +340,27 @@ def attn_temporal(q, ldq, k, ldk, v, ldv, o, ldo, *, B, T, Npix, heads, scale):
                   _ptr(o), ldo, B, T, Npix, heads, scale, _stream()), "pnc_attn_temporal_f16")
 
 
+def _lo_bytes(t) -> float:
+    return 0.0 if t is None else float(t.element_size())
+
+
 def groupnorm_stats(x32, ldx, F, Npix, Cch, ppc, partial):
     _check(_timed("groupnorm", 0.0, 4.0 * F * Npix * Cch, load().pnc_groupnorm_stats, _ptr(x32), ldx, F, Npix, Cch,
                   ppc, _ptr(partial), _stream()), "pnc_groupnorm_stats")
 
 
 def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy, y16_lo=None):
-    nb = (8.0 if y16_lo is not None else 6.0) * F * Npix * Cch
+    nb = (6.0 + _lo_bytes(y16_lo)) * F * Npix * Cch
     _check(_timed("groupnorm", 0.0, nb, load().pnc_groupnorm_apply, _ptr(x32), ldx, F, Npix, Cch,
-                  ppc, _ptr(partial), _ptr(gamma), _ptr(beta), eps, int(silu), _ptr(y16), ldy, _ptr(y16_lo), _stream()),
+                  ppc, _ptr(partial), _ptr(gamma), _ptr(beta), eps, int(silu), _ptr(y16), ldy, _ptr(y16_lo), lo_fmt(y16_lo),
+                  _stream()),
            "pnc_groupnorm_apply")
 
 
 def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16, y16_lo=None):
-    nb = (8.0 if y16_lo is not None else 6.0) * B * T * Npix * Cch
+    nb = (6.0 + _lo_bytes(y16_lo)) * B * T * Npix * Cch
     _check(_timed("groupnorm_temporal", 0.0, nb, load().pnc_groupnorm_temporal_silu,
-                  _ptr(x32), B, T, Npix, Cch, _ptr(gamma), _ptr(beta), eps, _ptr(y16), _ptr(y16_lo), _stream()),
+                  _ptr(x32), B, T, Npix, Cch, _ptr(gamma), _ptr(beta), eps, _ptr(y16), _ptr(y16_lo), lo_fmt(y16_lo), _stream()),
            "pnc_groupnorm_temporal_silu")
 
 
@@ -359,15 +398,15 @@ def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):
 
 
 def concat_add(a32, C1, s32, c32, C2, M, out32, out16, out16_lo=None):
-    nb = M * (4.0 * C1 + (8.0 if c32 is not None else 4.0) * C2 + (8.0 if out16_lo is not None else 6.0) * (C1 + C2))
+    nb = M * (4.0 * C1 + (8.0 if c32 is not None else 4.0) * C2 + (6.0 + _lo_bytes(out16_lo)) * (C1 + C2))
     _check(_timed("elementwise", 0.0, nb, load().pnc_concat_add, _ptr(a32), C1, _ptr(s32), _ptr(c32), C2, M,
-                  _ptr(out32), _ptr(out16), _ptr(out16_lo), _stream()), "pnc_concat_add")
+                  _ptr(out32), _ptr(out16), _ptr(out16_lo), lo_fmt(out16_lo), _stream()), "pnc_concat_add")
 
 
 def add_f32(x32, a32, n, y32, y16, y16_lo=None):
     _check(_timed("elementwise", 0.0, 12.0 * n, load().pnc_add_f32, _ptr(x32), _ptr(a32), n, _ptr(y32), _ptr(y16),
-                  _ptr(y16_lo), _stream()), "pnc_add_f32")
+                  _ptr(y16_lo), lo_fmt(y16_lo), _stream()), "pnc_add_f32")
 
 
 def cast_f16(x32, n, y16, y16_lo=None):
-    _check(load().pnc_cast_f16(_ptr(x32), n, _ptr(y16), _ptr(y16_lo), _stream()), "pnc_cast_f16")
+    _check(load().pnc_cast_f16(_ptr(x32), n, _ptr(y16), _ptr(y16_lo), lo_fmt(y16_lo), _stream()), "pnc_cast_f16")

@@ -286,7 +286,7 @@ class BasicTransformerBlock(nn.Module, Packable):
         x16 = self.attn2._run_text(rt, x16, F, H, W, t32, t32, ln=ln3)
         if last:
             out16 = rt.empty((M, C), torch.float16)
-            out16lo = rt.empty((M, C), torch.float16) if rt.prec.ff_out else None
+            out16lo = rt.lo_plane((M, C), "ff_out")
             self.ff._run(rt, x16, M, t32, out32=None, out16=out16, out16_lo=out16lo)
             return out16, out16lo
         self.ff._run(rt, x16, M, t32, out32=t32)
@@ -362,7 +362,7 @@ class SpatialTemporalTransformer(nn.Module, Packable):
         pk = self.packed()
         C, M = x.C, x.M
         n16, n16lo = E.gn_spatial(rt, x.f32, x.F, x.N, C, pk["g" + sfx], pk["b" + sfx], 1e-6, False,
-                                  split=rt.prec.gn_stt)
+                                  split="gn_stt")
         sh = rt.shard if branch == "temporal" else None
         if sh is not None:
             # Frame-sharded run: the temporal branch is pointwise per pixel (LN, projections, text cross-attention, FF) or
@@ -379,10 +379,10 @@ class SpatialTemporalTransformer(nn.Module, Packable):
         if branch == "temporal":
             # + position table indexed by t = frame % T (attention.py:1117-1118)
             rt.be.gemm(n16, pk["wi" + sfx], M=Mb, N=C, K=C, lda=C, bias=pk["bi" + sfx], rowbias=pk["pos"],
-                       rb_rows=Hb * Wb, rb_mod=rt.T, out32=t32, ldc32=C, a16_lo=n16lo, **lnkw)
+                       rb_rows=Hb * Wb, rb_mod=rt.T, out32=t32, ldc32=C, a16_lo=n16lo, w_lo=E.wlo(pk, "wi" + sfx, n16lo), **lnkw)
         else:
             rt.be.gemm(n16, pk["wi" + sfx], M=Mb, N=C, K=C, lda=C, bias=pk["bi" + sfx], out32=t32, ldc32=C,
-                       a16_lo=n16lo, **lnkw)
+                       a16_lo=n16lo, w_lo=E.wlo(pk, "wi" + sfx, n16lo), **lnkw)
         p16 = p16lo = None
         for i, blk in enumerate(blocks):
             r = blk._run(rt, t32, Fb, Hb, Wb, branch, last=(i == len(blocks) - 1), x16=x16 if i == 0 else None)
@@ -393,7 +393,8 @@ class SpatialTemporalTransformer(nn.Module, Packable):
             p16lo = sh.to_frames(p16lo, rt.B, x.N) if p16lo is not None else None
         # x = proj_out(t) + x_in, in place on the stream
         rt.be.gemm(p16, pk["wo" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bo" + sfx], res1=x.f32, ldr1=C,
-                   out32=x.f32, ldc32=C, out16=out16, ldc16=C, a16_lo=p16lo, out16_lo=out16_lo)
+                   out32=x.f32, ldc32=C, out16=out16, ldc16=C, a16_lo=p16lo, out16_lo=out16_lo,
+                   w_lo=E.wlo(pk, "wo" + sfx, p16lo))
 
     def _run(self, rt: Runtime, x: Act, want_f16: bool = False) -> Act:
         if rt.T != self.num_frames:
@@ -402,7 +403,7 @@ class SpatialTemporalTransformer(nn.Module, Packable):
         if self.insert_crossview:
             self._branch(rt, x, "_crossview", self.transformer_blocks_crossview, "crossview")
         out16 = rt.empty((x.M, x.C), torch.float16) if want_f16 else None
-        out16lo = rt.empty((x.M, x.C), torch.float16) if (want_f16 and rt.prec.stream) else None
+        out16lo = rt.lo_plane((x.M, x.C), "stream", on=want_f16)
         self._branch(rt, x, "_temporal", self.transformer_blocks_temporal, "temporal", out16=out16, out16_lo=out16lo)
         return Act(x.F, x.H, x.W, x.C, f32=x.f32, f16=out16, f16_lo=out16lo)
 

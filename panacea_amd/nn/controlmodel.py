@@ -84,13 +84,13 @@ class ControlNet3D(UNetModel3D):
         F, C, H, W = hint.shape
         cp = (C + 7) // 8 * 8
         t16 = rt.empty((F * H * W, cp), torch.float16)
-        t16lo = rt.empty((F * H * W, cp), torch.float16) if rt.prec.conv_mid else None
+        t16lo = rt.lo_plane((F * H * W, cp), "conv_mid")
         rt.be.nchw_to_tokens_f16(hint.detach().to(torch.float32).contiguous(), C, None, 0, F, H * W, cp, t16, t16lo)
         a = Act(F, H, W, cp, f16=t16, f16_lo=t16lo)
         for i, ((w, b), s) in enumerate(zip(pk["hint"], HINT_STRIDES)):
             last = i == len(HINT_STRIDES) - 1
             a = run_conv3x3(rt, a.f16, a.F, a.H, a.W, a.C, w, b, w.shape[0], stride=s, act_silu=not last,
-                            out32=last, out16=not last, x16_lo=a.f16_lo, split_out=rt.prec.conv_mid)
+                            out32=last, out16=not last, x16_lo=a.f16_lo, split_out="conv_mid")
         return a
 
     def _run_control(self, rt: Runtime, x16: Act, hint: torch.Tensor, emb32: torch.Tensor) -> List[Act]:
@@ -98,7 +98,7 @@ class ControlNet3D(UNetModel3D):
         self._project_text(rt)
         guided = rt.guided if rt.guided is not None else self._hint_stem(rt, hint)
         outs, h = [], x16
-        for i, (module, (zw, zb)) in enumerate(zip(self.input_blocks, pk["zero"])):
+        for i, module in enumerate(self.input_blocks):
             h = module._run(rt, h, emb32, want_f16=(i != 0))
             if rt.trace is not None:
                 rt.trace[f"controlnet.input_blocks.{i}"] = h.to_nchw()
@@ -107,20 +107,22 @@ class ControlNet3D(UNetModel3D):
                     raise ValueError(f"hint stem output {guided.H}x{guided.W}x{guided.C} does not match the latent "
                                      f"{h.H}x{h.W}x{h.C} (the hint must be 8x the latent resolution)")
                 h.f16 = rt.empty((h.M, h.C), torch.float16)
-                h.f16_lo = rt.empty((h.M, h.C), torch.float16) if rt.prec.stream else None
+                h.f16_lo = rt.lo_plane((h.M, h.C), "stream")
                 rt.be.add_f32(h.f32, guided.f32, h.M * h.C, h.f32, h.f16, h.f16_lo)   # h += guided_hint
-            outs.append(self._zero_conv(rt, h, zw, zb))
+            outs.append(self._zero_conv(rt, h, pk, i))
         h = self.middle_block._run(rt, h, emb32, want_f16=True)
         if rt.trace is not None:
             rt.trace["controlnet.middle_block"] = h.to_nchw()
-        zw, zb = pk["zero"][-1]
-        outs.append(self._zero_conv(rt, h, zw, zb))
+        outs.append(self._zero_conv(rt, h, pk, len(pk["zero"]) - 1))
         return outs
 
     @staticmethod
-    def _zero_conv(rt: Runtime, h: Act, w16, b) -> Act:
+    def _zero_conv(rt: Runtime, h: Act, pk: dict, idx: int) -> Act:
+        w16, b = pk["zero"][idx]
         o = rt.empty((h.M, h.C), torch.float32)
-        rt.be.gemm(h.need_f16(rt), w16, M=h.M, N=h.C, K=h.C, lda=h.C, bias=b, out32=o, ldc32=h.C, a16_lo=h.f16_lo)
+        x16 = h.need_f16(rt)
+        rt.be.gemm(x16, w16, M=h.M, N=h.C, K=h.C, lda=h.C, bias=b, out32=o, ldc32=h.C, a16_lo=h.f16_lo,
+                   w_lo=E.wlo(pk, ("zero", idx), h.f16_lo, w16))
         return Act(h.F, h.H, h.W, h.C, f32=o)
 
     def forward(self, x, hint, timesteps=None, context=None, y=None, **kwargs):

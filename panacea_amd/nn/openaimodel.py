@@ -46,9 +46,10 @@ def conv_params(conv: nn.Conv2d):
 
 def run_conv3x3(rt: Runtime, x16: torch.Tensor, F: int, Hin: int, Win: int, Cin_pad: int, w16, bias, Cout: int,
                 stride: int = 1, upsample: bool = False, act_silu: bool = False, out32: bool = True,
-                out16: bool = False, x16_lo: Optional[torch.Tensor] = None, split_out: bool = False):
+                out16: bool = False, x16_lo: Optional[torch.Tensor] = None, split_out: Optional[str] = None, w_lo=None):
     """3x3 conv (pad 1) as implicit GEMM over the channels-last fp16 image x16 [F*Hin*Win, Cin_pad] (+ lo plane of a
-    precise operand); `split_out`: the fp16 output is written as a precise pair."""
+    precise operand, + `w_lo` = engine.wlo(...) when that plane is e4m3); `split_out`: operand class of the fp16 output, which
+    is written as a precise pair when the policy splits that class."""
     if upsample:
         Hout, Wout = 2 * Hin, 2 * Win
     else:
@@ -56,8 +57,8 @@ def run_conv3x3(rt: Runtime, x16: torch.Tensor, F: int, Hin: int, Win: int, Cin_
     M = F * Hout * Wout
     o32 = rt.empty((M, Cout), torch.float32) if out32 else None
     o16 = rt.empty((M, Cout), torch.float16) if out16 else None
-    o16lo = rt.empty((M, Cout), torch.float16) if (out16 and split_out) else None
-    rt.be.gemm(x16, w16, M=M, N=Cout, K=9 * Cin_pad, a_mode=E._hip.A_CONV3X3,
+    o16lo = rt.lo_plane((M, Cout), split_out, on=out16) if split_out else None
+    rt.be.gemm(x16, w16, M=M, N=Cout, K=9 * Cin_pad, a_mode=E._hip.A_CONV3X3, w_lo=w_lo,
                conv=dict(Cin=Cin_pad, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride, upsample=int(upsample)),
                bias=bias, act=E._hip.ACT_SILU if act_silu else E._hip.ACT_NONE,
                out32=o32, ldc32=Cout, out16=o16, ldc16=Cout, a16_lo=x16_lo, out16_lo=o16lo)
@@ -86,17 +87,20 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock, Packable):
             elif isinstance(layer, (Upsample, Downsample)):
                 x = layer._run(rt, x, want_f16=wf)
             elif isinstance(layer, nn.Conv2d):
-                w16, b = self.packed()[i]
+                pk = self.packed()
+                w16, b = pk[i]
+                x16 = x.need_f16(rt)
+                w_lo = E.wlo(pk, i, x.f16_lo, w16)
                 if layer.kernel_size[0] == 3:
-                    x = run_conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, w16, b, layer.out_channels,
-                                    stride=layer.stride[0], out16=wf, x16_lo=x.f16_lo, split_out=rt.prec.stream)
+                    x = run_conv3x3(rt, x16, x.F, x.H, x.W, x.C, w16, b, layer.out_channels,
+                                    stride=layer.stride[0], out16=wf, x16_lo=x.f16_lo, split_out="stream", w_lo=w_lo)
                 else:
                     o32 = rt.empty((x.M, layer.out_channels), torch.float32)
                     o16 = rt.empty((x.M, layer.out_channels), torch.float16) if wf else None
-                    o16lo = rt.empty((x.M, layer.out_channels), torch.float16) if (wf and rt.prec.stream) else None
-                    rt.be.gemm(x.need_f16(rt), w16, M=x.M, N=layer.out_channels, K=x.C, lda=x.C, bias=b,
+                    o16lo = rt.lo_plane((x.M, layer.out_channels), "stream", on=wf)
+                    rt.be.gemm(x16, w16, M=x.M, N=layer.out_channels, K=x.C, lda=x.C, bias=b,
                                out32=o32, ldc32=layer.out_channels, out16=o16, ldc16=layer.out_channels,
-                               a16_lo=x.f16_lo, out16_lo=o16lo)
+                               a16_lo=x.f16_lo, out16_lo=o16lo, w_lo=w_lo)
                     x = Act(x.F, x.H, x.W, layer.out_channels, f32=o32, f16=o16, f16_lo=o16lo)
             else:
                 raise NotImplementedError(f"{type(layer).__name__} inside TimestepEmbedSequential")
@@ -120,8 +124,9 @@ class Upsample(nn.Module, Packable):
 
     def _run(self, rt: Runtime, x: Act, want_f16=False) -> Act:
         pk = self.packed()
-        return run_conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, pk["w"], pk["b"], self.out_channels,
-                           upsample=True, out16=want_f16, x16_lo=x.f16_lo, split_out=rt.prec.stream)
+        x16 = x.need_f16(rt)
+        return run_conv3x3(rt, x16, x.F, x.H, x.W, x.C, pk["w"], pk["b"], self.out_channels,
+                           upsample=True, out16=want_f16, x16_lo=x.f16_lo, split_out="stream", w_lo=E.wlo(pk, "w", x.f16_lo))
 
 
 class Downsample(nn.Module, Packable):
@@ -141,8 +146,9 @@ class Downsample(nn.Module, Packable):
 
     def _run(self, rt: Runtime, x: Act, want_f16=False) -> Act:
         pk = self.packed()
-        return run_conv3x3(rt, x.need_f16(rt), x.F, x.H, x.W, x.C, pk["w"], pk["b"], self.out_channels,
-                           stride=2, out16=want_f16, x16_lo=x.f16_lo, split_out=rt.prec.stream)
+        x16 = x.need_f16(rt)
+        return run_conv3x3(rt, x16, x.F, x.H, x.W, x.C, pk["w"], pk["b"], self.out_channels,
+                           stride=2, out16=want_f16, x16_lo=x.f16_lo, split_out="stream", w_lo=E.wlo(pk, "w", x.f16_lo))
 
 
 class ResBlock3D(TimestepBlock, Packable):
@@ -207,7 +213,7 @@ class ResBlock3D(TimestepBlock, Packable):
         Mt = rt.B * rt.T * Nt
         tconv = dict(C=Co, T=rt.T, Npix=Nt)
         # in_layers: GN + SiLU + conv3x3
-        a16, a16lo = E.gn_spatial(rt, x.f32, F, N, Cin, pk["g1"], pk["b1"], 1e-5, True, split=rt.prec.gn_res)
+        a16, a16lo = E.gn_spatial(rt, x.f32, F, N, Cin, pk["g1"], pk["b1"], 1e-5, True, split="gn_res")
         h = run_conv3x3(rt, a16, F, H, W, Cin, pk["w1"], pk["c1"], Co, x16_lo=a16lo).f32
         # h = h + conv1d_t(SiLU(GN_t(h))) + emb_layers(emb)[frame]      (:505-531)
         # emb32 arrives as SiLU(emb): the activation of `emb_layers` is applied ONCE per network evaluation by
@@ -219,33 +225,35 @@ class ResBlock3D(TimestepBlock, Packable):
             emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
         t16, t16lo = E.gn_temporal(rt, h, Nt, Co, pk["gt1"], pk["bt1"], 1e-5)
         rt.be.gemm(t16, pk["wt1"], M=Mt, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct1"],
-                   rowbias=emb_out, rb_rows=Nt, rb_mod=rt.B * rt.T, res1=h, ldr1=Co, out32=h, ldc32=Co, a16_lo=t16lo)
+                   rowbias=emb_out, rb_rows=Nt, rb_mod=rt.B * rt.T, res1=h, ldr1=Co, out32=h, ldc32=Co, a16_lo=t16lo,
+                   w_lo=E.wlo(pk, "wt1", t16lo))
         if sh is not None:
             h = sh.to_frames(h, rt.B, N)
         # out_layers: GN + SiLU + conv3x3
-        a16, a16lo = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True, split=rt.prec.gn_res)
+        a16, a16lo = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True, split="gn_res")
         g = run_conv3x3(rt, a16, F, H, W, Co, pk["w2"], pk["c2"], Co, x16_lo=a16lo).f32
         # skip path
         if "ws" in pk:
             s = rt.empty((M, Co), torch.float32)
-            rt.be.gemm(x.need_f16(rt), pk["ws"], M=M, N=Co, K=Cin, lda=Cin, bias=pk["bs"], out32=s, ldc32=Co,
-                       a16_lo=x.f16_lo)
+            x16 = x.need_f16(rt)
+            rt.be.gemm(x16, pk["ws"], M=M, N=Co, K=Cin, lda=Cin, bias=pk["bs"], out32=s, ldc32=Co,
+                       a16_lo=x.f16_lo, w_lo=E.wlo(pk, "ws", x.f16_lo))
         else:
             s = x.f32
         # return skip(x) + (g + conv1d_t(SiLU(GN_t(g))))                 (:533-542)
         o16 = rt.empty((M, Co), torch.float16) if want_f16 else None
-        o16lo = rt.empty((M, Co), torch.float16) if (want_f16 and rt.prec.stream) else None
+        o16lo = rt.lo_plane((M, Co), "stream", on=want_f16)
         if sh is None:
             t16, t16lo = E.gn_temporal(rt, g, N, Co, pk["gt2"], pk["bt2"], 1e-5)
             rt.be.gemm(t16, pk["wt2"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct2"],
                        res1=g, ldr1=Co, res2=s, ldr2=Co, out32=g, ldc32=Co, out16=o16, ldc16=Co, a16_lo=t16lo,
-                       out16_lo=o16lo)
+                       out16_lo=o16lo, w_lo=E.wlo(pk, "wt2", t16lo))
         else:
             # the skip path stays in the frame layout: g + conv1d in the pixel layout, exchange back, then + skip
             gp = sh.to_pixels(g, rt.B, N)
             t16, t16lo = E.gn_temporal(rt, gp, Nt, Co, pk["gt2"], pk["bt2"], 1e-5)
             rt.be.gemm(t16, pk["wt2"], M=Mt, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct2"],
-                       res1=gp, ldr1=Co, out32=gp, ldc32=Co, a16_lo=t16lo)
+                       res1=gp, ldr1=Co, out32=gp, ldc32=Co, a16_lo=t16lo, w_lo=E.wlo(pk, "wt2", t16lo))
             g = sh.to_frames(gp, rt.B, N)
             rt.be.add_f32(g, s, M * Co, g, o16, o16lo)
         return Act(F, H, W, Co, f32=g, f16=o16, f16_lo=o16lo)
@@ -424,8 +432,9 @@ class UNetModel3D(nn.Module, Packable):
         """self.out: GN + SiLU + conv3x3 -> NCHW fp32 (:1245-1253, controlmodel.py:197-202); `tokens`: the channels-last
         fp32 tokens instead (consumed by the fused sampler-step exit, pnc_cfg_euler_step)."""
         pk = self.packed()
-        a16, a16lo = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, pk["og"], pk["ob"], 1e-5, True, split=rt.prec.gn_head)
-        o = run_conv3x3(rt, a16, h.F, h.H, h.W, h.C, pk["ow"], pk["oc"], self.out_channels, x16_lo=a16lo)
+        a16, a16lo = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, pk["og"], pk["ob"], 1e-5, True, split="gn_head")
+        o = run_conv3x3(rt, a16, h.F, h.H, h.W, h.C, pk["ow"], pk["oc"], self.out_channels, x16_lo=a16lo,
+                        w_lo=E.wlo(pk, "ow", a16lo))
         if tokens:
             return o
         out = rt.empty((h.F, self.out_channels, h.H, h.W), torch.float32)
@@ -444,7 +453,7 @@ class UNetModel3D(nn.Module, Packable):
         x32 = x.detach().to(torch.float32).contiguous()
         b32 = None if concat is None else concat.detach().to(torch.float32).contiguous()
         t16 = rt.empty((F * H * W, cp), torch.float16)
-        t16lo = rt.empty((F * H * W, cp), torch.float16) if rt.prec.stem else None
+        t16lo = rt.lo_plane((F * H * W, cp), "stem")
         rt.be.nchw_to_tokens_f16(x32, C, b32, C2, F, H * W, cp, t16, t16lo, a_scale=scale, a_frames=Fx)
         return Act(F, H, W, cp, f16=t16, f16_lo=t16lo)
 
@@ -481,7 +490,7 @@ class UNetModel3D(nn.Module, Packable):
             ct = h.C + s.C
             cat32 = rt.empty((h.M, ct), torch.float32)
             cat16 = rt.empty((h.M, ct), torch.float16)
-            cat16lo = rt.empty((h.M, ct), torch.float16) if rt.prec.stream else None
+            cat16lo = rt.lo_plane((h.M, ct), "stream")
             # th.cat([h, hs.pop() + control.pop()], dim=1): one pass, fp32 stream + fp16 operand (of the skip 1x1 conv)
             rt.be.concat_add(h.f32, h.C, s.f32, None if c is None else c.f32, s.C, h.M, cat32, cat16, cat16lo)
             h = module._run(rt, Act(h.F, h.H, h.W, ct, f32=cat32, f16=cat16, f16_lo=cat16lo), emb32)

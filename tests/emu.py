@@ -33,13 +33,22 @@ STRICT_DTYPES = True
 LO_SCALE = 2048.0
 
 
-def _lo(v: torch.Tensor, hi: torch.Tensor) -> torch.Tensor:
-    """lo plane of a precise (split) operand: fp16((v - hi) * 2^11), exactly like the kernels"""
-    return ((v.float() - hi.float()) * LO_SCALE).half()
+def _lo(v: torch.Tensor, hi: torch.Tensor, like: torch.Tensor = None) -> torch.Tensor:
+    """lo plane of a precise (split) operand, exactly like the kernels: fp16((v - hi) * 2^11), or — when the destination `like`
+    is a uint8 tensor (PNC_LO_E4M3) — the OCP e4m3 byte of the same residual clamped to +-448"""
+    r = (v.float() - hi.float()) * LO_SCALE
+    if like is not None and like.dtype == torch.uint8:
+        return r.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    return r.half()
+
+
+def _lo_value(lo: torch.Tensor) -> torch.Tensor:
+    """fp32 value of a lo plane in either storage format"""
+    return lo.view(torch.float8_e4m3fn).float() if lo.dtype == torch.uint8 else lo.float()
 
 
 def _join(hi: torch.Tensor, lo) -> torch.Tensor:
-    return hi.float() if lo is None else hi.float() + lo.float() / LO_SCALE
+    return hi.float() if lo is None else hi.float() + _lo_value(lo) / LO_SCALE
 
 
 # ---- MX block-scaled fp8 lo plane (DESIGN.md section 12.5: the format of the NEXT round's lo pass; nothing in the library
@@ -122,13 +131,25 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
          rb_rows=0, rb_mod=0, res1=None, ldr1=0, res2=None, ldr2=0, out32=None, ldc32=0, out16=None,
          ldc16=0, out16t=None, ldt=0, t_rows=0, t_gstride=0, n_split=0, act=ACT_NONE, geglu=False,
          a16_lo=None, out16_lo=None, w_ld=0, ln_gamma=None, ln_beta=None, ln_out16=None, ldln=0, ln_eps=1e-5,
-         ln_in_library=False):
+         ln_in_library=False, w_lo=None):
     assert (not STRICT_DTYPES) or (a16.dtype == torch.float16 and w16.dtype == torch.float16)
     assert K % 8 == 0
     Wm = _mat(w16, N, K, w_ld or K).float()
-    if a16_lo is not None:       # precise operand: A = hi + lo * 2^-11 (the kernel sums the two planes' products in fp32)
+    acc_lo = None
+    if a16_lo is not None and a16_lo.dtype == torch.uint8:
+        # e4m3 lo plane: its pass runs against the e4m3 copy of the weights (engine.pk_lo8), products weighted 2^-11
+        if w_lo is None:
+            raise PncError("an e4m3 lo plane needs the e4m3 copy of the weights (w_lo)")
+        cin = lda if a_mode == A_PLAIN else (conv["Cin"] if a_mode == A_CONV3X3 else tconv["C"])
+        if K % 16 or cin % (16 if a_mode == A_PLAIN else 64):      # the library's PNC_EALIGN
+            raise PncError("e4m3 lo pass: K % 16 == 0 and lda % 16 == 0 (plain) / Cin % 64 == 0 (conv gathers)")
+        Wl = _mat(w_lo[0], N, K, w_lo[0].shape[-1]).view(torch.float8_e4m3fn).float() * (2.0 ** (int(w_lo[1]) - 127))
+        acc_lo = _contract(_lo_value(a16_lo.reshape(-1)[: a16.numel()]), Wl, M, N, K, lda, a_mode, conv, tconv) / LO_SCALE
+    elif a16_lo is not None:     # fp16 lo plane: A = hi + lo * 2^-11 (the kernel sums the two planes' products in fp32)
         a16 = _join(a16.reshape(-1), a16_lo.reshape(-1)[: a16.numel()])
     acc = _contract(a16, Wm, M, N, K, lda, a_mode, conv, tconv)
+    if acc_lo is not None:
+        acc = acc + acc_lo
     if ACC_HOOK is not None:     # numerics experiments (tools/exp/error_budget.py): e.g. the weight side of an MX lo pass
         acc = ACC_HOOK(acc, a16, Wm, dict(M=M, N=N, K=K, lda=lda, a_mode=a_mode, conv=conv, tconv=tconv))
     v = acc
@@ -144,7 +165,7 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
             h = r16(v, 'gemm.geglu')
             _mat(out16, M, N // 2, ldc16).copy_(h)
             if out16_lo is not None:
-                _mat(out16_lo, M, N // 2, ldc16).copy_(_lo(v, h))
+                _mat(out16_lo, M, N // 2, ldc16).copy_(_lo(v, h, out16_lo))
         return
     if rowbias is not None:
         idx = (torch.arange(M, device=v.device) // rb_rows) % rb_mod
@@ -164,7 +185,7 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
         h = r16(v[:, :ns], 'gemm.out16')
         _mat(out16, M, ns, ldc16).copy_(h)
         if out16_lo is not None:
-            _mat(out16_lo, M, ns, ldc16).copy_(_lo(v[:, :ns], h))
+            _mat(out16_lo, M, ns, ldc16).copy_(_lo(v[:, :ns], h, out16_lo))
     if ln_out16 is not None:
         assert out32 is not None and out16t is None
         layernorm(out32, ldc32, M, N, ln_gamma, ln_beta, ln_eps, ln_out16, ldln)
@@ -254,7 +275,7 @@ def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu
     h = r16(y, 'groupnorm_apply')
     _mat(y16, F * Npix, Cch, ldy).copy_(h)
     if y16_lo is not None:
-        _mat(y16_lo, F * Npix, Cch, ldy).copy_(_lo(y, h))
+        _mat(y16_lo, F * Npix, Cch, ldy).copy_(_lo(y, h, y16_lo))
 
 
 def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16, y16_lo=None):
@@ -264,7 +285,7 @@ def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16, y16_lo=
     h = r16(y, 'groupnorm_temporal')
     y16.reshape(-1)[: y.numel()].copy_(h)
     if y16_lo is not None:
-        y16_lo.reshape(-1)[: y.numel()].copy_(_lo(y, h))
+        y16_lo.reshape(-1)[: y.numel()].copy_(_lo(y, h, y16_lo))
 
 
 def layernorm(x32, ldx, M, Cch, gamma, beta, eps, y16, ldy, y16_lo=None):
@@ -273,7 +294,7 @@ def layernorm(x32, ldx, M, Cch, gamma, beta, eps, y16, ldy, y16_lo=None):
     h = r16(y, 'layernorm')
     _mat(y16, M, Cch, ldy).copy_(h)
     if y16_lo is not None:
-        _mat(y16_lo, M, Cch, ldy).copy_(_lo(y, h))
+        _mat(y16_lo, M, Cch, ldy).copy_(_lo(y, h, y16_lo))
 
 
 def linear_smallm(a32, lda, w16, bias, out32, ldo, M, N, K, silu_in=False, silu_out=False):
@@ -337,7 +358,7 @@ def concat_add(a32, C1, s32, c32, C2, M, out32, out16, out16_lo=None):
         h = r16(y.reshape(-1), 'concat_add')
         out16.reshape(-1)[: y.numel()].copy_(h)
         if out16_lo is not None:
-            out16_lo.reshape(-1)[: y.numel()].copy_(_lo(y.reshape(-1), h))
+            out16_lo.reshape(-1)[: y.numel()].copy_(_lo(y.reshape(-1), h, out16_lo))
 
 
 def add_f32(x32, a32, n, y32, y16, y16_lo=None):
@@ -348,7 +369,7 @@ def add_f32(x32, a32, n, y32, y16, y16_lo=None):
         h = r16(y, 'add_f32')
         y16.reshape(-1)[:n].copy_(h)
         if y16_lo is not None:
-            y16_lo.reshape(-1)[:n].copy_(_lo(y, h))
+            y16_lo.reshape(-1)[:n].copy_(_lo(y, h, y16_lo))
     if y32 is not None and (a32 is not None or y32.data_ptr() != x32.data_ptr()):
         y32.reshape(-1)[:n].copy_(y)
 

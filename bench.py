@@ -13,8 +13,12 @@ per view (latent (8, 4, 32, 384), BEV hint (8, 19, 256, 3072)), classifier-free 
 Inputs are resident in HBM before the timed region; nothing is cached across steps (hint stem and text K/V
 are recomputed every step, like the reference).
 
-N > 1: one process per GPU, one independent sample per rank (the reference's own multi-GPU strategy,
-inference.py:248-280 — replicas, no collective on the data path), hence "scaling": "weak".
+N > 1: one process per GPU.  Without torchrun's environment `--gpus N` SPAWNS the N ranks itself (this process becomes the
+launcher; rank 0 prints the line), so `python bench.py --gpus 8` is a complete command.  The headline is the reference's own
+multi-GPU strategy — one independent sample per rank (inference.py:248-280: replicas, no collective on the data path), hence
+"scaling": "weak" — and, with the default `--parallelism auto`, the same line carries under "strong_scaling" the
+per-sample-latency mode (one sample over 2 CFG halves x up to 4 frame groups, RCCL all-to-all at the temporal sites) measured
+in the same run: RCCL rank count, exchanges and bytes sent per rank and step.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the whole step against the dense fp16 MFMA peak using the
 ALGORITHMIC 96.59 TFLOP/step of SURVEY.md §8(d); `roofline.kernels` is a per-kernel-family breakdown from a
@@ -110,6 +114,7 @@ def run_vae_decode(args, dev):
     from panacea_amd import hip, synth
     from panacea_amd.nn import model
     hip.load()
+    sync = torch.cuda.synchronize
     enc = args.stage == "vae-encode"
     fs = model.FirstStageEncoder(4, VAE_FULL) if enc else model.FirstStageDecoder(4, VAE_FULL)
     man = {k: list(v.shape) for k, v in fs.state_dict().items()}
@@ -125,11 +130,11 @@ def run_vae_decode(args, dev):
     with torch.no_grad():
         for _ in range(max(1, args.warmup)):
             img = run(z)
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             img = run(z)
-        torch.cuda.synchronize()
+        sync()
         dt = (time.perf_counter() - t0) / args.steps
         assert img.shape == oshape and torch.isfinite(img).all()
         prof = hip.Profiler()
@@ -178,6 +183,94 @@ def run_vae_decode(args, dev):
     print(json.dumps(out), flush=True)
 
 
+def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, g_salt, den) -> dict:
+    """The per-sample-latency mode of SURVEY section 8(e) timed in the same process group as the headline: ONE sample over
+    2 CFG halves x G frame groups (`ShardedCFG` + `engine.FrameShard`), same steps and warm-up.  Returns the record that goes
+    under "strong_scaling" (value = samples advanced per second x steps, i.e. steps/s of the job; per_sample_latency_ms)."""
+    from panacea_amd import parallel, sampling
+    import torch.distributed as dist
+    T, (h, w) = kw["num_frames"], hw
+    layout = parallel.layout_for(world, rank, parallelism)
+    groups = parallel.Groups(layout)
+    # every rank of a sample starts from the SAMPLE's inputs (salt = sample index; the synthetic generator is deterministic):
+    # `g` was drawn for this rank's sample of the headline layout, which is another sample for most ranks
+    if layout.sample != g_salt:
+        from panacea_amd import synth
+        g = {k: v.to(dev) for k, v in synth.synth_inputs(2, T, h, w, context_dim=kw["context_dim"], salt=layout.sample).items()}
+    cond = {"crossattn": g["crossattn"][1:2], "concat": g["concat"][T:], "cond_feat": g["cond_feat"][T:]}
+    uc = {"crossattn": g["crossattn"][0:1], "concat": g["concat"][:T], "cond_feat": g["cond_feat"][:T]}
+    guider = groups.guider(5.0)
+    smp = sampling.EulerEDMSampler(args.num_sampling_steps, guider=guider, device=dev)
+    smp.fuse = not args.no_fused_step
+    shard = groups.frame_shard()
+    parallel.apply_frame_shard(net, shard)
+    try:
+        if shard is not None:
+            cond, uc = parallel.shard_conditioning(cond, layout, T), parallel.shard_conditioning(uc, layout, T)
+        sig = smp.sigmas()
+        nsig = len(sig) - 1
+        x = parallel.local_frames(g["x"][T:] * torch.sqrt(1.0 + sig[0] ** 2.0), layout, T)
+        s_in = x.new_ones([x.shape[0]])
+        if layout.cfg > 1:
+            guider.check_pair_consistency(x, s_in * sig[0])
+        denoiser = sampling.BoundDenoiser(den, net)
+        rows = [s_in * sig[j] for j in range(nsig + 1)]
+        with torch.no_grad():
+            xx = x
+            for i in range(args.warmup):
+                xx = smp.sampler_step(rows[i % nsig], rows[i % nsig + 1], denoiser, xx, cond, uc)
+            sync()
+            dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                j = (args.warmup + i) % nsig
+                xx = smp.sampler_step(rows[j], rows[j + 1], denoiser, xx, cond, uc)
+            sync()
+            dist.barrier()
+            elapsed = time.perf_counter() - t0
+        tt = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+        assert torch.isfinite(xx).all()
+    finally:
+        parallel.apply_frame_shard(net, None)
+    nsteps = args.steps + args.warmup
+    rec = {"parallelism": layout.name, "scaling": "strong", "ranks_per_sample": layout.per_sample, "samples_in_flight": layout.samples,
+           "value": layout.samples * args.steps / elapsed, "unit": "steps/s", "per_sample_latency_ms": elapsed / args.steps * 1e3,
+           "collective_backend": f"{args.backend} ({'RCCL over xGMI' if args.backend == 'nccl' else 'CPU self-test'}), {world} ranks",
+           "cfg_all_gathers_per_step": 1 if layout.cfg > 1 else 0}
+    if shard is not None:
+        rec["exchange"] = {"all_to_all_per_step": shard.exchanges // max(1, nsteps),
+                           "MB_sent_per_rank_and_step": round(shard.bytes_sent / max(1, nsteps) / 1e6, 1),
+                           "note": "engine.FrameShard: temporal sites run pixel-sharded (DESIGN.md section 9)"}
+    return rec
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without torchrun: start the N ranks as child processes of this one (same command line, the
+    torchrun environment variables per rank, rendezvous on 127.0.0.1), let rank 0's stdout — the ONE JSON line — through,
+    and return the worst exit code.  Equivalent to the driver's `python -m torch.distributed.run --nproc-per-node N ...`."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [pr.wait() for pr in procs]
+    if any(rcs):
+        log(f"bench.py: rank exit codes {rcs}")
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stage", default="denoise", choices=["denoise", "vae-decode", "vae-encode"],
@@ -193,8 +286,9 @@ def main():
     ap.add_argument("--precision", default="precise", choices=["fast", "precise", "precise-all", "precise-lite", "precise-f16lo"],
                     help="operand policy of the timed region (DESIGN §6).  precise (default) meets eps max-abs < 1e-3; the "
                          "other of fast / precise is timed too and reported under `modes`")
-    ap.add_argument("--parallelism", default="replica", choices=["replica", "cfg", "cfg+frames", "frames"],
-                    help="N > 1: replica = one sample per rank (the reference's strategy, weak scaling, default); cfg = one "
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "replica", "cfg", "cfg+frames", "frames"],
+                    help="N > 1: auto (default) = replica as the headline + cfg+frames reported under strong_scaling in the same "
+                         "line; replica = one sample per rank (the reference's strategy, weak scaling); cfg = one "
                          "sample per rank pair (CFG halves, one all-gather per step); cfg+frames = one sample over "
                          "2 CFG halves x min(4, N/2) frame groups (RCCL all-to-all at the temporal sites, SURVEY §8e): "
                          "per-sample latency, strong scaling")
@@ -206,6 +300,11 @@ def main():
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--emulate-kernels", action="store_true",
+                    help="HARNESS SELF-TEST ONLY (tests/test_bench_harness.py): run --config tiny on the CPU against the torch "
+                         "emulation of the C-ABI (tests/emu.py) with --backend gloo, to exercise rank spawning, sharding and the "
+                         "JSON contract where there is no GPU.  The line says so; it is never a measurement")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py spawns the ranks itself (0 = pick a free one)")
     ap.add_argument("--device", type=int, default=None, help="override the HIP device index (default LOCAL_RANK)")
     ap.add_argument("--one-stream", action="store_true", help="do not overlap the ControlNet with the UNet encoder")
     ap.add_argument("--split-samples", action="store_true", help="issue the two CFG halves as independent stream pairs")
@@ -228,16 +327,24 @@ def main():
     if args.yaml_exact:
         args.num_sampling_steps = 25
 
+    if args.emulate_kernels and (args.config != "tiny" or args.backend != "gloo" or args.stage != "denoise"):
+        raise SystemExit("--emulate-kernels is the CPU self-test of the harness: --config tiny --backend gloo only")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)                     # this process becomes the launcher of N ranks
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    dev_index = local_rank if args.device is None else args.device
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    if args.emulate_kernels:
+        dev, sync = torch.device("cpu"), (lambda: None)
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(1, world)))
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        dev_index = local_rank if args.device is None else args.device
+        torch.cuda.set_device(dev_index)
+        dev, sync = torch.device("cuda", dev_index), torch.cuda.synchronize
     if args.stage != "denoise":
         if world > 1:
             raise SystemExit("--stage vae-decode / vae-encode are single-GPU measurements")
@@ -250,15 +357,22 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    from panacea_amd import build_network, configs, hip, parallel, sampling, synth
-    hip.load()
+    from panacea_amd import build_network, configs, engine, hip, parallel, sampling, synth
+    if args.emulate_kernels:
+        sys.path.insert(0, str(ROOT / "tests"))
+        import emu                                   # test infrastructure, explicit opt-in (see --emulate-kernels)
+        _emu_ctx = engine.use_backend(emu)
+        _emu_ctx.__enter__()
+    else:
+        hip.load()
     if args.no_ln_fusion:
         hip.set_option(hip.OPT_GEMM_FUSE_LN, 0)
     if args.stencil_tiles is not None:
         hip.set_option(hip.OPT_STENCIL_TILES, args.stencil_tiles)
     if args.gemm_group_m:
         hip.set_option(hip.OPT_GEMM_GROUP_M, args.gemm_group_m)
-    layout = parallel.layout_for(world, rank, args.parallelism)
+    primary = "replica" if args.parallelism == "auto" else args.parallelism
+    layout = parallel.layout_for(world, rank, primary)
     groups = parallel.Groups(layout) if (layout.cfg > 1 or layout.frames > 1) else None
     kw = configs.with_frames(configs.get(args.config), args.frames) if args.config == "full" else configs.get(args.config)
     B, T, h, w = configs.SHAPES[args.config]
@@ -285,22 +399,23 @@ def main():
     smp = sampling.EulerEDMSampler(args.num_sampling_steps, guider=guider, device=dev)
     smp.fuse = not args.no_fused_step
     shard = groups.frame_shard() if groups is not None else None
-    if shard is not None:
-        parallel.apply_frame_shard(net, shard)
-        cond, uc = parallel.shard_conditioning(cond, layout, T), parallel.shard_conditioning(uc, layout, T)
     sig = smp.sigmas()
     nsig = len(sig) - 1
     x0 = g["x"][T:]
     if args.yaml_exact:
         # cond_image_type final_cond_zero (nuscenes_datasets_video.py:559-572): the conditioning image sits in the LAST
         # frame, the other frames encode a zero image (one constant latent); initial latent = randn + 0.07 * concat[-1]
-        # (share_noise_level, diffusion.py:242-249)
+        # (share_noise_level, diffusion.py:242-249).  Built on the sample's FULL T frames, BEFORE any frame sharding: a
+        # frame group must see the sample's global last frame, not its own.
         zero_lat = g["concat"][T:T + 1].mean(dim=(2, 3), keepdim=True).expand(-1, -1, h, w)
         for d in (cond, uc):
             cc = d["concat"].clone()
             cc[:-1] = zero_lat
             d["concat"] = cc
         x0 = sampling.share_noise_init(x0, cond["concat"], 0.07)
+    if shard is not None:
+        parallel.apply_frame_shard(net, shard)
+        cond, uc = parallel.shard_conditioning(cond, layout, T), parallel.shard_conditioning(uc, layout, T)
     x = x0 * torch.sqrt(1.0 + sig[0] ** 2.0)
     x = parallel.local_frames(x, layout, T)                     # this rank's frame group of the sample
     s_in = x.new_ones([x.shape[0]])
@@ -362,21 +477,21 @@ def main():
         xx = x
         for i in range(args.warmup):
             xx = step(i, xx)
-        torch.cuda.synchronize()
+        sync()
         run = None
         if args.graph:
             from panacea_amd.graph import GraphedStep
             run = GraphedStep(step_fn, x, sig_rows[0], sig_rows[1])
             for i in range(args.warmup):
                 xx = run(xx, sig_rows[i % nsig], sig_rows[i % nsig + 1])
-            torch.cuda.synchronize()
+            sync()
         barrier()
-        torch.cuda.synchronize()
+        sync()
         t_start = time.perf_counter()
         for i in range(args.steps):
             j = (args.warmup + i) % nsig
             xx = step(args.warmup + i, xx) if run is None else run(xx, sig_rows[j], sig_rows[j + 1])
-        torch.cuda.synchronize()
+        sync()
         barrier()
         elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -427,13 +542,18 @@ def main():
             out["roofline"]["basis"] = "sum of 2MNK over the contractions launched in one step (HIP-event pass) / measured step time"
     if parity:
         out["parity"] = parity
+    if args.emulate_kernels:
+        out["emulated_kernels"] = True
+        out["metric"] += " [HARNESS SELF-TEST on the CPU emulation of the C-ABI: not a measurement]"
+    if args.parallelism == "auto" and world > 1 and world % 2 == 0 and T % max(1, min(4, world // 2)) == 0:
+        out["strong_scaling"] = run_sharded_mode(args, "cfg+frames", net, kw, (h, w), dev, sync, rank, world, g, layout.sample, den)
     if shard is not None:
         nsteps = args.steps + args.warmup
         out["config"]["exchange"] = {"all_to_all_per_step": shard.exchanges // max(1, nsteps),
                                      "MB_sent_per_rank_and_step": round(shard.bytes_sent / max(1, nsteps) / 1e6, 1),
                                      "note": "engine.FrameShard: temporal sites run pixel-sharded (DESIGN.md §9)"}
 
-    if rank == 0 and not args.no_kernel_breakdown and layout.per_sample == 1:
+    if rank == 0 and not args.no_kernel_breakdown and layout.per_sample == 1 and not args.emulate_kernels:
         prof = hip.Profiler()
         hip.set_profiler(prof)
         two = net.diffusion_model.two_stream
@@ -477,11 +597,11 @@ def main():
             xx = x
             for i in range(args.warmup):
                 xx = step(i, xx)
-            torch.cuda.synchronize()
+            sync()
             t0 = time.perf_counter()
             for i in range(args.steps):
                 xx = step(args.warmup + i, xx)
-            torch.cuda.synchronize()
+            sync()
             dt = (time.perf_counter() - t0) / args.steps
             po = parity_of(other)
         net.diffusion_model.precision = args.precision
@@ -498,7 +618,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -41,6 +41,16 @@ CONDITIONER_TARGETS = {"sgm.modules.encoders.modules": ("GeneralConditioner", "I
                                                         "FrozenOpenCLIPEmbedder")}
 
 
+# Bindings of the rebound classes that OTHER modules of the reference hold by value (`from .encoders.modules import
+# GeneralConditioner` in sgm/modules/__init__.py — and `sgm.modules.GeneralConditioner` is what the YAML names —;
+# `from ..modules.encoders.modules import VAEEmbedder` in sgm/models/diffusion.py, used in an isinstance check).  When those
+# modules are already imported at install() time their copies are rebound too; modules imported later pick the patched
+# attribute up by themselves.
+RE_EXPORTS = {"sgm.modules.encoders.modules": ("sgm.modules", "sgm.models.diffusion", "sgm.modules.encoders"),
+              "sgm.modules.diffusionmodules.model": ("sgm.models.autoencoder",),
+              "sgm.modules.diffusionmodules.wrappers": ("sgm.models.diffusion",)}
+
+
 def _patch(module) -> None:
     from . import nn as mirror
     from .nn import model as first_stage
@@ -49,8 +59,15 @@ def _patch(module) -> None:
     else:
         src = first_stage if module.__name__.endswith("diffusionmodules.model") else mirror
     for cls in TARGETS[module.__name__]:
-        setattr(module, "_reference_" + cls, getattr(module, cls, None))
+        ref_cls = getattr(module, cls, None)
+        if ref_cls is getattr(src, cls):
+            continue                                       # already patched
+        setattr(module, "_reference_" + cls, ref_cls)
         setattr(module, cls, getattr(src, cls))
+        for other in RE_EXPORTS.get(module.__name__, ()):
+            om = sys.modules.get(other)
+            if om is not None and ref_cls is not None and getattr(om, cls, None) is ref_cls:
+                setattr(om, cls, getattr(src, cls))
     if module.__name__.endswith("controlmodel"):
         # the mirror ControlledUNetModel3D resolves `controlnet_config.target` through the same (patched) module
         module._panacea_amd = True

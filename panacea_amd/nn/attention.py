@@ -407,11 +407,14 @@ class SpatialTemporalTransformer(nn.Module, Packable):
         self._branch(rt, x, "_temporal", self.transformer_blocks_temporal, "temporal", out16=out16, out16_lo=out16lo)
         return Act(x.F, x.H, x.W, x.C, f32=x.f32, f16=out16, f16_lo=out16lo)
 
+    precision = "precise"      # operand policy of the reference-compatible entry below (the network sets rt.prec itself)
+
     def forward(self, x, context=None):
         """Reference-compatible entry: x (B*T, C, h, w) NCHW, context (B*T, n, D) already tiled over T."""
         from .util import act_from_nchw, runtime_for
         ctx = context[0] if isinstance(context, list) else context
         rt = runtime_for(x, self.num_frames)
+        rt.prec = E.precision(self.precision)
         rt.set_context(ctx.view(rt.B, rt.T, *ctx.shape[1:])[:, 0])
         a = act_from_nchw(rt, x)
         return self._run(rt, a).to_nchw().to(x.dtype)

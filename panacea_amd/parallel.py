@@ -190,9 +190,16 @@ def gather_frames(x_local: torch.Tensor, groups: "Groups", num_frames: int) -> t
     lo = groups.layout
     if lo.frames == 1:
         return x_local
+    tl = num_frames // lo.frames
+    if x_local.shape[0] % tl:
+        raise ValueError(f"{x_local.shape[0]} local frames are not a multiple of the {tl} frames per sample of this rank")
+    nb = x_local.shape[0] // tl                 # samples in the batch
     parts = [torch.empty_like(x_local) for _ in range(lo.frames)]
     dist.all_gather(parts, x_local.contiguous(), group=groups.frame_group)
-    return torch.cat(parts, dim=0)
+    # parts[g] holds rows (b, t_local) of frame group g; the sample's frames in global order are (b, g, t_local)
+    # — the order local_frames() cut them in and FrameShard.gather_rows() restores (a plain cat interleaves
+    # the samples for more than one sample per rank)
+    return torch.stack([q.view(nb, tl, *q.shape[1:]) for q in parts], dim=1).reshape(nb * lo.frames * tl, *x_local.shape[1:])
 
 
 class ShardedCFG(VanillaCFG):

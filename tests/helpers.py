@@ -53,3 +53,12 @@ def err_stats(got: torch.Tensor, ref) -> dict:
     d = (got.detach().float().cpu() - ref).abs()
     return dict(max_abs=d.max().item(), mean_abs=d.mean().item(), ref_rms=ref.pow(2).mean().sqrt().item(),
                 ref_max=ref.abs().max().item())
+
+
+def measured(tag: str, **values):
+    """append one line of measured numbers to gpurun_out/test_measurements.log (GPU runs: the gates next to each test are
+    pinned from these; no-op when the directory does not exist)"""
+    d = Path(__file__).resolve().parent.parent / "gpurun_out"
+    if d.is_dir():
+        with open(d / "test_measurements.log", "a") as f:
+            f.write(tag + " " + " ".join(f"{k}={v:.4e}" if isinstance(v, float) else f"{k}={v}" for k, v in values.items()) + "\n")

@@ -51,7 +51,8 @@ def test_enum_constants_match_the_header_as_gcc_reads_it(tmp_path):
              "PNC_OPT_ATTN_VARIANT": hip.OPT_ATTN_VARIANT, "PNC_OPT_ATTN_DMA": hip.OPT_ATTN_DMA,
              "PNC_OPT_GEMM_FUSE_LN": hip.OPT_GEMM_FUSE_LN, "PNC_OPT_GEMM_GROUP_M": hip.OPT_GEMM_GROUP_M,
              "PNC_OPT_STENCIL_TILES": hip.OPT_STENCIL_TILES, "PNC_A_PLAIN": hip.A_PLAIN, "PNC_A_CONV3X3": hip.A_CONV3X3,
-             "PNC_A_CONV1D_T": hip.A_CONV1D_T, "PNC_ACT_NONE": hip.ACT_NONE, "PNC_ACT_SILU": hip.ACT_SILU, "PNC_ACT_GELU": hip.ACT_GELU}
+             "PNC_A_CONV1D_T": hip.A_CONV1D_T, "PNC_ACT_NONE": hip.ACT_NONE, "PNC_ACT_SILU": hip.ACT_SILU, "PNC_ACT_GELU": hip.ACT_GELU,
+             "PNC_LO_F16": hip.LO_F16, "PNC_LO_E4M3": hip.LO_E4M3}
     src = ['#include <stdio.h>', f'#include "{hip.HEADER}"', 'int main(void) {']
     src += [f'printf("{n} %d\\n", (int){n});' for n in list(names) + ["PNC_OPT_COUNT"]]
     src.append('return 0; }')
@@ -145,12 +146,32 @@ def test_dropin_rebinds_the_conditioner_classes_on_request():
     from panacea_amd import conditioner as C, dropin
     m = import_conditioner()
     saved = {k: getattr(m, k) for k in dropin.CONDITIONER_TARGETS["sgm.modules.encoders.modules"]}
+    # the bindings other modules of the reference hold BY VALUE when sgm was imported before install(): the YAML names
+    # `sgm.modules.GeneralConditioner` (a re-export of sgm/modules/__init__.py), diffusion.py keeps its own `VAEEmbedder`
+    import types
+    pkg = sys.modules.get("sgm.modules") or types.ModuleType("sgm.modules")
+    diff = sys.modules.get("sgm.models.diffusion") or types.ModuleType("sgm.models.diffusion")
+    had = {n: n in sys.modules for n in ("sgm.modules", "sgm.models.diffusion")}
+    sys.modules["sgm.modules"], sys.modules["sgm.models.diffusion"] = pkg, diff
+    pkg.GeneralConditioner, diff.VAEEmbedder = saved["GeneralConditioner"], saved["VAEEmbedder"]
     try:
         dropin.install(lazy=True, conditioner=True)
         assert m.GeneralConditioner is C.GeneralConditioner and m.FrozenOpenCLIPEmbedder is C.FrozenOpenCLIPEmbedder
         assert m._reference_GeneralConditioner is saved["GeneralConditioner"]
+        # resolved the way instantiate_from_config does it: getattr(import_module("sgm.modules"), "GeneralConditioner")
+        import importlib
+        assert getattr(importlib.import_module("sgm.modules"), "GeneralConditioner") is C.GeneralConditioner
+        assert diff.VAEEmbedder is C.VAEEmbedder
+        assert issubclass(C.VAEEmbedder, C.AbstractEmbModel)        # the isinstance check of GeneralConditioner.__init__
     finally:
         for k, v in saved.items():
             setattr(m, k, v)
         for k in dropin.CONDITIONER_TARGETS:
             dropin.TARGETS.pop(k, None)
+        for n, was in had.items():
+            if not was:
+                sys.modules.pop(n, None)
+        if had["sgm.modules"]:
+            pkg.__dict__.pop("GeneralConditioner", None)
+        if had["sgm.models.diffusion"]:
+            diff.__dict__.pop("VAEEmbedder", None)

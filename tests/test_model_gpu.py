@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, cond, err_stats, golden, manifest, oracle_cfg, product_network, step_inputs
+from helpers import GOLDEN, cond, err_stats, golden, manifest, measured, oracle_cfg, product_network, step_inputs
 from oracle import panacea_oracle as po
 from panacea_amd import configs, hip
 
@@ -30,6 +30,11 @@ CONFIG2_TOL = (NORTH_STAR, 2e-4)
 # conv3x3 output feeding it) 1.0e-3 / 1.6e-4 with every class split, 5.7e-3 / 8.4e-4 fast
 TOL = {("tiny", "precise"): (NORTH_STAR, 2e-4), ("tiny", "fast"): (3e-3, 5e-4),
        ("plain1", "precise-all"): (1.4e-3, 2.2e-4), ("plain1", "fast"): (8e-3, 1.2e-3)}
+
+
+# block outputs / ControlNet residuals (stride-7 samples of the reference's tensors): max-abs error relative to max(1, max|ref|)
+# of the tensor, pinned ~1.5x above the worst block measured on the MI355X (round 3; round 2 allowed 2e-3 / 6e-3 everywhere)
+BLOCK_TOL = {("tiny", "precise"): 2e-3, ("tiny", "fast"): 2e-3, ("plain1", "precise-all"): 6e-3, ("plain1", "fast"): 6e-3}
 
 
 def test_library_is_loaded_and_native():
@@ -52,13 +57,16 @@ def test_hip_path_matches_reference_golden(name, prec):
     print(name, prec, st)
     assert eps.is_cuda and eps.dtype == torch.float32
     assert st["max_abs"] <= TOL[(name, prec)][0] and st["mean_abs"] <= TOL[(name, prec)][1], st
+    worst = 0.0
     for k in gold.files:
         key = k[6:] if k.startswith("block.") else k
         if key in trace and k != "eps":
             ref = gold[k]
             got = trace[key].reshape(-1)[::7].cpu().numpy()
-            lim = (2e-3 if name == "tiny" else 6e-3) * max(1.0, np.abs(ref).max())
-            assert np.abs(got - ref).max() <= lim, (k, np.abs(got - ref).max())
+            rel = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+            worst = max(worst, rel)
+            assert rel <= BLOCK_TOL[(name, prec)], (k, rel)
+    measured("block_trace", net=name, prec=prec, worst_rel=float(worst))
 
 
 def test_baseline_config1_64x64_latent_vs_reference_golden():
@@ -175,8 +183,21 @@ def test_full_size_properties_and_golden(full_net):
         g = np.load(path)
         st = err_stats(eps.reshape(-1)[::7], g["eps_s7"])
         print("config 3 vs reference:", w.diffusion_model.precision, st)
+        measured("full_cfg3", t=999, salt=0, max_abs=st["max_abs"], mean_abs=st["mean_abs"])
         assert w.diffusion_model.precision == "precise"
         assert st["max_abs"] <= NORTH_STAR and st["mean_abs"] <= 2e-4, st
+        # further pins of the reference's own forward (round 3): other noise levels, another input seed — same gate
+        for fname, t_index, salt in (("full_cfg3_t500.npz", 500, 0), ("full_cfg3_t39_s1.npz", 39, 1)):
+            from panacea_amd import synth
+            gi = {k: v.to(DEV) for k, v in synth.synth_inputs(2, 8, 32, 384, context_dim=kw["context_dim"], t_index=t_index,
+                                                               salt=salt).items()}
+            gp = np.load(GOLDEN / fname)
+            assert int(gp["t_index"]) == t_index and int(gp["input_salt"]) == salt
+            st2 = err_stats(w(gi["x"], gi["t"], cond(gi)).reshape(-1)[::7], gp["eps_s7"])
+            print(f"config 3 vs reference, t={t_index} salt={salt}:", st2)
+            measured("full_cfg3", t=t_index, salt=salt, max_abs=st2["max_abs"], mean_abs=st2["mean_abs"])
+            assert st2["max_abs"] <= NORTH_STAR and st2["mean_abs"] <= 2e-4, (fname, st2)
+            del gi
         w.diffusion_model.precision = "fast"
         st = err_stats(w(inp["x"], inp["t"], cond(inp)).reshape(-1)[::7], g["eps_s7"])
         w.diffusion_model.precision = "precise"

@@ -6,12 +6,19 @@ at best.)"""
 import pytest
 import torch
 
+from helpers import measured
 from oracle import panacea_oracle as po
 from panacea_amd import synth
 from panacea_amd.nn import attention as A, openaimodel as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+
+
+# (max-abs, mean-abs) of the module outputs (|out| ~ 5-7) in the default `precise` policy; provisional until pinned ~1.5x above
+# the MI355X measurements (gpurun_out/test_measurements.log)
+RES_TOL = (4e-3, 5e-4)
+STT_TOL = (5e-3, 8e-4)
 
 
 def _load(module, prefix, salt=0):
@@ -38,8 +45,14 @@ def test_resblock3d_vs_oracle(cin, cout, T):
     err = (got - ref).abs()
     print(f"ResBlock3D {cin}->{cout} T={T}: max {err.max().item():.3e} mean {err.mean().item():.3e} |ref| {ref.abs().max().item():.2f}")
     assert got.shape == ref.shape
-    # plain fp16 operands (module entry points use engine.FAST); emulation of the same graph: 0.6-1.3e-3 / 0.9-1.9e-4
-    assert err.max().item() <= 4e-3 and err.mean().item() <= 5e-4
+    assert blk.precision == "precise"          # the module entry runs the product's default operand policy (round 2: engine.FAST)
+    measured("resblock3d_vs_oracle", cin=cin, cout=cout, T=T, max_abs=err.max().item(), mean_abs=err.mean().item(),
+             ref_max=ref.abs().max().item())
+    assert err.max().item() <= RES_TOL[0] and err.mean().item() <= RES_TOL[1]
+    blk.precision = "fast"                     # plain fp16 operands; emulation of the same graph: 0.6-1.3e-3 / 0.9-1.9e-4
+    errf = (blk(x.to(DEV), emb.to(DEV)).cpu() - ref).abs()
+    measured("resblock3d_vs_oracle_fast", cin=cin, max_abs=errf.max().item(), mean_abs=errf.mean().item())
+    assert errf.max().item() <= 4e-3 and errf.mean().item() <= 5e-4
 
 
 @pytest.mark.parametrize("C,T,h,w", [(320, 2, 8, 96), (640, 4, 4, 48), (1280, 2, 2, 24)])
@@ -56,5 +69,10 @@ def test_spatial_temporal_transformer_vs_oracle(C, T, h, w):
     got = stt.to(DEV)(x.to(DEV), ctx_t.to(DEV)).cpu()
     err = (got - ref).abs()
     print(f"STT C={C} T={T} {h}x{w}: max {err.max().item():.3e} mean {err.mean().item():.3e} |ref| {ref.abs().max().item():.2f}")
-    # emulation of the same graph: 1.75e-3 / 3.0e-4 at |out| ~ 7
-    assert err.max().item() <= 5e-3 and err.mean().item() <= 8e-4
+    assert stt.precision == "precise"
+    measured("stt_vs_oracle", C=C, T=T, max_abs=err.max().item(), mean_abs=err.mean().item(), ref_max=ref.abs().max().item())
+    assert err.max().item() <= STT_TOL[0] and err.mean().item() <= STT_TOL[1]
+    stt.precision = "fast"                     # emulation of the same graph: 1.75e-3 / 3.0e-4 at |out| ~ 7
+    errf = (stt(x.to(DEV), ctx_t.to(DEV)).cpu() - ref).abs()
+    measured("stt_vs_oracle_fast", C=C, max_abs=errf.max().item(), mean_abs=errf.mean().item())
+    assert errf.max().item() <= 5e-3 and errf.mean().item() <= 8e-4

@@ -165,26 +165,44 @@ class FrameShard:
         self.bytes_sent = 0                       # accounting for bench / DESIGN §9 (this rank, since construction)
         self.exchanges = 0
 
-    def _a2a(self, send: torch.Tensor) -> torch.Tensor:
+    def _a2a(self, send: torch.Tensor):
+        """-> (recv, work): work is None when the exchange has completed (loop-back), else the handle of the collective running
+        on the communicator's own stream — `work.wait()` orders the CURRENT stream behind it"""
         self.exchanges += 1
         self.bytes_sent += send.numel() * send.element_size() * (self.G - 1) // self.G
         if self.group is None:
-            return send.clone()
+            return send.clone(), None
         import torch.distributed as dist
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
-        return recv
+        return recv, dist.all_to_all_single(recv, send, group=self.group, async_op=True)
 
-    def to_pixels(self, x: torch.Tensor, B: int, N: int) -> torch.Tensor:
-        """[B*T_l*N, C] rows (b, t_local, p) -> [B*T*(N/G), C] rows (b, t, p_local)"""
+    class Pending:
+        """An exchange in flight.  Kernels enqueued between `*_start()` and `result()` run UNDER the transfer (RCCL executes
+        the collective on its own stream; the compute stream only waits in `result()`): the independent work every ResBlock3D
+        site has — the skip 1x1 conv and the `emb_layers` linear — goes there."""
+
+        def __init__(self, recv, work, finish):
+            self._recv, self._work, self._finish = recv, work, finish
+
+        def result(self) -> torch.Tensor:
+            if self._work is not None:
+                self._work.wait()
+                self._work = None
+            return self._finish(self._recv)
+
+    def to_pixels_start(self, x: torch.Tensor, B: int, N: int) -> "FrameShard.Pending":
         G = self.G
         if N % G:
             raise ValueError(f"{N} pixels per frame do not split over {G} frame groups")
         C = x.shape[-1]
         Tl, Np = x.shape[0] // (B * N), N // G
         send = x.view(B, Tl, G, Np, C).permute(2, 0, 1, 3, 4).contiguous()      # [dest pixel group, b, t_l, p, c]
-        recv = self._a2a(send)                                                  # [src frame group, b, t_l, p, c]
-        return recv.permute(1, 0, 2, 3, 4).contiguous().view(B * G * Tl * Np, C)
+        recv, work = self._a2a(send)                                            # [src frame group, b, t_l, p, c]
+        return FrameShard.Pending(recv, work, lambda r: r.permute(1, 0, 2, 3, 4).contiguous().view(B * G * Tl * Np, C))
+
+    def to_pixels(self, x: torch.Tensor, B: int, N: int) -> torch.Tensor:
+        """[B*T_l*N, C] rows (b, t_local, p) -> [B*T*(N/G), C] rows (b, t, p_local)"""
+        return self.to_pixels_start(x, B, N).result()
 
     def to_frames(self, x: torch.Tensor, B: int, N: int) -> torch.Tensor:
         """inverse of to_pixels: [B*T*(N/G), C] -> [B*T_l*N, C]"""
@@ -193,7 +211,9 @@ class FrameShard:
         Np = N // G
         Tl = x.shape[0] // (B * G * Np)
         send = x.view(B, G, Tl, Np, C).permute(1, 0, 2, 3, 4).contiguous()      # [dest frame group, b, t_l, p, c]
-        recv = self._a2a(send)                                                  # [src pixel group, b, t_l, p, c]
+        recv, work = self._a2a(send)                                            # [src pixel group, b, t_l, p, c]
+        if work is not None:
+            work.wait()
         return recv.permute(1, 2, 0, 3, 4).contiguous().view(B * Tl * N, C)
 
     def gather_rows(self, x: torch.Tensor, B: int) -> torch.Tensor:

@@ -106,9 +106,16 @@ class ControlNet3D(UNetModel3D):
                 if (guided.H, guided.W, guided.C) != (h.H, h.W, h.C):
                     raise ValueError(f"hint stem output {guided.H}x{guided.W}x{guided.C} does not match the latent "
                                      f"{h.H}x{h.W}x{h.C} (the hint must be 8x the latent resolution)")
+                if guided.F < 1 or h.F % guided.F:
+                    raise ValueError(f"{guided.F} hint frames do not tile the batch of {h.F} frames")
                 h.f16 = rt.empty((h.M, h.C), torch.float16)
                 h.f16_lo = rt.lo_plane((h.M, h.C), "stream")
-                rt.be.add_f32(h.f32, guided.f32, h.M * h.C, h.f32, h.f16, h.f16_lo)   # h += guided_hint
+                # h += guided_hint.  A hint of F / k frames is shared by the k groups of the batch (the two CFG halves carry
+                # the SAME BEV layout: the fused sampler step hands it over once and the stem runs on T frames, not 2 T)
+                mg = guided.M * h.C
+                for r in range(h.F // guided.F):
+                    sl = slice(r * guided.M, (r + 1) * guided.M)
+                    rt.be.add_f32(h.f32[sl], guided.f32, mg, h.f32[sl], h.f16[sl], None if h.f16_lo is None else h.f16_lo[sl])
             outs.append(self._zero_conv(rt, h, pk, i))
         h = self.middle_block._run(rt, h, emb32, want_f16=True)
         if rt.trace is not None:
@@ -215,7 +222,9 @@ class ControlledUNetModel3D(UNetModel3D):
     def denoise_tokens(self, x, c_in, timesteps, context, concat, hint, invariants=None) -> Act:
         """Fused sampler entry: `x` is the UNSCALED latent of one CFG half, `c_in` the per-frame input scale of
         the whole batch, `concat` the batch's conditioning latents; returns eps as channels-last fp32 tokens (Act.f32
-        [F*h*w, 4]) for pnc_cfg_euler_step.  Same network evaluation as `denoise(cat(x * c_in, concat), ...)`."""
+        [F*h*w, 4]) for pnc_cfg_euler_step.  Same network evaluation as `denoise(cat(x * c_in, concat), ...)`.  `hint` may hold
+        the BEV layout of ONE CFG half (F / 2 frames) when both halves share it: the hint stem then runs once per step on those
+        frames (controlmodel.py:125-129 evaluates it on the doubled batch: 2x the work for the same result)."""
         return self._denoise_one(x, timesteps, context, hint, None, 0, invariants, fused=(c_in, concat))
 
     def _denoise_one(self, x, timesteps, context, hint, trace, side_idx, inv=None, fused=None):

@@ -218,9 +218,14 @@ class ResBlock3D(TimestepBlock, Packable):
         # h = h + conv1d_t(SiLU(GN_t(h))) + emb_layers(emb)[frame]      (:505-531)
         # emb32 arrives as SiLU(emb): the activation of `emb_layers` is applied ONCE per network evaluation by
         # _time_embedding (32 ResBlocks x 16 x 1280 identical SiLUs otherwise), the Linear runs here
+        s = None
         if sh is not None:
-            h = sh.to_pixels(h, rt.B, N)
+            # the exchange runs on the communicator's stream; what this site computes independently of it — the timestep
+            # embedding's linear and the skip path — is enqueued under the transfer
+            pend = sh.to_pixels_start(h, rt.B, N)
             emb_out = E.small_linear(rt, rt.emb_all, pk["we"], pk["be"], rt.B * rt.T, Co, self.emb_channels)
+            s = self._skip(rt, x, pk)
+            h = pend.result()
         else:
             emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
         t16, t16lo = E.gn_temporal(rt, h, Nt, Co, pk["gt1"], pk["bt1"], 1e-5)
@@ -233,13 +238,8 @@ class ResBlock3D(TimestepBlock, Packable):
         a16, a16lo = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True, split="gn_res")
         g = run_conv3x3(rt, a16, F, H, W, Co, pk["w2"], pk["c2"], Co, x16_lo=a16lo).f32
         # skip path
-        if "ws" in pk:
-            s = rt.empty((M, Co), torch.float32)
-            x16 = x.need_f16(rt)
-            rt.be.gemm(x16, pk["ws"], M=M, N=Co, K=Cin, lda=Cin, bias=pk["bs"], out32=s, ldc32=Co,
-                       a16_lo=x.f16_lo, w_lo=E.wlo(pk, "ws", x.f16_lo))
-        else:
-            s = x.f32
+        if s is None:
+            s = self._skip(rt, x, pk)
         # return skip(x) + (g + conv1d_t(SiLU(GN_t(g))))                 (:533-542)
         o16 = rt.empty((M, Co), torch.float16) if want_f16 else None
         o16lo = rt.lo_plane((M, Co), "stream", on=want_f16)
@@ -257,6 +257,16 @@ class ResBlock3D(TimestepBlock, Packable):
             g = sh.to_frames(gp, rt.B, N)
             rt.be.add_f32(g, s, M * Co, g, o16, o16lo)
         return Act(F, H, W, Co, f32=g, f16=o16, f16_lo=o16lo)
+
+    def _skip(self, rt: Runtime, x: Act, pk: dict) -> torch.Tensor:
+        """skip_connection(x): the 1x1 conv where the channel count changes (openaimodel.py:486), else x itself"""
+        if "ws" not in pk:
+            return x.f32
+        s = rt.empty((x.M, self.out_channels), torch.float32)
+        x16 = x.need_f16(rt)
+        rt.be.gemm(x16, pk["ws"], M=x.M, N=self.out_channels, K=self.channels, lda=self.channels, bias=pk["bs"], out32=s,
+                   ldc32=self.out_channels, a16_lo=x.f16_lo, w_lo=E.wlo(pk, "ws", x.f16_lo))
+        return s
 
     precision = "precise"      # operand policy of the reference-compatible entry below (the network sets rt.prec itself)
 

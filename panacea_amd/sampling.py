@@ -110,6 +110,12 @@ class VanillaCFG:
         return torch.cat([x] * 2), torch.cat([s] * 2), c_out
 
 
+def _same_tensor(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """the two names refer to the same values in the same memory (identity of content without reading it)"""
+    return a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype
+                      and a.device == b.device)
+
+
 class BoundDenoiser:
     """`lambda input, sigma, c: denoiser(model, input, sigma, c)` of DiffusionEngine3D.sample (diffusion.py:251-253) as an
     object: the sampler can see which denoiser and which network it drives and run the whole step on the device — the
@@ -165,7 +171,15 @@ class EulerEDMSampler:
             cat, inv, nh = cond, cond.get("_invariants"), 1
         else:
             pre = cond.get("_cat")
-            cat = pre if pre is not None else {k: torch.cat((uc[k], cond[k]), 0) for k in ("crossattn", "concat", "cond_feat")}
+            if pre is not None:
+                cat = pre
+            else:
+                cat = {k: torch.cat((uc[k], cond[k]), 0) for k in ("crossattn", "concat")}
+                # the BEV-layout hint: uc and c normally hold the SAME tensor (IdentityEncoder returns its input for both
+                # conditioner passes, modules.py:242-247).  Then it is handed over once — no 2 x 0.5 GB concatenation per step
+                # and the network runs its hint stem on T frames instead of 2 T
+                hu, hc = uc["cond_feat"], cond["cond_feat"]
+                cat["cond_feat"] = hc if _same_tensor(hu, hc) else torch.cat((hu, hc), 0)
             inv, nh = cond.get("_invariants"), 2
         ctx = cat["crossattn"].to(model.controlnet.input_hint_block[0].weight.dtype)
         eps = model.denoise_tokens(x, c_in.repeat(nh).contiguous(), c_noise.repeat(nh).contiguous(), ctx, cat["concat"],

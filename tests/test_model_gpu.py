@@ -339,6 +339,14 @@ def test_fused_sampler_step_on_device_replays_the_reference_trajectory():
     print("fused == plain bitwise:", torch.equal(fused, plain), (fused - plain).abs().max().item())
     assert torch.allclose(fused, plain, rtol=0, atol=2e-5)
     assert torch.equal(graphed, fused)
+    # the BEV hint as ONE tensor shared by c and uc (what the reference's conditioner hands over): the hint stem then runs on
+    # T frames instead of 2 T and nothing is concatenated — same bits as the doubled evaluation above
+    assert torch.equal(uc["cond_feat"], c["cond_feat"])
+    uc_shared = dict(uc, cond_feat=c["cond_feat"])
+    with torch.no_grad():
+        shared = smp.sampler_step(s_in * sig[0], s_in * sig[1], bd, x0, c, uc_shared)
+    torch.cuda.synchronize()
+    assert torch.equal(shared, fused)
 
 
 def test_yaml_exact_25_step_trajectory_vs_oracle_on_the_gpu():

@@ -33,8 +33,9 @@ TOL = {("tiny", "precise"): (NORTH_STAR, 2e-4), ("tiny", "fast"): (3e-3, 5e-4),
 
 
 # block outputs / ControlNet residuals (stride-7 samples of the reference's tensors): max-abs error relative to max(1, max|ref|)
-# of the tensor, pinned ~1.5x above the worst block measured on the MI355X (round 3; round 2 allowed 2e-3 / 6e-3 everywhere)
-BLOCK_TOL = {("tiny", "precise"): 2e-3, ("tiny", "fast"): 2e-3, ("plain1", "precise-all"): 6e-3, ("plain1", "fast"): 6e-3}
+# of the tensor, pinned ~1.5x above the worst block measured on the MI355X in round 3 (gpurun_out/test_measurements.log:
+# 5.9e-4 / 7.2e-4 / 8.8e-4 / 4.0e-3; round 2 allowed 2e-3 on tiny and 6e-3 on plain1 whatever the policy)
+BLOCK_TOL = {("tiny", "precise"): 9e-4, ("tiny", "fast"): 1.1e-3, ("plain1", "precise-all"): 1.4e-3, ("plain1", "fast"): 6e-3}
 
 
 def test_library_is_loaded_and_native():

@@ -15,10 +15,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-# (max-abs, mean-abs) of the module outputs (|out| ~ 5-7) in the default `precise` policy; provisional until pinned ~1.5x above
-# the MI355X measurements (gpurun_out/test_measurements.log)
-RES_TOL = (4e-3, 5e-4)
-STT_TOL = (5e-3, 8e-4)
+# (max-abs, mean-abs) of the module outputs (|out| ~ 5-7), pinned ~1.5x above the MI355X measurements of round 3
+# (gpurun_out/test_measurements.log).  `precise` (the modules' default): ResBlock3D 4.8-6.3e-4 / 7.2-8.6e-5, STT 8.0-8.8e-4 /
+# 1.3-1.5e-4;  `fast` (plain fp16 operands, what round 2's entries ran): 0.7-1.3e-3 / 0.9-1.9e-4 and 1.7-1.8e-3 / 2.9-3.1e-4
+RES_TOL, RES_TOL_FAST = (1.0e-3, 1.4e-4), (2.0e-3, 3.0e-4)
+STT_TOL, STT_TOL_FAST = (1.35e-3, 2.3e-4), (2.7e-3, 4.6e-4)
 
 
 def _load(module, prefix, salt=0):
@@ -52,7 +53,7 @@ def test_resblock3d_vs_oracle(cin, cout, T):
     blk.precision = "fast"                     # plain fp16 operands; emulation of the same graph: 0.6-1.3e-3 / 0.9-1.9e-4
     errf = (blk(x.to(DEV), emb.to(DEV)).cpu() - ref).abs()
     measured("resblock3d_vs_oracle_fast", cin=cin, max_abs=errf.max().item(), mean_abs=errf.mean().item())
-    assert errf.max().item() <= 4e-3 and errf.mean().item() <= 5e-4
+    assert errf.max().item() <= RES_TOL_FAST[0] and errf.mean().item() <= RES_TOL_FAST[1]
 
 
 @pytest.mark.parametrize("C,T,h,w", [(320, 2, 8, 96), (640, 4, 4, 48), (1280, 2, 2, 24)])
@@ -75,4 +76,4 @@ def test_spatial_temporal_transformer_vs_oracle(C, T, h, w):
     stt.precision = "fast"                     # emulation of the same graph: 1.75e-3 / 3.0e-4 at |out| ~ 7
     errf = (stt(x.to(DEV), ctx_t.to(DEV)).cpu() - ref).abs()
     measured("stt_vs_oracle_fast", C=C, max_abs=errf.max().item(), mean_abs=errf.mean().item())
-    assert errf.max().item() <= 5e-3 and errf.mean().item() <= 8e-4
+    assert errf.max().item() <= STT_TOL_FAST[0] and errf.mean().item() <= STT_TOL_FAST[1]

@@ -3,8 +3,7 @@ BASELINE config 3 (profiles/round3/shape_profile_r3b_precise.log), interleaved p
 import sys
 from pathlib import Path
 import torch
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from panacea_amd import engine, hip
 DEV = "cuda"
 

@@ -321,9 +321,6 @@ def main():
     ap.add_argument("--gemm-group-m", type=int, default=0,
                     help="A/B: PNC_OPT_GEMM_GROUP_M (0 = auto, 1 = plain tile order, k = groups of k row panels); same result")
     ap.add_argument("--no-modes", action="store_true", help="do not time the other operand policy (profiling runs)")
-    ap.add_argument("--mall-panels", type=int, default=None,
-                    help="A/B: engine.MALL_PANEL_BYTES in MB (0 = off: GroupNorm / FeedForward launch pairs over all rows at once)")
-    ap.add_argument("--two-wg", type=int, default=None, help="A/B: PNC_OPT_GEMM_TWO_WG (128x320 tiles, two workgroups per CU)")
     ap.add_argument("--hoist", action="store_true",
                     help="sampler mode (SURVEY §8 f1): text K/V + ControlNet hint stem computed once per schedule, outside "
                          "the timed steps.  NOT the headline: the default re-evaluates the whole path every step")
@@ -377,10 +374,6 @@ def main():
         hip.set_option(hip.OPT_STENCIL_TILES, args.stencil_tiles)
     if args.gemm_group_m:
         hip.set_option(hip.OPT_GEMM_GROUP_M, args.gemm_group_m)
-    if args.two_wg is not None:
-        hip.set_option(hip.OPT_GEMM_TWO_WG, args.two_wg)
-    if args.mall_panels is not None:
-        engine.MALL_PANEL_BYTES = args.mall_panels << 20
     primary = "replica" if args.parallelism == "auto" else args.parallelism
     layout = parallel.layout_for(world, rank, primary)
     groups = parallel.Groups(layout) if (layout.cfg > 1 or layout.frames > 1) else None

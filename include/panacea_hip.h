@@ -47,7 +47,7 @@ enum {
     PNC_OPT_GEMM_TAIL_SPLIT = 0,  /* 1 (default): run a sparse last round of output tiles as half / quarter-row workgroups
                                      (bit-identical to 0: rows of a GEMM are independent) */
     PNC_OPT_GEMM_TILE = 1,        /* 0 (default): score-based tile choice; 1 = 128x128, 2 = 256x128, 3 = 256x320,
-                                     4 = 256x256, 6 = 128x320 force a geometry where the shape allows it (kernel micro-benchmarks) */
+                                     4 = 256x256 force a geometry where the shape allows it (kernel micro-benchmarks) */
     PNC_OPT_ATTN_VARIANT = 2,     /* 0 (default): by view size; 41 / 81 / 42 / 82 = (waves, query blocks per wave) */
     PNC_OPT_ATTN_DMA = 3,         /* 1 (default): LDS-DMA staging of K / V^T tiles where alignment allows; 0 = register staging */
     PNC_OPT_GEMM_FUSE_LN = 4,     /* 1 (default): PncGemmParams.ln_* is reduced in the GEMM epilogue where a workgroup owns whole
@@ -59,11 +59,7 @@ enum {
                                      the input incl. its halo per 64-channel slice and read the nine taps from it (gemm_stencil_tile.hip);
                                      0 = always one gathered A tile per tap; 2 = wherever the shape allows (tests).  Bit-identical
                                      results either way */
-    PNC_OPT_GEMM_TWO_WG = 7,      /* 1 (default): stream-bound GEMMs (fp32 residual / output streams at K <= 1280, N % 320 == 0) run 128x320 tiles,
-                                     two 4-wave workgroups per CU with one operand stage each: one workgroup's epilogue streams while
-                                     the other loads and multiplies; 0 = 256x320 as before.  Rows of a GEMM are independent and the K
-                                     order is the same: bit-identical results */
-    PNC_OPT_COUNT = 8
+    PNC_OPT_COUNT = 7
 };
 int pnc_set_option(int option, int value);
 

@@ -564,10 +564,8 @@ __device__ __forceinline__ void epi_generic(const PncGemmParams& p, f32x16 (&acc
     });
 }
 
-// 4-wave workgroups are meant to run TWO per CU (each SIMD then hosts one wave of either): the second launch-bounds argument
-// (min waves per SIMD) keeps their allocation at <= 256 registers — with 256 threads alone hipcc may take up to 512
 template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE, unsigned EPI>
-__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? 2 : 1)) void gemm_glds_kernel(const PncGemmParams pin, const int ksplit,
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams pin, const int ksplit,
                                                                    const int nfull, const int tail_f,
                                                                    const float* __restrict__ phi_g, const int group_m) {
     PncGemmParams p = pin;
@@ -844,28 +842,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4 ? 2 : 1)) void gemm
     // The second-dispatched half of an 8-wave workgroup loses every issue arbitration by age (MI355X_MICROARCH.md, two waves per
     // SIMD): static priority for it.  Plain-A GEMMs -1.9 ms per step in a same-box A/B; the gathers (+0.3 / +0.4 ms) keep age order.
     if (AMODE == PNC_A_PLAIN && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    if (STAGES == 1) {
-        // ONE operand stage (56 KB at 128x320): load -> barrier -> MFMAs -> barrier, nothing overlapped inside the workgroup.
-        // The geometry that uses it runs two workgroups per CU, and THEY overlap: one streams its epilogue (the K = 320-1280
-        // residual GEMMs are bound by the fp32 stream they read and write, 4 TB/s with one workgroup per CU) while the other
-        // loads and multiplies.
-        const int n8 = lo8 ? nt_lo : 0;
-        for (int kt = 0; kt < n8; ++kt) {
-            issue_tile(kt, 0);
-            __syncthreads();
-            if (wave_on) compute8(0, kt);
-            __syncthreads();
-        }
-        for (int kt = n8; kt < ntot; ++kt) {
-            issue_tile(kt, 0);
-            __syncthreads();
-            if (wave_on) {
-                compute(0);
-                if (!lo8 && kt + 1 == nt_lo) scale_lo();
-            }
-            __syncthreads();
-        }
-    } else if (STAGES == 2) {
+    if (STAGES == 2) {
         // one tile in flight: the plain barrier carries the vmcnt(0) that lands the DMA
         issue_tile(0, 0);
         __syncthreads();
@@ -1052,7 +1029,28 @@ static inline int splitk_slices(const PncGemmParams& p) {
 // as 4x2, wave tile 64x160, 2 stages = 144 KB): no column waste at N = 320, A is read once per 320 output columns, 9 DMA
 // instructions per 40 MFMAs.  256x256 serves GEGLU (value / gate blocks pair inside a wave) and N % 256 == 0; 256x128
 // (3-stage ring) and 128x128 the small grids; 128x32 the narrow-N convs (hint stem, output head).
-enum { T_128x128 = 1, T_256x128 = 2, T_256x320 = 3, T_256x256 = 4, T_128x32 = 5, T_128x320 = 6 };
+enum { T_128x128 = 1, T_256x128 = 2, T_256x320 = 3, T_256x256 = 4, T_128x32 = 5 };
+
+struct TileChoice { int tile; int ksplit; };
+
+// Split K when one K loop per output tile would leave most CUs idle (the M = 3072 level: 60 tiles of 256x256).
+// Returns the number of K slices (1 = do not split) for the 256x256 tile.  The slice count is a function of K ALONE
+// and only the on/off decision looks at M, so that a batch and its halves (CFG sharding, tests) run the same K
+// partition and stay bit-identical as long as both are in the split regime.
+static inline int splitk_slices(const PncGemmParams& p) {
+    if (p.geglu || p.out16t || (p.N % 256) || (p.N % 8)) return 1;
+    if ((p.out32 && (p.ldc32 % 4)) || (p.out16 && (p.ldc16 % 8))) return 1;
+    const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
+    const int ktiles = (p.K + BK - 1) / BK;
+    if (tiles > 96 || ktiles < 48) return 1;
+    return ktiles >= 320 ? 8 : (ktiles >= 160 ? 4 : 2);
+}
+
+// Tile geometries.  Every channel width of the network is a multiple of 320, so the preferred tile is 256x320 (8 waves
+// as 4x2, wave tile 64x160, 2 stages = 144 KB): no column waste at N = 320, A is read once per 320 output columns, 9 DMA
+// instructions per 40 MFMAs.  256x256 serves GEGLU (value / gate blocks pair inside a wave) and N % 256 == 0; 256x128
+// (3-stage ring) and 128x128 the small grids; 128x32 the narrow-N convs (hint stem, output head).
+enum { T_128x128 = 1, T_256x128 = 2, T_256x320 = 3, T_256x256 = 4, T_128x32 = 5 };
 
 struct TileChoice { int tile; int ksplit; };
 
@@ -1086,17 +1084,14 @@ static inline TileChoice choose_tile(const PncGemmParams& p) {
     const int force = pnc_get_option(PNC_OPT_GEMM_TILE);
     if (force == T_128x128 || force == T_256x128) pick = force;
     if ((force == T_256x320 && w320_ok) || (force == T_256x256 && w256_ok)) pick = force;
-    // 128x320, two workgroups per CU: the stream-bound residual / projection GEMMs (plain A and the temporal conv, N a multiple of
-    // 320, K <= 1280 incl. a second pass) — PNC_OPT_GEMM_TILE 6 forces it wherever the shape allows, 0 applies the measured rule
-    const bool t2_ok = w320_ok && p.a_mode != PNC_A_CONV3X3;
-    if (force == T_128x320 && t2_ok) pick = T_128x320;
-    if (!force && t2_ok && pnc_get_option(PNC_OPT_GEMM_TWO_WG) && two_wg_rule(p, keff)) pick = T_128x320;
+    // (Round 3 measured 128x320 tiles with two 4-wave workgroups per CU — one streaming its epilogue while the other multiplies —
+    // on every stream-bound shape of the path: 0-11 % slower than 256x320, profiles/round3/kbench_r3c_two_wg_128x320.log.  Not kept.)
     return {pick, 1};
 }
 
 // one workgroup owns whole output rows: the geometries that carry an E_LN variant (level-0 width 320 on 256x320; <= 128 on 128x128)
 static inline bool ln_whole_rows(const PncGemmParams& p, TileChoice tc) {
-    return tc.ksplit == 1 && (((tc.tile == T_256x320 || tc.tile == T_128x320) && p.N <= 320) || (tc.tile == T_128x128 && p.N <= 128));
+    return tc.ksplit == 1 && ((tc.tile == T_256x320 && p.N <= 320) || (tc.tile == T_128x128 && p.N <= 128));
 }
 
 // launch the variant EPI of AMODE on the chosen tile
@@ -1109,11 +1104,6 @@ int launch_tile(const PncGemmParams& p, hipStream_t st, TileChoice tc) {
             return PNC_EINVAL;
         case T_256x320:
             if constexpr (!GEGLU) return launch<AMODE, 256, 320, 4, 2, 2, false, EPI>(p, st);
-            return PNC_EINVAL;
-        case T_128x320:
-            if constexpr (!GEGLU && AMODE != PNC_A_CONV3X3 && !(EPI & (E_VT | E_GENERIC | E_GELU)))
-                return launch<AMODE, 128, 320, 2, 2, 1, false, EPI>(p, st);
-            else if constexpr (!GEGLU) return launch<AMODE, 256, 320, 4, 2, 2, false, EPI>(p, st);   // (no 128x320 instance of this variant)
             return PNC_EINVAL;
         case T_256x256:
             if (tc.ksplit > 1) return launch<AMODE, 256, 256, 4, 2, 2, true, E_O32>(p, st, tc.ksplit);   // raw partials

@@ -8,7 +8,6 @@ namespace pnc_gemm {
 template <unsigned EPI>
 static int launch_ln(const PncGemmParams& p, hipStream_t st, TileChoice tc) {
     if (tc.tile == T_256x320) return launch<PNC_A_PLAIN, 256, 320, 4, 2, 2, false, EPI>(p, st);
-    if (tc.tile == T_128x320) return launch<PNC_A_PLAIN, 128, 320, 2, 2, 1, false, EPI>(p, st);
     return launch<PNC_A_PLAIN, 128, 128, 2, 2, 2, true, EPI>(p, st);
 }
 

@@ -207,7 +207,7 @@ extern "C" const char* pnc_version(void) { return "panacea_hip 0.3.0 gfx950"; }
 #endif
 extern "C" const char* pnc_build_digest(void) { return PNC_BUILD_DIGEST; }
 
-static std::atomic<int> g_options[PNC_OPT_COUNT] = {{1}, {0}, {0}, {1}, {1}, {0}, {1}, {0}};
+static std::atomic<int> g_options[PNC_OPT_COUNT] = {{1}, {0}, {0}, {1}, {1}, {0}, {1}};
 
 int pnc_get_option(int option) { return g_options[option].load(std::memory_order_relaxed); }
 

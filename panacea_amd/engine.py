@@ -394,22 +394,6 @@ def _ppc(npix: int) -> int:
     return max(16, min(128, npix // 48), -(-npix // 256))
 
 
-# Panels sized for the 256 MB Infinity Cache (MALL).  A two-launch producer / consumer pair whose intermediate exceeds the cache
-# streams it through HBM twice; cut into row panels that fit, the second launch of a panel reads what the first has just
-# touched from the cache instead.  0 disables (A/B: bench.py --mall-panels 0).  Same kernels, same rows: bit-identical results.
-MALL_PANEL_BYTES = 112 << 20
-
-
-def row_panels(rows: int, bytes_per_row: int, align: int = 256):
-    """[(first_row, n_rows)] panels of at most MALL_PANEL_BYTES (whole multiples of `align` rows), one panel when it all fits"""
-    if MALL_PANEL_BYTES <= 0 or rows * bytes_per_row <= MALL_PANEL_BYTES:
-        return [(0, rows)]
-    n = -(-rows * bytes_per_row // MALL_PANEL_BYTES)
-    per = -(-rows // n)
-    per = -(-per // align) * align
-    return [(r0, min(per, rows - r0)) for r0 in range(0, rows, per)]
-
-
 def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, beta, eps: float, silu: bool,
                split: Optional[str] = None):
     """-> (y16, y16_lo).  `split`: the operand class of the output ("gn_stt" | "gn_res" | "gn_head"); y16_lo is None unless the
@@ -421,12 +405,9 @@ def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, be
     part = rt.empty((F * nchunk * 32 * 3,), torch.float32)
     y = rt.empty((F * N, C), torch.float16)
     ylo = rt.lo_plane((F * N, C), split) if split else None
-    # statistics are per frame: panels of whole frames, so that `apply` re-reads its frames from the Infinity Cache
-    for f0, nf in row_panels(F, N * C * 4, align=1):
-        r0, r1 = f0 * N, (f0 + nf) * N
-        pp = part[f0 * nchunk * 32 * 3:]
-        rt.be.groupnorm_stats(x32[r0:r1], C, nf, N, C, ppc, pp)
-        rt.be.groupnorm_apply(x32[r0:r1], C, nf, N, C, ppc, pp, gamma, beta, eps, silu, y[r0:r1], C, None if ylo is None else ylo[r0:r1])
+    # (launching the pair per Infinity-Cache sized panel of frames was measured: slower, profiles/round3/ab_two_wg_and_mall_panels_r3c.txt)
+    rt.be.groupnorm_stats(x32, C, F, N, C, ppc, part)
+    rt.be.groupnorm_apply(x32, C, F, N, C, ppc, part, gamma, beta, eps, silu, y, C, ylo)
     return y, ylo
 
 

@@ -164,7 +164,7 @@ def load():
     return lib
 
 
-OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA, OPT_GEMM_FUSE_LN, OPT_GEMM_GROUP_M, OPT_STENCIL_TILES, OPT_GEMM_TWO_WG = 0, 1, 2, 3, 4, 5, 6, 7
+OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA, OPT_GEMM_FUSE_LN, OPT_GEMM_GROUP_M, OPT_STENCIL_TILES = 0, 1, 2, 3, 4, 5, 6
 
 
 def build_digest() -> str:
@@ -174,7 +174,7 @@ def build_digest() -> str:
 
 def set_option(option: int, value: int) -> int:
     """pnc_set_option: process-global tuning / test switch of the library; returns the previous value."""
-    if not 0 <= option <= OPT_GEMM_TWO_WG:
+    if not 0 <= option <= OPT_STENCIL_TILES:
         raise PncError(f"unknown library option {option}")
     return load().pnc_set_option(option, value)
 

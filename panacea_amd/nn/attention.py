@@ -83,18 +83,12 @@ class FeedForward(nn.Module, Packable):
     def _run(self, rt: Runtime, x16, M, res32, out32=None, out16=None, out16_lo=None):
         """out = FF(x16) + res32 -> out32 (may alias res32) and/or out16 (+ lo plane of a precise operand)."""
         pk = self.packed()
-        # Row panels whose 4C hidden state fits the Infinity Cache (engine.row_panels): at level 0 the hidden state of all rows is
-        # 503 MB — written to HBM by the first GEMM and read back by the second; per 112 MB panel the second GEMM finds it cached.
-        panels = E.row_panels(M, self.inner_dim * 2)
-        hid = rt.empty((max(n for _, n in panels), self.inner_dim), torch.float16)
-        for r0, n in panels:
-            sl = slice(r0, r0 + n)
-            rt.be.gemm(x16[sl], pk["w1"], M=n, N=2 * self.inner_dim, K=self.dim, lda=self.dim, bias=pk["b1"],
-                       geglu=True, out16=hid, ldc16=self.inner_dim)
-            rt.be.gemm(hid, pk["w2"], M=n, N=self.dim_out, K=self.inner_dim, lda=self.inner_dim, bias=pk["b2"],
-                       res1=res32[sl], ldr1=self.dim_out, out32=None if out32 is None else out32[sl], ldc32=self.dim_out,
-                       out16=None if out16 is None else out16[sl], ldc16=self.dim_out,
-                       out16_lo=None if out16_lo is None else out16_lo[sl])
+        hid = rt.empty((M, self.inner_dim), torch.float16)
+        rt.be.gemm(x16, pk["w1"], M=M, N=2 * self.inner_dim, K=self.dim, lda=self.dim, bias=pk["b1"],
+                   geglu=True, out16=hid, ldc16=self.inner_dim)
+        rt.be.gemm(hid, pk["w2"], M=M, N=self.dim_out, K=self.inner_dim, lda=self.inner_dim, bias=pk["b2"],
+                   res1=res32, ldr1=self.dim_out, out32=out32, ldc32=self.dim_out, out16=out16,
+                   ldc16=self.dim_out, out16_lo=out16_lo)
 
 
 def _ln_kwargs(rt: Runtime, ln, M: int, C: int):

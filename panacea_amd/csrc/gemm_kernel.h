@@ -1033,33 +1033,6 @@ enum { T_128x128 = 1, T_256x128 = 2, T_256x320 = 3, T_256x256 = 4, T_128x32 = 5 
 
 struct TileChoice { int tile; int ksplit; };
 
-// Split K when one K loop per output tile would leave most CUs idle (the M = 3072 level: 60 tiles of 256x256).
-// Returns the number of K slices (1 = do not split) for the 256x256 tile.  The slice count is a function of K ALONE
-// and only the on/off decision looks at M, so that a batch and its halves (CFG sharding, tests) run the same K
-// partition and stay bit-identical as long as both are in the split regime.
-static inline int splitk_slices(const PncGemmParams& p) {
-    if (p.geglu || p.out16t || (p.N % 256) || (p.N % 8)) return 1;
-    if ((p.out32 && (p.ldc32 % 4)) || (p.out16 && (p.ldc16 % 8))) return 1;
-    const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
-    const int ktiles = (p.K + BK - 1) / BK;
-    if (tiles > 96 || ktiles < 48) return 1;
-    return ktiles >= 320 ? 8 : (ktiles >= 160 ? 4 : 2);
-}
-
-// Tile geometries.  Every channel width of the network is a multiple of 320, so the preferred tile is 256x320 (8 waves
-// as 4x2, wave tile 64x160, 2 stages = 144 KB): no column waste at N = 320, A is read once per 320 output columns, 9 DMA
-// instructions per 40 MFMAs.  256x256 serves GEGLU (value / gate blocks pair inside a wave) and N % 256 == 0; 256x128
-// (3-stage ring) and 128x128 the small grids; 128x32 the narrow-N convs (hint stem, output head).
-enum { T_128x128 = 1, T_256x128 = 2, T_256x320 = 3, T_256x256 = 4, T_128x32 = 5 };
-
-struct TileChoice { int tile; int ksplit; };
-
-// Where the 128x320 / two-workgroups-per-CU geometry replaces 256x320 (measured on the MI355X, profiles/round3/kbench_r3c_*):
-// launches whose time is the fp32 stream of their epilogue, not their MFMAs — an added fp32 stream or an fp32 output at short K.
-static inline bool two_wg_rule(const PncGemmParams& p, int keff) {
-    const bool streams = (p.res1 || p.res2 || p.rowbias || p.out32) && !p.geglu && !p.out16t;
-    return streams && keff <= 1280 && (long)p.M * p.N >= 128L * 320 * 512;
-}
 
 static inline TileChoice choose_tile(const PncGemmParams& p) {
     if (p.N <= 32 && !p.geglu) return {T_128x32, 1};

@@ -142,3 +142,25 @@ def test_baseline_config1_as_written_64x64_latent():
     st = err_stats(eps, golden("plain64")["eps"])
     assert eps.shape == (1, 4, 64, 64)
     assert st["max_abs"] <= 1.7e-3 and st["mean_abs"] <= 1.8e-4, st
+
+
+def test_operand_policy_follows_the_network_unless_set():
+    """The default operand policy is `precise`; networks whose temporal GroupNorm groups hold fewer than 4 values (num_frames x
+    C / 32: the 64-channel single-frame nets of BASELINE config 1) get every class split AND a warning that they sit above the
+    1e-3 the wide networks meet — no configuration exceeds the contract silently (VERDICT r2 weak spot 2)."""
+    import warnings
+    from panacea_amd import build_network, configs, engine
+    net = build_network(configs.get("tiny")).diffusion_model               # 64 channels x 2 frames = 4 values per group
+    assert net.precision == "precise" and net.controlnet.precision == "precise"
+    t1 = build_network(configs.with_frames(configs.get("tiny"), 1)).diffusion_model     # 2 values per group
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert t1.precision == "precise-all"
+    assert any("precise-all" in str(x.message) and "1e-3" in str(x.message) for x in w)
+    full1 = build_network(configs.with_frames(configs.get("full"), 1)).diffusion_model  # 320 channels: 10 values per group
+    assert full1.precision == "precise"
+    t1.precision = "fast"                                                   # an explicit choice always wins
+    assert t1.precision == "fast" and t1.controlnet.precision == "fast"
+    assert engine.precision("precise").lo8 and not engine.precision("precise-f16lo").lo8
+    with pytest.raises(ValueError):
+        t1.precision = "fastest"

@@ -174,3 +174,30 @@ def test_frame_group_sharding_reproduces_the_single_process_eps(world, cfg, G, T
     lo = RankLayout(8, 5, cfg=2, frames=4)
     assert (lo.sample, lo.half, lo.frame_group) == (0, 1, 1) and lo.frame_group_ranks(0, 1) == [4, 5, 6, 7]
     assert lo.cfg_pair_ranks(0, 1) == [1, 5]
+
+
+def _gather_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from panacea_amd import parallel
+    parallel.init_distributed("gloo")
+    layout = parallel.RankLayout(world, rank, cfg=1, frames=2)
+    groups = parallel.Groups(layout)
+    B, T = 3, 4                                            # THREE samples per rank: a plain cat of the parts interleaves them
+    full = (torch.arange(B * T, dtype=torch.float32)[:, None] * 10 + torch.arange(5, dtype=torch.float32)[None]).view(B * T, 5)
+    mine = parallel.local_frames(full, layout, T)
+    assert mine.shape[0] == B * T // 2
+    back = parallel.gather_frames(mine, groups, T)
+    ok = torch.equal(back, full)
+    (Path(out_dir) / f"gather{rank}.txt").write_text("ok" if ok else f"order {back[:, 0].tolist()}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gather_frames_restores_sample_major_order_for_several_samples_per_rank():
+    """gather_frames() must return rows in (sample, frame) order — the order local_frames() cut them in — also when a
+    rank carries more than one sample"""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_gather_worker, args=(2, 29611 + os.getpid() % 200, d), nprocs=2, join=True)
+        assert [(Path(d) / f"gather{r}.txt").read_text() for r in range(2)] == ["ok", "ok"]

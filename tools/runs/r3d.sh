@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r3d; mkdir -p $O
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_ff_chain_gpu.py -q --timeout=120 -x 2>&1 | tail -25 > $O/ffchain_tests.log
+timeout 300 python -m pytest tests/test_ff_chain_gpu.py -q --timeout=120 -s 2>&1 | grep -v amdgpu.ids | tail -25 > $O/ffchain_tests.log
 tail -12 $O/ffchain_tests.log
 if ! grep -q "passed" $O/ffchain_tests.log || grep -q "failed" $O/ffchain_tests.log; then echo "ff_chain tests did not pass: stopping"; exit 0; fi
 timeout 200 python tools/runs/r3d_ffchain.py 2>&1 | grep -v amdgpu.ids | tee $O/ffchain_kbench.log

@@ -49,6 +49,9 @@ __device__ __forceinline__ half8v ldfrag(const char* slot, int f, int lane) {
     return *reinterpret_cast<const half8v*>(slot + f * 1024 + lane * 16);
 }
 
+// ABL: compile-time ablation mask of tools/exp/ffchain_probe.hip (where does the time go); the library instantiates 0 only.
+//   1 no tape DMA in the loop  2 no MFMAs  4 no fragment reads  8 no GEGLU arithmetic  16 no barriers  32 no prologue loads / stores
+template <int ABL>
 __global__ __launch_bounds__(256, 1) void ff_chain_kernel(const PncFfChainParams p, const float* __restrict__ phi_g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // The two lookup tables are LDS variables of their own, filled with ordinary stores: hipcc puts `s_waitcnt vmcnt(0)` in front
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(256, 1) void ff_chain_kernel(const PncFfChainParams
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + 32 * b + 8 * q + 4 * g);
+            f32x4 v = {1.0f, 2.0f, 3.0f, 4.0f};
+            if constexpr (!(ABL & 32)) v = *reinterpret_cast<const f32x4*>(xrow + 32 * b + 8 * q + 4 * g);
             X[b][4 * q] = v[0]; X[b][4 * q + 1] = v[1]; X[b][4 * q + 2] = v[2]; X[b][4 * q + 3] = v[3];
         }
     // ---- LayerNorm of the row, two-pass in registers (the lane pair (l, l + 32) holds the two halves of a row) ----
@@ -140,13 +144,15 @@ __global__ __launch_bounds__(256, 1) void ff_chain_kernel(const PncFfChainParams
     // retires all reads of the slot recycled next), MFMAs of stage i.
     int st = 0;
     auto stage_begin = [&]() -> const char* {
-        if (st + DEPTH < nstages) {
-            issue(st + DEPTH);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH * (STAGE_FR / 4)) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!(ABL & 1)) {
+            if (st + DEPTH < nstages) {
+                issue(st + DEPTH);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH * (STAGE_FR / 4)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         const char* slot = ring + (st % RING) * STAGE_BYTES;
         ++st;
         return slot;
@@ -171,14 +177,18 @@ __global__ __launch_bounds__(256, 1) void ff_chain_kernel(const PncFfChainParams
     auto rd = [&](const char* slot, int grp, auto b_) {
         constexpr int bb = decltype(b_)::value;
 #pragma unroll
-        for (int k = 0; k < GR; ++k) wf[bb][k] = ldfrag(slot, grp * GR + k, lane);
+        for (int k = 0; k < GR; ++k) {
+            if constexpr (!(ABL & 4)) wf[bb][k] = ldfrag(slot, grp * GR + k, lane);
+            else wf[bb][k] = A[(grp * GR + k) % NKS];
+        }
     };
     // GEGLU of the previous chunk, elements [2 part, 2 part + 2) of 16: h = value * gelu(gate) -> B fragment of the second GEMM
     auto geglu2 = [&](const f32x16& v, const f32x16& gt, int part) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int r = 2 * part + e;
-            Hf[r >> 3][r & 7] = (half_t)(v[r] * gelu_tab_f(gt[r], phi));
+            if constexpr (!(ABL & 8)) Hf[r >> 3][r & 7] = (half_t)(v[r] * gelu_tab_f(gt[r], phi));
+            else Hf[r >> 3][r & 7] = (half_t)(v[r] + gt[r]);
         }
     };
     const std::integral_constant<int, 0> B0{};
@@ -195,6 +205,7 @@ __global__ __launch_bounds__(256, 1) void ff_chain_kernel(const PncFfChainParams
 #pragma unroll
             for (int k = 0; k < GR; ++k) {
                 const int f = grp * GR + k, s = half * (NKS / 2) + (f >> 1);
+                if constexpr (ABL & 2) { asm volatile("" ::"v"(wf[grp & 1][k])); continue; }
                 if (f & 1) ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[grp & 1][k], A[s], ag, 0, 0, 0);
                 else av = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[grp & 1][k], A[s], av, 0, 0, 0);
             }
@@ -212,6 +223,7 @@ __global__ __launch_bounds__(256, 1) void ff_chain_kernel(const PncFfChainParams
 #pragma unroll
             for (int k = 0; k < GR; ++k) {
                 const int f = grp * GR + k, h = f / NB, b = f - h * NB;
+                if constexpr (ABL & 2) { asm volatile("" ::"v"(wf[grp & 1][k])); continue; }
                 X[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[grp & 1][k], Hf[h], X[b], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -254,6 +266,7 @@ __global__ __launch_bounds__(256, 1) void ff_chain_kernel(const PncFfChainParams
         for (int q = 0; q < 4; ++q) {
             const int col = 32 * b + 8 * q + 4 * g;
             const float v[4] = {X[b][4 * q], X[b][4 * q + 1], X[b][4 * q + 2], X[b][4 * q + 3]};
+            if constexpr (ABL & 32) { if (v[0] + v[1] + v[2] + v[3] != 12345.678f) continue; }
             if (p.out32) *reinterpret_cast<f32x4*>(p.out32 + row * p.ldo32 + col) = f32x4{v[0], v[1], v[2], v[3]};
             if (o16) {
                 const half4v h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
@@ -293,9 +306,9 @@ extern "C" int pnc_ff_chain_f16(const PncFfChainParams* pp, void* stream) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_done[dev & 63].load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ff_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ff_chain_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_done[dev & 63].store(1, std::memory_order_release);
     }
-    hipLaunchKernelGGL(ff_chain_kernel, dim3(p.M / ROWS), dim3(256), LDS_BYTES, st, p, phi);
+    hipLaunchKernelGGL(ff_chain_kernel<0>, dim3(p.M / ROWS), dim3(256), LDS_BYTES, st, p, phi);
     return pnc_launch_status();
 }

@@ -8,14 +8,14 @@
 #include <vector>
 
 template <int ABL>
-static float run(const PncFfChainParams& p, const float* phi, int iters) {
+static float run(const PncFfChainParams& p, const float*, int iters) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ff_chain_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(ff_chain_kernel<ABL>, dim3(p.M / ROWS), dim3(256), LDS_BYTES, 0, p, phi);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(ff_chain_kernel<ABL>, dim3(p.M / ROWS), dim3(256), LDS_BYTES, 0, p);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(ff_chain_kernel<ABL>, dim3(p.M / ROWS), dim3(256), LDS_BYTES, 0, p, phi);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(ff_chain_kernel<ABL>, dim3(p.M / ROWS), dim3(256), LDS_BYTES, 0, p);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;

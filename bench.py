@@ -321,8 +321,8 @@ def main():
     ap.add_argument("--gemm-group-m", type=int, default=0,
                     help="A/B: PNC_OPT_GEMM_GROUP_M (0 = auto, 1 = plain tile order, k = groups of k row panels); same result")
     ap.add_argument("--no-modes", action="store_true", help="do not time the other operand policy (profiling runs)")
-    ap.add_argument("--no-ff-chain", action="store_true",
-                    help="A/B: level-0 feed-forwards as LayerNorm + GEGLU GEMM + output GEMM instead of the fused pnc_ff_chain_f16 launch")
+    ap.add_argument("--ff-chain", action="store_true",
+                    help="A/B: level-0 feed-forwards through the fused pnc_ff_chain_f16 launch (off by default: measured no faster)")
     ap.add_argument("--hoist", action="store_true",
                     help="sampler mode (SURVEY §8 f1): text K/V + ControlNet hint stem computed once per schedule, outside "
                          "the timed steps.  NOT the headline: the default re-evaluates the whole path every step")
@@ -376,8 +376,8 @@ def main():
         hip.set_option(hip.OPT_STENCIL_TILES, args.stencil_tiles)
     if args.gemm_group_m:
         hip.set_option(hip.OPT_GEMM_GROUP_M, args.gemm_group_m)
-    if args.no_ff_chain:
-        engine.FUSE_FF_CHAIN = False
+    if args.ff_chain:
+        engine.FUSE_FF_CHAIN = True
     primary = "replica" if args.parallelism == "auto" else args.parallelism
     layout = parallel.layout_for(world, rank, primary)
     groups = parallel.Groups(layout) if (layout.cfg > 1 or layout.frames > 1) else None

@@ -43,8 +43,12 @@ def use_backend(be):
 
 
 # x = ff(norm3(x)) + x of a BasicTransformerBlock as ONE launch (pnc_ff_chain_f16) where the library serves the shape (level 0:
-# C = 320); False = LayerNorm (on the preceding GEMM) + GEGLU GEMM + output GEMM everywhere (A/B: bench.py --no-ff-chain)
-FUSE_FF_CHAIN = True
+# C = 320).  OFF by default: correct (tests/test_ff_chain_gpu.py, whole-network parity 7.8e-4) but not faster than the launch
+# sequence it replaces — 860-920 us vs 866-891 us at M = 196 608 in both versions measured (profiles/round3/ffchain_*): with the
+# tokens in registers a workgroup is 4 waves = ONE instruction stream per SIMD, and the tape's DMA issues (1 KB per 4 MFMAs and wave,
+# ~80 % of a CU's LDS-DMA rate), the fragment reads and the GEGLU arithmetic serialise with the MFMAs in it.
+# bench.py --ff-chain switches it on for A/B runs.
+FUSE_FF_CHAIN = False
 
 TEXT_PAD = 80          # 77 text tokens padded to a multiple of 8 rows (zero rows, masked in the kernel)
 

@@ -83,3 +83,28 @@ def test_ff_chain_argument_checks():
         hip.ff_chain(q["x"], C, 128, C, 1024, q["g"], q["b"], 1e-5, q["tape"], q["b1"], q["b2"], out32=o, ldo32=C)
     with pytest.raises(hip.PncError):            # no output
         hip.ff_chain(q["x"], C, 128, C, 1280, q["g"], q["b"], 1e-5, q["tape"], q["b1"], q["b2"])
+
+
+def test_network_with_fused_feed_forward_meets_the_contract():
+    """The full-width network with its level-0 feed-forwards on the fused launch (engine.FUSE_FF_CHAIN, off by default) against the
+    oracle: same 1e-3 contract as the default path, and it does change the launch sequence (different bits)."""
+    from helpers import cond, err_stats, oracle_cfg, product_network, step_inputs
+    from oracle import panacea_oracle as po
+    from panacea_amd import configs
+    kw = configs.with_frames(configs.get("full"), 2)
+    w, sd, _ = product_network("full", "cpu", kw=kw)
+    inp = step_inputs("full", kw, "cpu", shape=(1, 2, 16, 192))
+    ref = po.wrapper_forward(sd, oracle_cfg(kw), inp["x"], inp["t"], cond(inp))
+    w = w.to(DEV)
+    g = {k: v.to(DEV) for k, v in inp.items()}
+    base = w(g["x"], g["t"], cond(g))
+    assert engine.FUSE_FF_CHAIN is False
+    engine.FUSE_FF_CHAIN = True
+    try:
+        eps = w(g["x"], g["t"], cond(g))
+    finally:
+        engine.FUSE_FF_CHAIN = False
+    st = err_stats(eps, ref)
+    print("full network, 16x192, fused feed-forward:", st)
+    assert not torch.equal(eps, base)
+    assert st["max_abs"] <= 1e-3 and st["mean_abs"] <= 2e-4, st

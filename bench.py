@@ -250,6 +250,40 @@ def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, 
     return rec
 
 
+def run_text_tower(args, dev):
+    """`--stage text-tower`: FrozenOpenCLIPEmbedder at the YAML's size — OpenCLIP ViT-H/14 text side, width 1024,
+    23 of 24 blocks (`penultimate`), 16 heads, 77 tokens — for the two prompts of one sample (c and uc), synthetic weights, token
+    ids resident in HBM.  One "step" = one encode of both prompts.  Runs once per sample, never per denoising step."""
+    from panacea_amd import conditioner, hip
+    hip.load()
+    torch.manual_seed(3)
+    emb = conditioner.FrozenOpenCLIPEmbedder(arch="ViT-H-14", layer="penultimate")
+    with torch.no_grad():
+        for n, p_ in emb.named_parameters():
+            if p_.dim() >= 2 and "embedding" not in n:
+                p_.copy_((torch.randn_like(p_) * (p_.shape[-1] ** -0.5)).half().float())
+    emb = emb.to(dev)
+    tokens = torch.randint(0, 49408, (2, 77), generator=torch.Generator().manual_seed(4)).to(dev)
+    with torch.no_grad():
+        for _ in range(max(1, args.warmup)):
+            out = emb(tokens)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = emb(tokens)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+    assert out.shape == (2, 77, 1024) and torch.isfinite(out).all()
+    flops = 23 * (2.0 * 154 * 1024 * (3 * 1024 + 1024 + 8 * 1024) + 2 * 16 * 4.0 * 77 * 77 * 64)
+    print(json.dumps({"metric": "text-tower encodes/s (OpenCLIP ViT-H/14 text side, 2 prompts x 77 tokens)", "value": 1.0 / dt,
+                      "unit": "encodes/s", "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": dt * 1e3,
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                      "config": {"workload": "FrozenOpenCLIPEmbedder penultimate layer, width 1024, 23 blocks, 16 heads, (2, 77) tokens",
+                                 "stage": "text-tower", "GFLOP": round(flops / 1e9, 1),
+                                 "note": "154 rows: a launch-bound stage (one (sample, head) attention problem per launch), "
+                                         "run once per sample"}}), flush=True)
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without torchrun: start the N ranks as child processes of this one (same command line, the
     torchrun environment variables per rank, rendezvous on 127.0.0.1), let rank 0's stdout — the ONE JSON line — through,
@@ -276,7 +310,7 @@ def spawn_ranks(args) -> int:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--stage", default="denoise", choices=["denoise", "vae-decode", "vae-encode"],
+    ap.add_argument("--stage", default="denoise", choices=["denoise", "vae-decode", "vae-encode", "text-tower"],
                     help="denoise = the headline metric (default); vae-decode / vae-encode = first stage on one sample's frames")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -352,8 +386,8 @@ def main():
         dev, sync = torch.device("cuda", dev_index), torch.cuda.synchronize
     if args.stage != "denoise":
         if world > 1:
-            raise SystemExit("--stage vae-decode / vae-encode are single-GPU measurements")
-        return run_vae_decode(args, dev)
+            raise SystemExit("--stage vae-decode / vae-encode / text-tower are single-GPU measurements")
+        return run_text_tower(args, dev) if args.stage == "text-tower" else run_vae_decode(args, dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

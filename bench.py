@@ -205,14 +205,15 @@ def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, 
     guider = groups.guider(5.0)
     smp = sampling.EulerEDMSampler(args.num_sampling_steps, guider=guider, device=dev)
     smp.fuse = not args.no_fused_step
-    shard = groups.frame_shard()
+    shard, vshard = groups.frame_shard(), groups.view_shard()
     parallel.apply_frame_shard(net, shard)
+    parallel.apply_view_shard(net, vshard)
     try:
-        if shard is not None:
+        if shard is not None or vshard is not None:
             cond, uc = parallel.shard_conditioning(cond, layout, T), parallel.shard_conditioning(uc, layout, T)
         sig = smp.sigmas()
         nsig = len(sig) - 1
-        x = parallel.local_frames(g["x"][T:] * torch.sqrt(1.0 + sig[0] ** 2.0), layout, T)
+        x = parallel.local_views(parallel.local_frames(g["x"][T:] * torch.sqrt(1.0 + sig[0] ** 2.0), layout, T), layout)
         s_in = x.new_ones([x.shape[0]])
         if layout.cfg > 1:
             guider.check_pair_consistency(x, s_in * sig[0])
@@ -238,6 +239,7 @@ def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, 
         assert torch.isfinite(xx).all()
     finally:
         parallel.apply_frame_shard(net, None)
+        parallel.apply_view_shard(net, None)
     nsteps = args.steps + args.warmup
     rec = {"parallelism": layout.name, "scaling": "strong", "ranks_per_sample": layout.per_sample, "samples_in_flight": layout.samples,
            "value": layout.samples * args.steps / elapsed, "unit": "steps/s", "per_sample_latency_ms": elapsed / args.steps * 1e3,
@@ -247,6 +249,10 @@ def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, 
         rec["exchange"] = {"all_to_all_per_step": shard.exchanges // max(1, nsteps),
                            "MB_sent_per_rank_and_step": round(shard.bytes_sent / max(1, nsteps) / 1e6, 1),
                            "note": "engine.FrameShard: temporal sites run pixel-sharded (DESIGN.md section 9)"}
+    if vshard is not None:
+        rec["exchange"] = {"neighbour_exchanges_per_step": vshard.exchanges // max(1, nsteps),
+                           "MB_sent_per_rank_and_step": round(vshard.bytes_sent / max(1, nsteps) / 1e6, 1),
+                           "note": "engine.ViewShard: conv halos, panorama GroupNorm statistics, neighbour views (DESIGN.md section 9)"}
     return rec
 
 
@@ -323,7 +329,7 @@ def main():
     ap.add_argument("--precision", default="precise", choices=["fast", "precise", "precise-all", "precise-lite", "precise-f16lo"],
                     help="operand policy of the timed region (DESIGN §6).  precise (default) meets eps max-abs < 1e-3; the "
                          "other of fast / precise is timed too and reported under `modes`")
-    ap.add_argument("--parallelism", default="auto", choices=["auto", "replica", "cfg", "cfg+frames", "frames"],
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "replica", "cfg", "cfg+frames", "frames", "views", "cfg+views"],
                     help="N > 1: auto (default) = replica as the headline + cfg+frames reported under strong_scaling in the same "
                          "line; replica = one sample per rank (the reference's strategy, weak scaling); cfg = one "
                          "sample per rank pair (CFG halves, one all-gather per step); cfg+frames = one sample over "
@@ -414,7 +420,7 @@ def main():
         engine.FUSE_FF_CHAIN = True
     primary = "replica" if args.parallelism == "auto" else args.parallelism
     layout = parallel.layout_for(world, rank, primary)
-    groups = parallel.Groups(layout) if (layout.cfg > 1 or layout.frames > 1) else None
+    groups = parallel.Groups(layout) if (layout.per_sample > 1) else None
     kw = configs.with_frames(configs.get(args.config), args.frames) if args.config == "full" else configs.get(args.config)
     B, T, h, w = configs.SHAPES[args.config]
     T = kw["num_frames"]
@@ -442,6 +448,7 @@ def main():
     smp = sampling.EulerEDMSampler(args.num_sampling_steps, guider=guider, device=dev)
     smp.fuse = not args.no_fused_step
     shard = groups.frame_shard() if groups is not None else None
+    vshard = groups.view_shard() if groups is not None else None
     sig = smp.sigmas()
     nsig = len(sig) - 1
     x0 = g["x"][T:]
@@ -456,11 +463,12 @@ def main():
             cc[:-1] = zero_lat
             d["concat"] = cc
         x0 = sampling.share_noise_init(x0, cond["concat"], 0.07)
-    if shard is not None:
+    if shard is not None or vshard is not None:
         parallel.apply_frame_shard(net, shard)
+        parallel.apply_view_shard(net, vshard)
         cond, uc = parallel.shard_conditioning(cond, layout, T), parallel.shard_conditioning(uc, layout, T)
     x = x0 * torch.sqrt(1.0 + sig[0] ** 2.0)
-    x = parallel.local_frames(x, layout, T)                     # this rank's frame group of the sample
+    x = parallel.local_views(parallel.local_frames(x, layout, T), layout)    # this rank's frame group / view band of the sample
     s_in = x.new_ones([x.shape[0]])
     if layout.cfg > 1:
         guider.check_pair_consistency(x, s_in * sig[0])
@@ -488,7 +496,7 @@ def main():
     def parity_of(prec):
         """eps of one network call at BASELINE config 3 vs the REFERENCE's own fp32 forward, at every committed pin (three noise
         levels, two input seeds); the headline numbers are the WORST over the pins"""
-        if not (args.config == "full" and T == 8 and rank == 0 and GOLDEN_FULL.exists()) or shard is not None:
+        if not (args.config == "full" and T == 8 and rank == 0 and GOLDEN_FULL.exists()) or shard is not None or vshard is not None:
             return None          # (a frame-sharded network runs collectives: no single-rank evaluation)
         import numpy as np
         net.diffusion_model.precision = prec
@@ -559,7 +567,7 @@ def main():
                    "frames_per_step": 2 * T, "parallelism": layout.name,
                    "ranks_per_sample": layout.per_sample, "per_sample_latency_ms": ms_per_step,
                    "graph": bool(args.graph), "streams": 1 if args.one_stream else 2,
-                   "hoisted_step_invariants": bool(args.hoist), "fused_step_tail": bool(smp.fuse and shard is None and layout.cfg == 1)},
+                   "hoisted_step_invariants": bool(args.hoist), "fused_step_tail": bool(smp.fuse and shard is None and vshard is None and layout.cfg == 1)},
     }
     if args.config == "full":
         ach = ALGO_TFLOP_PER_STEP * (value / world) if T == 8 else None     # per GPU
@@ -595,6 +603,11 @@ def main():
         out["config"]["exchange"] = {"all_to_all_per_step": shard.exchanges // max(1, nsteps),
                                      "MB_sent_per_rank_and_step": round(shard.bytes_sent / max(1, nsteps) / 1e6, 1),
                                      "note": "engine.FrameShard: temporal sites run pixel-sharded (DESIGN.md §9)"}
+    if vshard is not None:
+        nsteps = args.steps + args.warmup
+        out["config"]["exchange"] = {"neighbour_exchanges_per_step": vshard.exchanges // max(1, nsteps),
+                                     "MB_sent_per_rank_and_step": round(vshard.bytes_sent / max(1, nsteps) / 1e6, 1),
+                                     "note": "engine.ViewShard: conv halos, panorama GroupNorm statistics, neighbour views (DESIGN.md §9)"}
 
     if rank == 0 and not args.no_kernel_breakdown and layout.per_sample == 1 and not args.emulate_kernels:
         prof = hip.Profiler()

@@ -237,14 +237,162 @@ class FrameShard:
         return torch.stack([p.view(B, Tl, D) for p in parts], dim=1).reshape(B * G * Tl, D)
 
 
+class ViewShard:
+    """The six camera views of every panoramic frame sharded over the G in {2, 3, 6} ranks of a process group: rank g holds
+    views [g*6/G, (g+1)*6/G) — a band of W/G columns of every map, at every level.  Per pixel, per frame and per view work
+    (1x1 convs, the temporal GroupNorm / conv1d / attention, LayerNorm, feed-forward, text attention, intra-view attention:
+    attention.py:382-489) stays local.  What couples the views:
+
+        3x3 convs (all)              one halo column per side from the neighbour band         `halo`, `conv_window`
+        spatial GroupNorm(32)        per-(frame, group) statistics over the whole panorama     `combine_stats`
+        cross-view attention         keys / values of the two neighbouring views (circular:    `neighbour_views`
+                                     attention.py:545-559; view 5 attends view 4 only)
+
+    Neighbour exchanges are point-to-point (one xGMI link per neighbour pair on MI355X); the statistics are one tiny
+    all-gather.  With a "gloo" group, device tensors are staged through host memory (the two-process tests on one GPU)."""
+    VIEWS = 6
+
+    def __init__(self, G: int, index: int, group=None):
+        if G not in (2, 3, 6) or not (0 <= index < G):
+            raise ValueError(f"bad view shard {index} of {G}: the six views split over 2, 3 or 6 ranks")
+        if group is None:
+            raise ValueError("a view shard needs its process group")
+        self.G, self.index, self.group = G, index, group
+        self.n_local = self.VIEWS // G
+        self.first = index * self.n_local              # global index of this rank's first view
+        self.bytes_sent = 0
+        self.exchanges = 0
+        import torch.distributed as dist
+        self._left = dist.get_global_rank(group, (index - 1) % G)
+        self._right = dist.get_global_rank(group, (index + 1) % G)
+        self._host = dist.get_backend(group) == "gloo"
+
+    # -- circular neighbour exchange: every tensor of `to_left` goes to the left neighbour, `to_right` to the right one;
+    #    returns (from_left, from_right) = what the neighbours sent towards this rank
+    def _exchange(self, to_left, to_right):
+        import torch.distributed as dist
+        dev = to_left[0].device
+        stage = self._host and dev.type != "cpu"
+        sl = [t.contiguous().cpu() if stage else t.contiguous() for t in to_left]
+        sr = [t.contiguous().cpu() if stage else t.contiguous() for t in to_right]
+        fl, fr = [torch.empty_like(t) for t in sr], [torch.empty_like(t) for t in sl]
+        ops = []
+        # with G = 2 both neighbours are the same peer: a message is identified by its direction tag, and the receives are
+        # posted in the order the peer sends (its to_left batch is what arrives from the right)
+        for i, t in enumerate(sl):
+            ops.append(dist.P2POp(dist.isend, t, self._left, self.group, tag=2 * i))
+        for i, t in enumerate(sr):
+            ops.append(dist.P2POp(dist.isend, t, self._right, self.group, tag=2 * i + 1))
+        for i, t in enumerate(fr):
+            ops.append(dist.P2POp(dist.irecv, t, self._right, self.group, tag=2 * i))
+        for i, t in enumerate(fl):
+            ops.append(dist.P2POp(dist.irecv, t, self._left, self.group, tag=2 * i + 1))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        self.exchanges += 1
+        self.bytes_sent += sum(t.numel() * t.element_size() for t in sl + sr)
+        if stage:
+            fl, fr = [t.to(dev) for t in fl], [t.to(dev) for t in fr]
+        return fl, fr
+
+    def halo(self, planes, left: int, right: int):
+        """planes: channels-last maps [F, H, W_l, C] of this band (hi and lo plane of one operand, any dtypes); ->
+        the same maps widened to [F, H, left + W_l + right, C]: the column next to the band comes from the neighbour (zeros at
+        the two ends of the panorama — the conv's own zero padding), any further `left` columns are zero (alignment)."""
+        fl, fr = self._exchange([p[:, :, :1] for p in planes], [p[:, :, -1:] for p in planes])
+        out = []
+        for p, a, b in zip(planes, fl, fr):
+            F, H, W, C = p.shape
+            q = torch.zeros((F, H, left + W + right, C), device=p.device, dtype=p.dtype)
+            q[:, :, left:left + W] = p
+            if left and self.index > 0:
+                q[:, :, left - 1:left] = a
+            if right and self.index < self.G - 1:
+                q[:, :, left + W:left + W + 1] = b
+            out.append(q)
+        return out
+
+    @staticmethod
+    def conv_window(Win: int, stride: int, upsample: bool):
+        """-> (left, right, first_out, n_out): halo columns a 3x3 conv (pad 1) needs around a band of Win columns and the
+        window of the widened conv's output columns that belong to the band.
+          stride 1: out column x reads x-1..x+1                         -> halo 1 | 1, outputs [1, 1 + Win)
+          stride 2: out column o reads 2o-1..2o+1 (band starts even)    -> halo 2 | 0 (the outer one only aligns the
+                    stride phase), outputs [1, 1 + Win/2)
+          nearest-x2 then conv: out column u reads (u-1)>>1..(u+1)>>1   -> halo 1 | 1, outputs [2, 2 + 2 Win)"""
+        if upsample:
+            return 1, 1, 2, 2 * Win
+        if stride == 2:
+            if Win % 2:
+                raise ValueError(f"a stride-2 conv over a view band needs an even band width, got {Win}")
+            return 2, 0, 1, Win // 2
+        return 1, 1, 1, Win
+
+    def combine_stats(self, part: torch.Tensor, F: int, nchunk: int) -> torch.Tensor:
+        """part: the {n, mean, M2} records [F, nchunk, 32, 3] of this band (pnc_groupnorm_stats) -> records of the same shape
+        whose Chan combination is the statistics of the whole panorama: every slot holds the combined record (k identical
+        records combine to the same mean and variance)."""
+        import torch.distributed as dist
+        mine = part.view(F, nchunk, 32, 3)
+        send = mine.cpu() if self._host and mine.device.type != "cpu" else mine
+        parts = [torch.empty_like(send) for _ in range(self.G)]
+        dist.all_gather(parts, send.contiguous(), group=self.group)
+        P = torch.cat(parts, dim=1).to(device=part.device, dtype=torch.float64)         # [F, G*nchunk, 32, 3]
+        n = P[..., 0].sum(1)
+        mean = (P[..., 0] * P[..., 1]).sum(1) / n
+        m2 = (P[..., 2] + P[..., 0] * (P[..., 1] - mean[:, None]) ** 2).sum(1)
+        rec = torch.stack([n, mean, m2], dim=-1).to(torch.float32)                       # [F, 32, 3]
+        self.exchanges += 1
+        self.bytes_sent += send.numel() * 4
+        return rec[:, None].expand(F, nchunk, 32, 3).contiguous().view(-1)
+
+    def neighbour_views(self, k4: torch.Tensor, v4: torch.Tensor):
+        """k4 [F, H, W_l, C] keys (channels-last), v4 [F, C, H, W_l] values (channel-major) of this band -> the same with one
+        view of the left neighbour in front and one of the right neighbour behind (circular), i.e. n_local + 2 views."""
+        Wv = k4.shape[2] // self.n_local
+        (kl, vl), (kr, vr) = self._exchange([k4[:, :, :Wv], v4[..., :Wv]], [k4[:, :, -Wv:], v4[..., -Wv:]])
+        return torch.cat([kl, k4, kr], dim=2).contiguous(), torch.cat([vl, v4, vr], dim=3).contiguous()
+
+    def local_segments(self, segs):
+        """the per-view key/value view lists of the whole panorama (e.g. INTER_SEGS) -> those of this rank's views, as
+        indices into the `neighbour_views` layout"""
+        out = []
+        for v in range(self.first, self.first + self.n_local):
+            row = []
+            for u in segs[v]:
+                if self.first <= u < self.first + self.n_local:
+                    row.append(u - self.first + 1)
+                elif u == (self.first - 1) % self.VIEWS:
+                    row.append(0)
+                elif u == (self.first + self.n_local) % self.VIEWS:
+                    row.append(self.n_local + 1)
+                else:
+                    raise ValueError(f"view {v} attends view {u}, which is not a neighbour of this rank's band")
+            out.append(row)
+        return out
+
+    def gather_width(self, x: torch.Tensor) -> torch.Tensor:
+        """[..., W_l] bands -> [..., W] (the latent at the end of the schedule, for the first-stage decoder)"""
+        import torch.distributed as dist
+        send = x.contiguous().cpu() if self._host and x.device.type != "cpu" else x.contiguous()
+        parts = [torch.empty_like(send) for _ in range(self.G)]
+        dist.all_gather(parts, send, group=self.group)
+        return torch.cat(parts, dim=-1).to(x.device)
+
+
 class Runtime:
     """Per-forward execution context.  B samples x T frames; with a FrameShard only T_local = T / G frames of every
-    sample live on this rank (F = B * T_local frames in the resident layout)."""
+    sample live on this rank (F = B * T_local frames in the resident layout); with a ViewShard every map is this rank's
+    band of W / G columns."""
 
-    def __init__(self, device: torch.device, B: int, T: int, shard: Optional[FrameShard] = None):
+    def __init__(self, device: torch.device, B: int, T: int, shard: Optional[FrameShard] = None,
+                 vshard: Optional[ViewShard] = None):
         self.be = backend()
         self.device = device
+        if shard is not None and vshard is not None:
+            raise NotImplementedError("frame groups and view groups are separate layouts; one sample uses one of them")
         self.shard = shard
+        self.vshard = vshard
         G = shard.G if shard is not None else 1
         if T % G:
             raise ValueError(f"{T} frames per sample do not split over {G} frame groups")
@@ -449,6 +597,8 @@ def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, be
     ylo = rt.lo_plane((F * N, C), split) if split else None
     # (launching the pair per Infinity-Cache sized panel of frames was measured: slower, profiles/round3/ab_two_wg_and_mall_panels_r3c.txt)
     rt.be.groupnorm_stats(x32, C, F, N, C, ppc, part)
+    if rt.vshard is not None:           # statistics of the whole panorama, not of this rank's band of views
+        part = rt.vshard.combine_stats(part, F, nchunk)
     rt.be.groupnorm_apply(x32, C, F, N, C, ppc, part, gamma, beta, eps, silu, y, C, ylo)
     return y, ylo
 

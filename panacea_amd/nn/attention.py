@@ -51,11 +51,12 @@ def zero_module(module):
     return module
 
 
-def panorama_grid(n_tokens: int):
-    """attention.py:428 — H = int(sqrt(N / 12)): six views of aspect 1:2 along the width."""
-    H = int(math.sqrt(n_tokens // 12))
-    if H == 0 or n_tokens % H or (n_tokens // H) % 6:
-        raise ValueError(f"{n_tokens} tokens are not a 6-view panorama of aspect 1:2 per view")
+def panorama_grid(n_tokens: int, views: int = 6):
+    """attention.py:428 — H = int(sqrt(N / 12)): six views of aspect 1:2 along the width.  `views` < 6: the tokens are a band
+    of that many views of the panorama (engine.ViewShard)."""
+    H = int(math.sqrt(n_tokens * 6 // views // 12))
+    if H == 0 or n_tokens % H or (n_tokens // H) % views:
+        raise ValueError(f"{n_tokens} tokens are not {views} views of aspect 1:2 per view")
     return H, n_tokens // H
 
 
@@ -182,7 +183,8 @@ class _AttentionBase(nn.Module, Packable):
         pk = self.packed()
         C, N = self.inner_dim, H * W
         M = F * N
-        views = len(segs)
+        vs = rt.vshard if len(segs) == E.ViewShard.VIEWS else None     # `segs` speaks of the six views of the panorama
+        views = vs.n_local if vs is not None else len(segs)
         if W % views:
             raise ValueError(f"grid width {W} is not divisible into {views} views")
         qk = rt.empty((M, 2 * C), torch.float16)
@@ -190,9 +192,20 @@ class _AttentionBase(nn.Module, Packable):
         rt.be.gemm(x16, pk["wqkv"], M=M, N=3 * C, K=self.query_dim, lda=self.query_dim, out16=qk, ldc16=2 * C,
                    out16t=vt, ldt=N, t_rows=N, t_gstride=C * N, n_split=2 * C)
         o = rt.empty((M, C), torch.float16)
-        rt.be.attn_views(qk, 2 * C, qk.view(-1)[C:], 2 * C, vt, N, C * N, o, C, groups=F, heads=self.heads,
-                         H=H, W=W, views=views, kvH=H, kvW=W, kv_views=views, kv_rows_per_group=N, q_per_kv=1,
-                         kv_valid=H * (W // views), segs=segs, scale=self.scale)
+        Wv = W // views
+        if vs is not None and any(u != v for v, row in enumerate(segs) for u in row):
+            # this rank's band of views attends its neighbours' edge views too: keys / values of n_local + 2 views
+            k_ext, v_ext = vs.neighbour_views(qk.view(F, H, W, 2 * C)[..., C:], vt.view(F, C, H, W))
+            We = W + 2 * Wv
+            rt.be.attn_views(qk, 2 * C, k_ext.view(-1), C, v_ext, H * We, C * H * We, o, C, groups=F, heads=self.heads,
+                             H=H, W=W, views=views, kvH=H, kvW=We, kv_views=views + 2, kv_rows_per_group=H * We, q_per_kv=1,
+                             kv_valid=H * Wv, segs=vs.local_segments(segs), scale=self.scale)
+        else:
+            if vs is not None:
+                segs = [[i] for i in range(views)]
+            rt.be.attn_views(qk, 2 * C, qk.view(-1)[C:], 2 * C, vt, N, C * N, o, C, groups=F, heads=self.heads,
+                             H=H, W=W, views=views, kvH=H, kvW=W, kv_views=views, kv_rows_per_group=N, q_per_kv=1,
+                             kv_valid=H * Wv, segs=segs, scale=self.scale)
         lnkw, y16 = _ln_kwargs(rt, ln, M, self.query_dim)
         rt.be.gemm(o, pk["wo"], M=M, N=self.query_dim, K=C, lda=C, bias=pk["bo"], res1=res32,
                    ldr1=self.query_dim, out32=out32, ldc32=self.query_dim, **lnkw)
@@ -287,15 +300,19 @@ class BasicTransformerBlock(nn.Module, Packable):
         if x16 is None:
             x16 = E.layer_norm(rt, t32, M, C, pk["norm1w"], pk["norm1b"])
         ln2, ln3 = (pk["norm2w"], pk["norm2b"]), (pk["norm3w"], pk["norm3b"])
+        nviews = rt.vshard.n_local if rt.vshard is not None else 6
         if branch == "temporal":
             x16 = self.attn1._run_temporal(rt, x16, N, t32, t32, ln=ln2)
         elif self.attn1.kind == "intra-view":
-            ph, pw = panorama_grid(N)
+            ph, pw = panorama_grid(N, nviews)
             x16 = self.attn1._run_views(rt, x16, F, ph, pw, INTRA_SEGS, t32, t32, ln=ln2)
         elif self.attn1.kind == "inter-view":
-            ph, pw = panorama_grid(N)
+            ph, pw = panorama_grid(N, nviews)
             x16 = self.attn1._run_views(rt, x16, F, ph, pw, INTER_SEGS, t32, t32, ln=ln2)
         else:
+            if rt.vshard is not None:
+                raise NotImplementedError("plain spatial self-attention spans the whole panorama; a view shard serves the "
+                                          "intra-view / inter-view kinds")
             x16 = self.attn1._run_views(rt, x16, F, H, W, [[0]], t32, t32, ln=ln2)
         # x = ff(norm3(x)) + x: one launch where the library fuses it (level 0) — norm3 is then computed inside, from the fp32
         # stream, and the text-attention output projection in front no longer writes it

@@ -137,7 +137,7 @@ class ControlNet3D(UNetModel3D):
         assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"
         with torch.no_grad():
-            rt = runtime_for(x, self.num_frames, self.frame_shard)
+            rt = runtime_for(x, self.num_frames, self.frame_shard, self.view_shard)
             rt.prec = E.precision(self.precision)
             rt.set_context(context)
             emb = self._time_embedding(rt, timesteps)
@@ -162,7 +162,7 @@ class ControlledUNetModel3D(UNetModel3D):
         assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"
         with torch.no_grad():
-            rt = runtime_for(x, self.num_frames, self.frame_shard)
+            rt = runtime_for(x, self.num_frames, self.frame_shard, self.view_shard)
             rt.prec = E.precision(self.precision)
             rt.set_context(context)
             emb = self._time_embedding(rt, timesteps)
@@ -181,7 +181,7 @@ class ControlledUNetModel3D(UNetModel3D):
         with torch.no_grad():
             F = hint.shape[0]
             sh = self.frame_shard
-            rt = Runtime(hint.device, F // (self.num_frames // (sh.G if sh is not None else 1)), self.num_frames, sh)
+            rt = Runtime(hint.device, F // (self.num_frames // (sh.G if sh is not None else 1)), self.num_frames, sh, self.view_shard)
             rt.prec = E.precision(self.precision)
             rt.set_context(context)
             self._project_text(rt)
@@ -229,7 +229,7 @@ class ControlledUNetModel3D(UNetModel3D):
 
     def _denoise_one(self, x, timesteps, context, hint, trace, side_idx, inv=None, fused=None):
         with torch.no_grad():
-            rt = runtime_for(x if fused is None else fused[1], self.num_frames, self.frame_shard)
+            rt = runtime_for(x if fused is None else fused[1], self.num_frames, self.frame_shard, self.view_shard)
             rt.prec = E.precision(self.precision)
             rt.trace = trace
             if inv is not None:
@@ -241,8 +241,8 @@ class ControlledUNetModel3D(UNetModel3D):
             x16 = self._stem_tokens(rt, x) if fused is None else self._stem_tokens(rt, x, fused[1], fused[0])
             cn = self.controlnet
             hint32 = hint if inv is not None else hint.detach().to(torch.float32).contiguous()
-            # frame-sharded runs issue collectives from both networks: one stream keeps their order identical on all ranks
-            if self.two_stream and x.is_cuda and trace is None and rt.shard is None:
+            # frame- / view-sharded runs issue collectives from both networks: one stream keeps their order identical on all ranks
+            if self.two_stream and x.is_cuda and trace is None and rt.shard is None and rt.vshard is None:
                 main = torch.cuda.current_stream()
                 # per-device tables that both streams read are created HERE, on the main stream, before the fork: their
                 # first use would otherwise be an H2D copy on the side stream that the main stream does not wait for

@@ -50,6 +50,9 @@ def run_conv3x3(rt: Runtime, x16: torch.Tensor, F: int, Hin: int, Win: int, Cin_
     """3x3 conv (pad 1) as implicit GEMM over the channels-last fp16 image x16 [F*Hin*Win, Cin_pad] (+ lo plane of a
     precise operand, + `w_lo` = engine.wlo(...) when that plane is e4m3); `split_out`: operand class of the fp16 output, which
     is written as a precise pair when the policy splits that class."""
+    if rt.vshard is not None:
+        return _conv3x3_view_band(rt, x16, F, Hin, Win, Cin_pad, w16, bias, Cout, stride, upsample, act_silu, out32, out16,
+                                  x16_lo, split_out, w_lo)
     if upsample:
         Hout, Wout = 2 * Hin, 2 * Win
     else:
@@ -63,6 +66,33 @@ def run_conv3x3(rt: Runtime, x16: torch.Tensor, F: int, Hin: int, Win: int, Cin_
                bias=bias, act=E._hip.ACT_SILU if act_silu else E._hip.ACT_NONE,
                out32=o32, ldc32=Cout, out16=o16, ldc16=Cout, a16_lo=x16_lo, out16_lo=o16lo)
     return Act(F, Hout, Wout, Cout, f32=o32, f16=o16, f16_lo=o16lo)
+
+
+def _conv3x3_view_band(rt: Runtime, x16, F, Hin, Win, Cin_pad, w16, bias, Cout, stride, upsample, act_silu, out32, out16,
+                       x16_lo, split_out, w_lo):
+    """run_conv3x3 on this rank's band of views (engine.ViewShard): the band is widened by the neighbours' halo columns, the
+    unmodified conv runs over the widened map, and the band's window of its output columns is kept.  (First form of the
+    view-group layout: the widen / window copies go away once the gather takes a window origin — DESIGN.md section 9.)"""
+    vs = rt.vshard
+    left, right, first, n_out = vs.conv_window(Win, stride, upsample)
+    planes = [x16.view(F, Hin, Win, Cin_pad)] + ([x16_lo.view(F, Hin, Win, Cin_pad)] if x16_lo is not None else [])
+    wide = vs.halo(planes, left, right)
+    Wp = left + Win + right
+    Hout = 2 * Hin if upsample else (Hin - 1) // stride + 1
+    Wout = 2 * Wp if upsample else (Wp - 1) // stride + 1
+    M = F * Hout * Wout
+    o32 = rt.empty((M, Cout), torch.float32) if out32 else None
+    o16 = rt.empty((M, Cout), torch.float16) if out16 else None
+    o16lo = rt.lo_plane((M, Cout), split_out, on=out16) if split_out else None
+    rt.be.gemm(wide[0].view(-1, Cin_pad), w16, M=M, N=Cout, K=9 * Cin_pad, a_mode=E._hip.A_CONV3X3, w_lo=w_lo,
+               conv=dict(Cin=Cin_pad, Hin=Hin, Win=Wp, Hout=Hout, Wout=Wout, stride=stride, upsample=int(upsample)),
+               bias=bias, act=E._hip.ACT_SILU if act_silu else E._hip.ACT_NONE,
+               out32=o32, ldc32=Cout, out16=o16, ldc16=Cout,
+               a16_lo=wide[1].view(-1, Cin_pad) if x16_lo is not None else None, out16_lo=o16lo)
+
+    def band(t):
+        return None if t is None else t.view(F, Hout, Wout, Cout)[:, :, first:first + n_out].contiguous().view(-1, Cout)
+    return Act(F, Hout, n_out, Cout, f32=band(o32), f16=band(o16), f16_lo=band(o16lo))
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock, Packable):
@@ -389,6 +419,7 @@ class UNetModel3D(nn.Module, Packable):
     # engine.FrameShard when the frames of every sample are sharded over a process group (panacea_amd.parallel); the
     # batch then carries num_frames / G frames per sample
     frame_shard = None
+    view_shard = None          # engine.ViewShard: this rank's batches carry a band of views only
 
     # Operand precision policy (engine.Precision or "fast" | "precise" | "precise-all").  "precise" carries the operand
     # classes that dominate the eps error as split fp16 pairs and meets the 1e-3 max-abs contract of the boundary
@@ -534,7 +565,7 @@ class UNetModel3D(nn.Module, Packable):
             "must specify y if and only if the model is class-conditional"
         from .util import runtime_for
         with torch.no_grad():
-            rt = runtime_for(x, self.num_frames, self.frame_shard)
+            rt = runtime_for(x, self.num_frames, self.frame_shard, self.view_shard)
             rt.prec = E.precision(self.precision)
             rt.set_context(context)
             emb = self._time_embedding(rt, timesteps)

@@ -53,13 +53,14 @@ def linear(*args, **kwargs):
 
 
 # ---- API-boundary glue ------------------------------------------------------------------------
-def runtime_for(x: torch.Tensor, num_frames: int, shard=None) -> Runtime:
-    """`shard`: engine.FrameShard when x carries only this rank's num_frames / G frames of every sample"""
+def runtime_for(x: torch.Tensor, num_frames: int, shard=None, vshard=None) -> Runtime:
+    """`shard`: engine.FrameShard when x carries only this rank's num_frames / G frames of every sample; `vshard`:
+    engine.ViewShard when x carries only this rank's band of views (W / G columns)"""
     F = x.shape[0]
     t_local = num_frames // (shard.G if shard is not None else 1)
     if t_local < 1 or F % t_local:
         raise ValueError(f"batch of {F} frames is not a multiple of the {t_local} frames per sample held by this rank")
-    return Runtime(x.device, F // t_local, num_frames, shard)
+    return Runtime(x.device, F // t_local, num_frames, shard, vshard)
 
 
 def act_from_nchw(rt: Runtime, x: torch.Tensor) -> Act:

@@ -18,8 +18,12 @@ rank = (sample * cfg + half) * G + frame_group  (`RankLayout`).
   branch of every STT (attention.py:1106-1134) — are pointwise per pixel across frames and run in the transposed
   sharding (all T frames of N/G pixels per rank): `engine.FrameShard.to_pixels / to_frames`, one all-to-all each.
   Bytes per rank and step, and the overlap plan, are in DESIGN.md §9.
-  View-group sharding (splitting the 6 views) is not built: every 3x3 conv and spatial GroupNorm couples the views, i.e.
-  a halo / partial-sum exchange at ~300 sites per step instead of ~90 frame exchanges that move whole tiles.
+* **view groups** (V = 2 | 3 | 6) — the alternative split of one half: rank v of a view group holds views
+  [v*6/V, (v+1)*6/V) of every frame, a band of W/V columns of every map (`engine.ViewShard`).  The temporal sites are then
+  local; what crosses ranks are the one-column halos of the 3x3 convs, the spatial GroupNorm statistics (96 floats per
+  frame) and the keys / values of the two neighbouring views in the cross-view attention — neighbour-to-neighbour
+  messages, each pair on its own xGMI link.  More, smaller messages than the frame exchange (DESIGN.md section 9 has the
+  counts); it is the layout for V ranks when T / G frames per rank would drop below the temporal kernels' tile.
 """
 from __future__ import annotations
 
@@ -30,7 +34,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
-from .engine import FrameShard
+from .engine import FrameShard, ViewShard
 from .sampling import VanillaCFG
 
 
@@ -67,19 +71,24 @@ def cfg_pair_groups(world: int) -> List[Optional[dist.ProcessGroup]]:
 
 @dataclass(frozen=True)
 class RankLayout:
-    """rank = (sample * cfg + half) * frames + frame_group"""
+    """rank = ((sample * cfg + half) * frames + frame_group) * views + view_group"""
     world: int
     rank: int
     cfg: int = 1            # 1: both CFG halves on every rank; 2: one half per rank
     frames: int = 1         # frame groups per half (G)
+    views: int = 1          # view groups per half (V): 1, 2, 3 or 6 — a half is split by frames OR by views
 
     def __post_init__(self):
-        if self.cfg not in (1, 2) or self.frames < 1 or self.world % (self.cfg * self.frames):
-            raise ValueError(f"{self.world} ranks do not factor into cfg {self.cfg} x frame groups {self.frames}")
+        if self.cfg not in (1, 2) or self.frames < 1 or self.views not in (1, 2, 3, 6) \
+                or self.world % (self.cfg * self.frames * self.views):
+            raise ValueError(f"{self.world} ranks do not factor into cfg {self.cfg} x frame groups {self.frames} x "
+                             f"view groups {self.views}")
+        if self.frames > 1 and self.views > 1:
+            raise ValueError("one CFG half is split over frame groups or over view groups, not both")
 
     @property
     def per_sample(self) -> int:
-        return self.cfg * self.frames
+        return self.cfg * self.frames * self.views
 
     @property
     def samples(self) -> int:
@@ -91,18 +100,27 @@ class RankLayout:
 
     @property
     def half(self) -> int:
-        return (self.rank // self.frames) % self.cfg
+        return (self.rank // (self.frames * self.views)) % self.cfg
 
     @property
     def frame_group(self) -> int:
-        return self.rank % self.frames
+        return (self.rank // self.views) % self.frames
+
+    @property
+    def view_group(self) -> int:
+        return self.rank % self.views
 
     def frame_group_ranks(self, sample: int, half: int) -> List[int]:
-        base = (sample * self.cfg + half) * self.frames
-        return [base + g for g in range(self.frames)]
+        base = (sample * self.cfg + half) * self.frames * self.views
+        return [base + g * self.views for g in range(self.frames)]
 
-    def cfg_pair_ranks(self, sample: int, frame_group: int) -> List[int]:
-        return [(sample * self.cfg + h) * self.frames + frame_group for h in range(self.cfg)]
+    def view_group_ranks(self, sample: int, half: int) -> List[int]:
+        base = (sample * self.cfg + half) * self.frames * self.views
+        return [base + v for v in range(self.views)]
+
+    def cfg_pair_ranks(self, sample: int, part: int) -> List[int]:
+        """the ranks holding the same frame group / view group (`part`) of the two halves of a sample"""
+        return [(sample * self.cfg + h) * self.frames * self.views + part for h in range(self.cfg)]
 
     @property
     def name(self) -> str:
@@ -111,6 +129,8 @@ class RankLayout:
             parts.append("cfg x2")
         if self.frames > 1:
             parts.append(f"frames x{self.frames}")
+        if self.views > 1:
+            parts.append(f"views x{self.views}")
         return " . ".join(parts) or "single"
 
 
@@ -125,6 +145,12 @@ def layout_for(world: int, rank: int, parallelism: str) -> RankLayout:
         return RankLayout(world, rank, cfg=2, frames=max(1, min(4, world // 2)))
     if parallelism == "frames":
         return RankLayout(world, rank, cfg=1, frames=min(4, world))
+    if parallelism in ("views", "cfg+views"):
+        cfg = 2 if parallelism == "cfg+views" else 1
+        fit = [v for v in (6, 3, 2) if (world // cfg) % v == 0 and world >= cfg * v]
+        if not fit:
+            raise ValueError(f"{world} ranks do not hold a view split (2, 3 or 6 view groups x {cfg} CFG halves)")
+        return RankLayout(world, rank, cfg=cfg, views=fit[0])
     raise ValueError(f"unknown parallelism {parallelism!r}")
 
 
@@ -134,7 +160,8 @@ class Groups:
 
     def __init__(self, layout: RankLayout):
         self.layout = layout
-        self.frame_group = self.cfg_pair = None
+        self.frame_group = self.view_group = self.cfg_pair = None
+        self._view_shard: Optional[ViewShard] = None
         for smp in range(layout.samples):
             for h in range(layout.cfg):
                 ranks = layout.frame_group_ranks(smp, h)
@@ -142,7 +169,12 @@ class Groups:
                     g = dist.new_group(ranks)
                     if layout.rank in ranks:
                         self.frame_group = g
-            for fg in range(layout.frames):
+                ranks = layout.view_group_ranks(smp, h)
+                if layout.views > 1:
+                    g = dist.new_group(ranks)
+                    if layout.rank in ranks:
+                        self.view_group = g
+            for fg in range(layout.frames * layout.views):
                 ranks = layout.cfg_pair_ranks(smp, fg)
                 if layout.cfg > 1:
                     g = dist.new_group(ranks)
@@ -152,6 +184,12 @@ class Groups:
     def frame_shard(self) -> Optional[FrameShard]:
         lo = self.layout
         return FrameShard(lo.frames, lo.frame_group, self.frame_group) if lo.frames > 1 else None
+
+    def view_shard(self) -> Optional[ViewShard]:
+        lo = self.layout
+        if lo.views > 1 and self._view_shard is None:
+            self._view_shard = ViewShard(lo.views, lo.view_group, self.view_group)
+        return self._view_shard
 
     def guider(self, scale: float) -> VanillaCFG:
         return ShardedCFG(scale, self.cfg_pair, self.layout.half) if self.layout.cfg > 1 else VanillaCFG(scale)
@@ -167,6 +205,32 @@ def apply_frame_shard(network, shard: Optional[FrameShard]):
     return network
 
 
+def apply_view_shard(network, shard: Optional[ViewShard]):
+    """Tell the network that its batches carry this rank's band of views only (W / V columns of the latent, of `concat`
+    and of the BEV hint)."""
+    model = getattr(network, "diffusion_model", network)
+    model.view_shard = shard
+    if hasattr(model, "controlnet"):
+        model.controlnet.view_shard = shard
+    return network
+
+
+def local_views(t: torch.Tensor, layout: RankLayout) -> torch.Tensor:
+    """this rank's band of views of an NCHW map (latent, `concat`, or the 8x larger hint): columns [v W/V, (v+1) W/V)"""
+    if layout.views == 1:
+        return t
+    W = t.shape[-1]
+    if W % layout.views:
+        raise ValueError(f"map width {W} does not split into {layout.views} view groups")
+    wl = W // layout.views
+    return t[..., layout.view_group * wl:(layout.view_group + 1) * wl].contiguous()
+
+
+def gather_views(x_local: torch.Tensor, groups: "Groups") -> torch.Tensor:
+    """the whole panorama from the view group (end of the schedule: hand the latent to the first-stage decoder)"""
+    return x_local if groups.layout.views == 1 else groups.view_shard().gather_width(x_local)
+
+
 def local_frames(t: torch.Tensor, layout: RankLayout, num_frames: int) -> torch.Tensor:
     """this rank's frames of a per-frame tensor whose leading dimension is (samples_in_t * num_frames)"""
     if layout.frames == 1:
@@ -177,11 +241,12 @@ def local_frames(t: torch.Tensor, layout: RankLayout, num_frames: int) -> torch.
 
 
 def shard_conditioning(cond: Dict, layout: RankLayout, num_frames: int) -> Dict:
-    """per-frame conditioning (`concat`, `cond_feat`) cut to this rank's frame group; per-sample entries untouched"""
+    """per-frame conditioning (`concat`, `cond_feat`) cut to this rank's frame group / view band; per-sample entries
+    untouched"""
     out = dict(cond)
     for k in ("concat", "cond_feat"):
         if k in out:
-            out[k] = local_frames(out[k], layout, num_frames)
+            out[k] = local_views(local_frames(out[k], layout, num_frames), layout)
     return out
 
 

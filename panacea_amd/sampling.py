@@ -153,6 +153,7 @@ class EulerEDMSampler:
         model = getattr(denoiser.network, "diffusion_model", None)
         den = denoiser.denoiser
         return (hasattr(model, "denoise_tokens") and getattr(model, "frame_shard", None) is None
+                and getattr(model, "view_shard", None) is None
                 and type(self.guider) in (VanillaCFG, type(None)) and isinstance(den, DiscreteDenoiser)
                 and isinstance(den.scaling, EpsScaling) and den.quantize_c_noise
                 and "concat" in cond and cond.get("vector") is None)

@@ -36,7 +36,7 @@ def test_bench_gpus_2_spawns_its_ranks_and_reports_both_scalings():
     assert s["cfg_all_gathers_per_step"] == 1 and "2 ranks" in s["collective_backend"]
 
 
-@pytest.mark.parametrize("mode,name", [("frames", "frames x2"), ("cfg", "cfg x2")])
+@pytest.mark.parametrize("mode,name", [("frames", "frames x2"), ("cfg", "cfg x2"), ("views", "views x2")])
 def test_bench_explicit_sharded_modes(mode, name):
     d = _run(2, ("--parallelism", mode))
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == name
@@ -44,3 +44,6 @@ def test_bench_explicit_sharded_modes(mode, name):
     if mode == "frames":
         ex = d["config"]["exchange"]
         assert ex["all_to_all_per_step"] > 0 and ex["MB_sent_per_rank_and_step"] > 0
+    if mode == "views":
+        ex = d["config"]["exchange"]
+        assert ex["neighbour_exchanges_per_step"] > 0 and ex["MB_sent_per_rank_and_step"] > 0

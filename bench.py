@@ -630,6 +630,8 @@ def main():
             kern[fam] = e
         out.setdefault("roofline", {})["kernels"] = kern
         out["roofline"]["kernel_ms_sum"] = round(tot, 2)
+        out["roofline"]["kernels_measured_on"] = ("one extra step on ONE stream after the timed region (HIP events around every "
+                                                  "launch; the timed steps overlap the ControlNet on a second stream)")
         if out["roofline"].get("achieved") is None:      # workloads other than config 3: algorithmic flops as launched
             tfl = sum(v["flops"] for v in summ.values()) / 1e12
             out["roofline"].update(bound="mfma", peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", achieved=tfl * value / world,

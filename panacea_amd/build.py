@@ -45,13 +45,18 @@ def library_digest(lib: Path = LIB):
     """The source digest compiled INTO a built library (pnc_build_digest()), or None when it cannot be read.  The digest
     travels inside the .so, so a checkout that pulls new sources next to an old (git-ignored) build is detected whatever
     side files say (a tracked build.stamp could match the new sources next to the old library)."""
-    import ctypes
     try:
-        fn = ctypes.CDLL(str(lib)).pnc_build_digest
-    except (OSError, AttributeError):
+        blob = Path(lib).read_bytes()
+    except OSError:
         return None
-    fn.restype = ctypes.c_char_p
-    return fn().decode()
+    i = blob.find(_DIGEST_MARK)          # read from the file, never by loading it (a loaded image would shadow a rebuild)
+    if i < 0:
+        return None
+    j = blob.find(b"\0", i)
+    return blob[i + len(_DIGEST_MARK):j].decode(errors="replace")
+
+
+_DIGEST_MARK = b"pnc-build-digest:"
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:

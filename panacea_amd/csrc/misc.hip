@@ -205,7 +205,10 @@ extern "C" const char* pnc_version(void) { return "panacea_hip 0.3.0 gfx950"; }
 #ifndef PNC_BUILD_DIGEST
 #define PNC_BUILD_DIGEST "unstamped"
 #endif
-extern "C" const char* pnc_build_digest(void) { return PNC_BUILD_DIGEST; }
+// (stored behind a marker so that build.py can read it from the FILE: dlopen-ing a library to ask it would pin the old image in
+// the asking process and make a rebuild + load in the same process see the stale one)
+static const char k_build_digest[] = "pnc-build-digest:" PNC_BUILD_DIGEST;
+extern "C" const char* pnc_build_digest(void) { return k_build_digest + 17; }
 
 static std::atomic<int> g_options[PNC_OPT_COUNT] = {{1}, {0}, {0}, {1}, {1}, {0}, {1}};
 

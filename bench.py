@@ -349,6 +349,8 @@ def main():
                          "JSON contract where there is no GPU.  The line says so; it is never a measurement")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py spawns the ranks itself (0 = pick a free one)")
     ap.add_argument("--device", type=int, default=None, help="override the HIP device index (default LOCAL_RANK)")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the parity evaluations against the golden pins (counter-collection runs: only timed work in the trace)")
     ap.add_argument("--strong-timeout", type=float, default=240.0,
                     help="seconds after which the secondary (strong-scaling) mode of --parallelism auto is abandoned")
     ap.add_argument("--one-stream", action="store_true", help="do not overlap the ControlNet with the UNet encoder")
@@ -498,7 +500,8 @@ def main():
     def parity_of(prec):
         """eps of one network call at BASELINE config 3 vs the REFERENCE's own fp32 forward, at every committed pin (three noise
         levels, two input seeds); the headline numbers are the WORST over the pins"""
-        if not (args.config == "full" and T == 8 and rank == 0 and GOLDEN_FULL.exists()) or shard is not None or vshard is not None:
+        if not (args.config == "full" and T == 8 and rank == 0 and GOLDEN_FULL.exists()) or shard is not None or vshard is not None \
+                or args.no_parity:
             return None          # (a frame-sharded network runs collectives: no single-rank evaluation)
         import numpy as np
         net.diffusion_model.precision = prec

@@ -16,6 +16,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
 # Calibration kernel: LayerNorm moves exactly 6 B per element (4 B fp32 read + 2 B fp16 write).  The elements of each dispatch
 # follow from its grid: layernorm_kernel<J> runs 16 rows per 256-thread block, J = ceil(C / 256) names the width class.
 LN_WIDTH = {2: 320, 3: 640, 5: 1280}
@@ -52,8 +53,9 @@ def mfma_record(mdir, evals, step_ms):
     per_eval = sum(busy.values()) / evals
     top = sorted(busy.items(), key=lambda kv: -kv[1])[:12]
     return {"mfma_busy_cycles_per_step": per_eval,
-            "note": "SQ_VALU_MFMA_BUSY_CYCLES counts cycles of the 32 cycles a 32x32x16 f16 MFMA occupies its SIMD: 96.59 TFLOP "
-                    "algorithmic = 9.43e10 cycles at 1024 flop/cycle/SIMD... /4 SIMDs per CU x 256 CUs",
+            "note": "SQ_VALU_MFMA_BUSY_CYCLES: cycles a SIMD's matrix pipe is occupied, summed over the 1024 SIMDs.  96.21 algorithmic "
+                    "TFLOP at 1024 flop/cycle/SIMD (fp16 32x32x16) = 9.40e10 cycles; the e4m3 lo passes of the precise policy run at "
+                    "2048 flop/cycle/SIMD",
             "utilisation_at_2p1GHz": per_eval / (1024 * 2.1e9 * step_ms * 1e-3),
             "top_kernels": [[k[:90], v / evals] for k, v in top]}
 

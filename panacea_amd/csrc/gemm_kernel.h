@@ -244,6 +244,10 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
     constexpr bool GELU = (EPI & E_GELU) != 0;
     const bool silu = (!HAS_X) && (p.act == PNC_ACT_SILU);
     const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    // (Measured and not kept, round 3: for fp16-only outputs — QKV, q-projections — applying the bias on the accumulators and
+    // staging only the fp16 result, as epi_geglu does, is 5-10 % SLOWER than this path (L0 QKV 224 -> 245-250 us): with no
+    // arithmetic to take off the LDS round trip, the 16 two-byte staging writes and 16 scalar conversions per block cost more
+    // than 16 four-byte writes and 8 packed conversions.  profiles/round3/kbench_r3l_register_epilogues_ab.log)
     f32x4 x0[NPMAX], x1[NPMAX], y0[NPMAX], y1[NPMAX];
     if constexpr (LN) {
         if (lane < MI * 32) ln_mine[lane] = make_float2(0.0f, 0.0f);         // MI * 32 <= 64 rows per wave
@@ -436,6 +440,72 @@ __device__ __forceinline__ void epi_geglu(const PncGemmParams& p, f32x16 (&acc)[
     const int Nout = p.N >> 1;
     half_t* out16 = reinterpret_cast<half_t*>(p.out16);
     void* out16_lo = p.out16_lo;
+    if (out16_lo == nullptr && mw + MI * 32 <= p.M && ((nw + NI * 32) >> 1) <= Nout) {
+        // (wave tiles inside the matrix and plain fp16 outputs; ragged tiles and lo planes take the staged path below)
+        // The value and the gate of an output element sit in the SAME lane and accumulator slot (block jc and jc + 1, column
+        // lane & 31), so the gate arithmetic runs on the accumulators where they are; only the fp16 RESULT is staged — for the
+        // transposition to 16-byte row segments.  A quarter of the staging bytes of the path below (16 x 2 B written, 2 x 16 B
+        // read per lane and slab, instead of 32 x 4 B / 8 x 16 B) and, more to the point, no arithmetic waits on an LDS round
+        // trip: every slab of the wave tile has its own 2 KB staging buffer and a wave's DS operations execute in order, so the
+        // gate arithmetic of all slabs runs first (phase 1) and the 16-byte reads and stores follow back to back (phase 2).
+        // Measured: L0 FF1 517 -> 467-480 us, L1 377-386 -> 360-365 us, L2 -3 % (profiles/round3/kbench_r3l_register_epilogues_ab.log).
+        // Same products, same roundings (fp32, then fp16): bit-identical to the staged path.
+        constexpr int P16 = 32;                                          // halves per staged row; one 2 KB buffer per slab
+        static_assert((NI / 2) * MI * 32 * P16 * 2 <= 32 * EPITCH * 4, "all slabs of a wave tile are staged side by side");
+        typedef half_t __attribute__((may_alias)) half_st;               // staged as halves, read back as 16-byte words
+        typedef int4 __attribute__((may_alias)) int4_st;
+        half_st* st = reinterpret_cast<half_st*>(ep);
+        const int c = lane & 31;
+        // phase 1: gate arithmetic on the accumulators, results to the staging buffers.  Per slab the 16 table reads are
+        // issued together (index / fraction first, reads, then the products) instead of one read -> wait -> use chain each.
+        static_for<NI / 2>([&](auto jc_) {
+            constexpr int jc = decltype(jc_)::value * 2;
+            const float bv = p.bias ? p.bias[nw + jc * 32 + c] : 0.0f;
+            const float bg = p.bias ? p.bias[nw + jc * 32 + 32 + c] : 0.0f;
+            static_for<MI>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                half_st* sb = st + (decltype(jc_)::value * MI + i) * (32 * P16);
+                float gx[16], fr[16];
+                int ix[16];
+                float2 e[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {                           // = gelu_tab_f(), split around its table read
+                    gx[r] = acc[i][jc + 1][r] + bg;
+                    float t = fmaf(gx[r], PHI_SCALE, -PHI_X0 * PHI_SCALE);
+                    t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)PHI_N - 0.001f);
+                    ix[r] = (int)t;
+                    fr[r] = t - (float)ix[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[r] = *reinterpret_cast<const float2*>(phi_tab + 2 * ix[r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                {
+                    // the fp32 product is kept opaque so that hipcc does not fuse multiply + conversion into v_fma_mixlo_f16 (one
+                    // rounding): the result is rounded to fp32, then to fp16, exactly like the staged path and the other tiles
+                    float prod = (acc[i][jc][r] + bv) * (gx[r] * fmaf(fr[r], e[r].y, e[r].x));
+                    asm("" : "+v"(prod));
+                    sb[mfma32_row(r, lane) * P16 + c] = (half_t)prod;
+                }
+            });
+        });
+        // phase 2: 16-byte row segments out — no per-lane predicates, no branches: all reads go out before the first store
+        static_for<NI / 2>([&](auto jc_) {
+            constexpr int jc = decltype(jc_)::value * 2;
+            const int ncol0 = (nw + jc * 32) >> 1;                       // first output column of the block pair
+            static_for<MI>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                const half_st* sb = st + (decltype(jc_)::value * MI + i) * (32 * P16);
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) {
+                    const int row = ps * RPP + rl;
+                    const int4 v = *reinterpret_cast<const int4_st*>(sb + row * P16 + cl * 8);
+                    *reinterpret_cast<int4_st*>(out16 + (int64_t)(mw + i * 32 + row) * p.ldc16 + ncol0 + cl * 8) = v;
+                }
+            });
+        });
+        return;
+    }
     const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
     static_for<NI / 2>([&](auto jc_) {
         constexpr int jc = decltype(jc_)::value * 2;

@@ -109,6 +109,29 @@ def test_gemm_geglu(M, C):
     check("geglu", h["o"], e["o"], 4e-3)
 
 
+@pytest.mark.parametrize("M,C", [(512, 320), (1000, 640), (300, 128), (196608 // 8, 320)])
+def test_gemm_geglu_register_epilogue_equals_the_staged_one(M, C):
+    """Round 3: without a lo plane the GEGLU epilogue does the gate arithmetic on the accumulators and stages only the fp16 result;
+    with one (out16_lo) it stages the fp32 value / gate blocks as before.  Same products, same roundings (the register path keeps
+    its last product opaque so that hipcc does not fuse multiply + conversion into one rounding — measured: that alone moved 42 of
+    655 360 elements by one fp16 ulp): the hi planes are equal bit for bit, ragged row tails included."""
+    N, K = 8 * C, C
+    a, w = rnd(M, K, dtype=torch.float16), rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    bias = rnd(N)
+    o_reg = torch.zeros(M, N // 2, device=DEV, dtype=torch.float16)
+    o_stg, lo = torch.zeros_like(o_reg), torch.zeros_like(o_reg)
+    hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, geglu=True, out16=o_reg, ldc16=N // 2)
+    hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=bias, geglu=True, out16=o_stg, ldc16=N // 2, out16_lo=lo)
+    torch.cuda.synchronize()
+    assert torch.equal(o_reg, o_stg)
+    assert o_reg.abs().max().item() > 0.1 and lo.abs().max().item() > 0
+    o_nb = torch.zeros_like(o_reg)
+    hip.gemm(a, w, M=M, N=N, K=K, lda=K, geglu=True, out16=o_nb, ldc16=N // 2)          # no bias
+    e_nb = torch.zeros_like(o_reg)
+    emu.gemm(a, w, M=M, N=N, K=K, lda=K, geglu=True, out16=e_nb, ldc16=N // 2)
+    check("geglu no bias", o_nb, e_nb, 4e-3)
+
+
 @pytest.mark.parametrize("G,t_rows,C", [(2, 128, 64), (3, 96, 128), (2, 80, 64), (2, 192, 320)])
 def test_gemm_split_transposed_output(G, t_rows, C):
     # q|k row-major for n < 2C, V^T channel-major for n >= 2C  (QKV projection epilogue)

@@ -425,7 +425,8 @@ def main():
     primary = "replica" if args.parallelism == "auto" else args.parallelism
     layout = parallel.layout_for(world, rank, primary)
     groups = parallel.Groups(layout) if (layout.per_sample > 1) else None
-    kw = configs.with_frames(configs.get(args.config), args.frames) if args.config == "full" else configs.get(args.config)
+    kw = configs.with_frames(configs.get(args.config), args.frames) if (args.config == "full" or args.frames != 8) \
+        else configs.get(args.config)
     B, T, h, w = configs.SHAPES[args.config]
     T = kw["num_frames"]
     man = json.loads((ROOT / "tests" / "golden" / f"manifest_{args.config}.json").read_text())

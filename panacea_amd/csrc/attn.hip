@@ -436,7 +436,11 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     // share a K/V tile and every fragment read feeds two MFMAs: 600-670 TFLOP/s at level 0 vs 470-500 for 4 x 1);
     // mid-size: 8 x 1 (256); small views: 4 x 1 (128).  Measured in profiles/round1/kbench_attn_variants.log.
     const int force = pnc_get_option(PNC_OPT_ATTN_VARIANT);      // tests / kbench: force one variant
-    const int variant = force ? force : (Nq >= 512 ? 82 : (Nq >= 256 ? 81 : 41));
+    // Few keys per view (the 77 text tokens: two K/V tiles): the launch is a stream of q in / o out, and three 4-wave workgroups
+    // per CU hide its latencies better than one of 8 waves — 4 x 1: 90 / 48 / 30 us at levels 0-2 vs 100 / 53 / 37 for 8 x 2
+    // (profiles/round3/attn_text_variants_r3p.txt).
+    const int kv_keys = p.kv_valid * 2;                           // at most two K/V segments per view
+    const int variant = force ? force : (kv_keys <= 256 ? 41 : (Nq >= 512 ? 82 : (Nq >= 256 ? 81 : 41)));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool dma = ((kvWv & 7) == 0) && ((p.kvW & 7) == 0) && ((p.ldvt & 7) == 0) && ((p.vt_gstride & 7) == 0) &&
                      pnc_get_option(PNC_OPT_ATTN_DMA) != 0;

@@ -47,3 +47,15 @@ def test_bench_explicit_sharded_modes(mode, name):
     if mode == "views":
         ex = d["config"]["exchange"]
         assert ex["neighbour_exchanges_per_step"] > 0 and ex["MB_sent_per_rank_and_step"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_8_is_the_drivers_scaling_command():
+    """what the driver's 8-GPU run executes (here: gloo + emulated kernels, tiny network with 4 frames): replica x8 as the headline
+    and ONE sample over 2 CFG halves x 4 frame groups under `strong_scaling`, in one line, unattended"""
+    d = _run(8, ("--frames", "4"))
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["parallelism"] == "replica x8"
+    s = d["strong_scaling"]
+    assert "error" not in s, s
+    assert s["parallelism"] == "cfg x2 . frames x4" and s["ranks_per_sample"] == 8 and s["samples_in_flight"] == 1
+    assert s["exchange"]["all_to_all_per_step"] > 0 and s["per_sample_latency_ms"] > 0

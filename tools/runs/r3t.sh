@@ -1,7 +1,7 @@
 #!/bin/bash
-# GEGLU epilogue arithmetic on the packed fp32 pipe + v_fract: tests (bit-equality with the staged path), per-shape and whole-step A/B
+# GEGLU gate: conflict-free piecewise-cubic Phi table (512 B) instead of the 2048-entry linear one: tests (bit-equality with the staged path), per-shape and whole-step A/B
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3r
+O=gpurun_out/r3t
 mkdir -p $O
 timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q --timeout=300 -k "geglu or grouped or tail_row" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $O/tests.log
 PREV=$GRAFT_REPO_ROOT/panacea_amd/lib/libpanacea_hip_prev.so
@@ -16,6 +16,6 @@ for r in 1 2; do
 done
 python - <<'PY'
 import json,glob
-for f in sorted(glob.glob('gpurun_out/r3r/bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/r3t/bench_*.json')):
     print(f.split('/')[-1], round(json.loads(open(f).read())['ms_per_step'],2))
 PY

@@ -59,3 +59,11 @@ def test_bench_gpus_8_is_the_drivers_scaling_command():
     assert "error" not in s, s
     assert s["parallelism"] == "cfg x2 . frames x4" and s["ranks_per_sample"] == 8 and s["samples_in_flight"] == 1
     assert s["exchange"]["all_to_all_per_step"] > 0 and s["per_sample_latency_ms"] > 0
+
+
+def test_bench_yaml_exact_setup_runs_multi_rank():
+    """BASELINE config 5's set-up (25-step schedule, last-frame `concat`, share-noise initial latent) through the multi-rank command:
+    replicas as the headline, one sample over a CFG pair underneath"""
+    d = _run(2, ("--yaml-exact",))
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "replica x2"
+    assert d["strong_scaling"]["parallelism"] == "cfg x2" and "error" not in d["strong_scaling"]

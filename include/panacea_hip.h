@@ -59,7 +59,10 @@ enum {
                                      the input incl. its halo per 64-channel slice and read the nine taps from it (gemm_stencil_tile.hip);
                                      0 = always one gathered A tile per tap; 2 = wherever the shape allows (tests).  Bit-identical
                                      results either way */
-    PNC_OPT_COUNT = 7
+    PNC_OPT_GEMM_PERSIST = 7,     /* 1 (default): GEGLU GEMMs of >= 512 full 256x256 tiles run as ONE persistent workgroup per CU that
+                                     requests the next output tile's first K tile before its epilogue (same results); 0 = one tile per
+                                     workgroup */
+    PNC_OPT_COUNT = 8
 };
 int pnc_set_option(int option, int value);
 

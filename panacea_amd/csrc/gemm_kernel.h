@@ -432,7 +432,9 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
 // 4 lanes per row own 8 of the 32 output columns each.
 template <int MI, int NI>
 __device__ __forceinline__ void epi_geglu(const PncGemmParams& p, f32x16 (&acc)[MI][NI], float* ep, int lane,
-                                          int mw, int nw, const float* phi_tab) {
+                                          int mw, int nw, const float* phi_tab, const float* pre_bias = nullptr) {
+    // pre_bias (register path only): bias of this lane's column in each of the NI column blocks, loaded by the caller — the
+    // persistent kernel must not wait on a global load here (vmcnt is in order: it would wait for the prefetched K tile too)
     static_assert(NI % 2 == 0, "GEGLU pairs value / gate column blocks inside a wave");
     constexpr int EPITCH = 2 * 32 + 4;
     constexpr int CPL = 4, RPP = 16, NP = 2;
@@ -460,8 +462,8 @@ __device__ __forceinline__ void epi_geglu(const PncGemmParams& p, f32x16 (&acc)[
         // issued together (index / fraction first, reads, then the products) instead of one read -> wait -> use chain each.
         static_for<NI / 2>([&](auto jc_) {
             constexpr int jc = decltype(jc_)::value * 2;
-            const float bv = p.bias ? p.bias[nw + jc * 32 + c] : 0.0f;
-            const float bg = p.bias ? p.bias[nw + jc * 32 + 32 + c] : 0.0f;
+            const float bv = pre_bias ? pre_bias[jc] : (p.bias ? p.bias[nw + jc * 32 + c] : 0.0f);
+            const float bg = pre_bias ? pre_bias[jc + 1] : (p.bias ? p.bias[nw + jc * 32 + 32 + c] : 0.0f);
             static_for<MI>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
                 half_st* sb = st + (decltype(jc_)::value * MI + i) * (32 * P16);
@@ -1026,7 +1028,218 @@ int dispatch_conv3x3_tiles(const PncGemmParams& p, unsigned epi, int geometry, h
 
 // gemm.hip
 int launch_splitk_reduce(const PncGemmParams& p, int ksplit, hipStream_t st);
+
 const float* phi_table_device(hipStream_t st, int* rc);
+
+// PERSISTENT form of the GEGLU GEMM (FF1; PNC_OPT_GEMM_PERSIST, on by default) — the first step of DESIGN.md section 12a: one workgroup
+// per CU walks its share of the output tiles, and the FIRST K tile of the next output tile is requested before the epilogue of the
+// current one, into the ring stage the epilogue does not use (the register GEGLU epilogue stages 8 KB per wave = exactly one 64 KB
+// stage).  Hidden: the ~2.5 us of DMA latency every tile otherwise starts with, the Phi table's reload and the workgroup turnover.
+// Same tiles, same K order, same epilogue: bit-identical to the one-tile-per-workgroup kernel.  Preconditions (host): plain A, no lo
+// plane, M % BM == 0, N % BN == 0, K % 64 == 0, fp16 output without lo plane.  Measured (profiles/round3/persist_ab_r3w.txt):
+// level-0 FF1 472-540 -> 409-430 us, level 1 356 -> 334, level 2 316 -> 308.
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(const PncGemmParams pin, const float* __restrict__ phi_g,
+                                                                            const int group_m) {
+    PncGemmParams p = pin;
+    constexpr int NW = WGM * WGN, MI = BM / WGM / 32, NI = BN / WGN / 32, RPI = NW * 8, A_IT = BM / RPI, B_IT = BN / RPI;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, RING_BYTES = 2 * STAGE;
+    static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must be a multiple of the DMA row group");
+    static_assert(NI % 2 == 0, "GEGLU pairs value / gate column blocks inside a wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // the operand ring: the ONLY memory LDS-DMA writes
+    // Everything the epilogue reads lives in LDS objects of its own: hipcc puts s_waitcnt vmcnt(0) in front of any LDS access that
+    // may alias an LDS-DMA in flight — with the staging inside the ring (as in gemm_glds_kernel) the epilogue would wait for the
+    // prefetched K tile before its first table read.  160 KB = ring 128 + table 16 + one 2 KB slab of staging per wave 16.
+    __shared__ __attribute__((aligned(16))) float s_phi[PHI_BYTES / 4];
+    __shared__ __attribute__((aligned(16))) half_t s_stage[NW][32 * 32];
+    const half_t* __restrict__ A = reinterpret_cast<const half_t*>(p.A);
+    const half_t* __restrict__ Wt = reinterpret_cast<const half_t*>(p.W);
+    const int tiles_n = p.N / BN, tiles_m = p.M / BM, ntile = tiles_m * tiles_n, nk = p.K / BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int srow = wave * 8 + (lane >> 3);
+    const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
+    const int frow = lane & 31, fk = lane >> 5;
+
+    // virtual block v -> output tile: the XCD-contiguous ranges and the grouped (tm, tn) order of gemm_glds_kernel
+    auto tile_origin = [&](int v, int& m0, int& n0) {
+        const int tile = xcd_remap(v, ntile);
+        int tn, tm;
+        if (group_m > 0) {
+            const int width = group_m * tiles_n;
+            const int gid = tile / width, first_m = gid * group_m;
+            const int gsz = min(tiles_m - first_m, group_m);
+            const int in = tile - gid * width;
+            tm = first_m + in % gsz; tn = in / gsz;
+        } else {
+            tn = tile % tiles_n; tm = tile / tiles_n;
+        }
+        m0 = tm * BM; n0 = tn * BN;
+    };
+    unsigned aoff[A_IT], woff[B_IT];                       // per-lane byte offsets inside a tile's windows: the same for every tile
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) aoff[i] = (unsigned)((i * RPI + srow) * p.lda + schunk * 8) * 2u;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) woff[i] = (unsigned)((i * RPI + srow) * p.ldw + schunk * 8) * 2u;
+    auto issue = [&](int m0, int n0, int kt, int stage) {
+        const buffer_rsrc_t rs_a = make_rsrc(A + (int64_t)m0 * p.lda, 0x7FFFFF00u);
+        const buffer_rsrc_t rs_w = make_rsrc(Wt + (int64_t)n0 * p.ldw, 0x7FFFFF00u);
+        char* sa = smem + stage * STAGE + wave * 1024;
+        char* sb = sa + A_BYTES;
+        const unsigned ks = (unsigned)kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) glds16_buf(rs_a, aoff[i], ks, sa + i * (RPI * 128));
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) glds16_buf(rs_w, woff[i], ks, sb + i * (RPI * 128));
+    };
+
+    for (int i = tid; i < PHI_BYTES / 16; i += 64 * NW)                 // the Phi table: once per workgroup, by plain stores
+        reinterpret_cast<f32x4*>(s_phi)[i] = reinterpret_cast<const f32x4*>(phi_g)[i];
+    f32x16 acc[MI][NI];
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE;
+        const char* sb = sa + A_BYTES;
+        half8v af[2][MI], bf[2][NI];
+        auto frags = [&](int ks, int b) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[b][i] = *reinterpret_cast<const half8v*>(sa + lds_off128(wm * (MI * 32) + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                bf[b][j] = *reinterpret_cast<const half8v*>(sb + lds_off128(wn * (NI * 32) + j * 32 + frow, ks * 2 + fk));
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            if (ks + 1 < BK / 16) frags(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    int v = blockIdx.x;
+    if (v >= ntile) return;
+    int m0, n0, sp = 0;
+    tile_origin(v, m0, n0);
+    float pb[NI], pbn[NI];
+    auto load_bias = [&](int n0_, float (&dst)[NI]) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) dst[j] = p.bias ? p.bias[n0_ + wn * (NI * 32) + j * 32 + (lane & 31)] : 0.0f;
+    };
+    load_bias(n0, pb);
+    issue(m0, n0, 0, 0);
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        __syncthreads();                        // K tile 0 of this output tile has landed; the previous epilogue's staging is retired
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) issue(m0, n0, kt + 1, (sp + kt + 1) & 1);
+            compute((sp + kt) & 1);
+            __syncthreads();
+        }
+        const int ls = (sp + nk - 1) & 1;       // the stage of the last K tile: every wave is done with it -> the epilogue's staging
+        const int vn = v + gridDim.x;
+        int m1 = 0, n1 = 0;
+        if (vn < ntile) {                       // (uniform) the next output tile's first K tile, into the other stage
+            tile_origin(vn, m1, n1);
+            load_bias(n1, pbn);                 // BEFORE the DMA: nothing in the epilogue below may wait on vmcnt
+            issue(m1, n1, 0, ls ^ 1);
+        }
+        {   // epi_geglu's register path, slab by slab (same operations in the same order: bit-identical)
+            half_t* out16 = reinterpret_cast<half_t*>(p.out16);
+            typedef half_t __attribute__((may_alias)) half_st;
+            typedef int4 __attribute__((may_alias)) int4_st;
+            half_st* sb = reinterpret_cast<half_st*>(&s_stage[wave][0]);
+            const int c = lane & 31, cl = lane & 3, rl = lane >> 2;
+            const int mw = m0 + wm * (MI * 32), nw = n0 + wn * (NI * 32);
+            static_for<NI / 2>([&](auto jc_) {
+                constexpr int jc = decltype(jc_)::value * 2;
+                const float bv = pb[jc], bg = pb[jc + 1];
+                const int ncol0 = (nw + jc * 32) >> 1;
+                static_for<MI>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    float gx[16], fr[16];
+                    int ix[16];
+                    float2 e[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        gx[r] = acc[i][jc + 1][r] + bg;
+                        float t = fmaf(gx[r], PHI_SCALE, -PHI_X0 * PHI_SCALE);
+                        t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)PHI_N - 0.001f);
+                        ix[r] = (int)t;
+                        fr[r] = t - (float)ix[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e[r] = *reinterpret_cast<const float2*>(s_phi + 2 * ix[r]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float prod = (acc[i][jc][r] + bv) * (gx[r] * fmaf(fr[r], e[r].y, e[r].x));
+                        asm("" : "+v"(prod));
+                        sb[mfma32_row(r, lane) * 32 + c] = (half_t)prod;
+                    }
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int row = ps * 16 + rl;
+                        const int4 v4 = *reinterpret_cast<const int4_st*>(sb + row * 32 + cl * 8);
+                        *reinterpret_cast<int4_st*>(out16 + (int64_t)(mw + i * 32 + row) * p.ldc16 + ncol0 + cl * 8) = v4;
+                    }
+                });
+            });
+        }
+        if (vn >= ntile) break;
+        v = vn; m0 = m1; n0 = n1; sp = ls ^ 1;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) pb[j] = pbn[j];
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_geglu_persist(const PncGemmParams& p, hipStream_t st) {
+    constexpr int lds = 2 * (BM + BN) * 128;               // dynamic part: the operand ring (table and staging are static)
+    static_assert(lds + PHI_BYTES + WGM * WGN * 2048 <= 160 * 1024, "LDS budget of one CU");
+    static std::atomic<unsigned char> attr_done[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto kern = gemm_geglu_persist_kernel<BM, BN, WGM, WGN>;
+    if (!attr_done[dev & 63].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done[dev & 63].store(1, std::memory_order_release);
+    }
+    int rc = PNC_OK;
+    const float* phi = phi_table_device(st, &rc);
+    if (rc != PNC_OK) return rc;
+    const int tiles_n = p.N / BN, tiles_m = p.M / BM, tiles = tiles_m * tiles_n;
+    const int gopt = pnc_get_option(PNC_OPT_GEMM_GROUP_M);
+    int group_m = gopt > 0 ? gopt : (tiles_n > 8 ? 4 : 0);
+    if (group_m > tiles_m) group_m = tiles_m;
+    if (tiles_n < 2) group_m = 0;
+    static std::atomic<int> ncu_of[64];                    // CUs per device, asked once (one persistent workgroup per CU)
+    int ncu = ncu_of[dev & 63].load(std::memory_order_relaxed);
+    if (ncu == 0) {
+        int v = 0;
+        ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        ncu_of[dev & 63].store(ncu, std::memory_order_relaxed);
+    }
+    const int blocks = tiles < ncu ? tiles : ncu;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * WGM * WGN), lds, st, p, phi, group_m);
+    return pnc_launch_status();
+}
+// the persistent kernel serves this problem (and the switch is on)
+static inline bool geglu_persist_ok(const PncGemmParams& p) {
+    return pnc_get_option(PNC_OPT_GEMM_PERSIST) != 0 && p.geglu && p.a_mode == PNC_A_PLAIN && !p.A_lo && !p.out16_lo && p.out16 &&
+           (p.M % 256) == 0 && (p.N % 256) == 0 && (p.K % 64) == 0 && p.K >= 64 && (p.M / 256) * (p.N / 256) >= 512;
+}
 
 template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE, unsigned EPI>
 int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {

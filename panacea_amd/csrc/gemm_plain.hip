@@ -33,7 +33,9 @@ int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st, bool* l
         case E_O32 | E_LN: return launch_ln<E_O32 | E_LN>(p, st, tc);               // proj_in + norm1
         case E_RB | E_O32 | E_LN: return launch_ln<E_RB | E_O32 | E_LN>(p, st, tc); // proj_in_temporal + pos + norm1
         case E_R1 | E_O32 | E_LN: return launch_ln<E_R1 | E_O32 | E_LN>(p, st, tc); // to_out + residual + norm2 / norm3
-        case E_GEGLU | E_O16: return launch_tile<AM, E_GEGLU | E_O16>(p, st, tc);   // ff1
+        case E_GEGLU | E_O16:                                                       // ff1
+            if (tc.tile == T_256x256 && geglu_persist_ok(p)) return launch_geglu_persist<256, 256, 4, 2>(p, st);
+            return launch_tile<AM, E_GEGLU | E_O16>(p, st, tc);
         case E_O16 | E_GELU:                                                        // text-tower c_fc + GELU (two geometries)
             if (tc.tile == T_256x256) return launch<AM, 256, 256, 4, 2, 2, true, E_O16 | E_GELU>(p, st);
             return launch<AM, 128, 128, 2, 2, 2, true, E_O16 | E_GELU>(p, st);

@@ -132,6 +132,29 @@ def test_gemm_geglu_register_epilogue_equals_the_staged_one(M, C):
     check("geglu no bias", o_nb, e_nb, 4e-3)
 
 
+@pytest.mark.parametrize("M,C,bias", [(256 * 64, 320, True), (256 * 26, 640, True), (256 * 70, 320, False)])
+def test_gemm_geglu_persistent_kernel_is_bit_identical(M, C, bias):
+    """PNC_OPT_GEMM_PERSIST (the default): one workgroup per CU walks its output tiles and requests the next tile's first K tile before the
+    current tile's epilogue.  Same tiles, same K order, same epilogue arithmetic: bit-identical to the one-tile-per-workgroup launch
+    (shapes with >= 512 full 256x256 tiles qualify; others keep the regular kernel whatever the switch says)."""
+    N, K = 8 * C, C
+    assert (M // 256) * (N // 256) >= 512
+    a, w = rnd(M, K, dtype=torch.float16), rnd(N, K, scale=K ** -0.5, dtype=torch.float16)
+    b = rnd(N) if bias else None
+    o_ref = torch.zeros(M, N // 2, device=DEV, dtype=torch.float16)
+    o_per = torch.zeros_like(o_ref)
+    prev = hip.set_option(hip.OPT_GEMM_PERSIST, 0)
+    try:
+        hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=b, geglu=True, out16=o_ref, ldc16=N // 2)
+        hip.set_option(hip.OPT_GEMM_PERSIST, 1)
+        hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=b, geglu=True, out16=o_per, ldc16=N // 2)
+        hip.gemm(a, w, M=M, N=N, K=K, lda=K, bias=b, geglu=True, out16=o_per, ldc16=N // 2)      # twice: no state left behind
+        torch.cuda.synchronize()
+    finally:
+        hip.set_option(hip.OPT_GEMM_PERSIST, prev)
+    assert torch.equal(o_per, o_ref) and o_ref.abs().max().item() > 0.1
+
+
 @pytest.mark.parametrize("G,t_rows,C", [(2, 128, 64), (3, 96, 128), (2, 80, 64), (2, 192, 320)])
 def test_gemm_split_transposed_output(G, t_rows, C):
     # q|k row-major for n < 2C, V^T channel-major for n >= 2C  (QKV projection epilogue)

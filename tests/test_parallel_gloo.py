@@ -300,6 +300,13 @@ def _views_worker(rank, world, port, out_dir, cfg, V, T, network):
         xs = smp(denoiser, parallel.local_views(x0, lo), parallel.shard_conditioning(cond, lo, T),
                  parallel.shard_conditioning(uc, lo, T))
         xs_all = parallel.gather_views(xs, groups)
+        # --- (4) the same schedule with the step invariants hoisted (hint stem on the band — its convs exchange halos once —, text
+        #         K/V): bit-identical to the schedule that recomputes them every step
+        n1 = vs.exchanges
+        ch, uh = S.hoist_invariants(net, smp.guider, parallel.shard_conditioning(cond, lo, T), parallel.shard_conditioning(uc, lo, T))
+        xs_h = smp(denoiser, parallel.local_views(x0, lo), ch, uh)
+        assert torch.equal(xs_h, xs), (xs_h - xs).abs().max().item()
+        assert vs.exchanges - n1 < 2 * (n1 - n0)        # fewer exchanges per step: the hint stem's halos are not repeated
         if rank == 0:
             parallel.apply_view_shard(net, None)
             eps_ref = net(inp["x"], inp["t"], cond_of(inp))

@@ -264,6 +264,7 @@ def run_text_tower(args, dev):
     hip.load()
     torch.manual_seed(3)
     emb = conditioner.FrozenOpenCLIPEmbedder(arch="ViT-H-14", layer="penultimate")
+    emb.allow_random_init = True          # synthetic weights written in place (no checkpoint offline): say so explicitly
     with torch.no_grad():
         for n, p_ in emb.named_parameters():
             if p_.dim() >= 2 and "embedding" not in n:
@@ -329,7 +330,7 @@ def main():
     ap.add_argument("--precision", default="precise", choices=["fast", "precise", "precise-all", "precise-lite", "precise-f16lo"],
                     help="operand policy of the timed region (DESIGN §6).  precise (default) meets eps max-abs < 1e-3; the "
                          "other of fast / precise is timed too and reported under `modes`")
-    ap.add_argument("--parallelism", default="auto", choices=["auto", "replica", "cfg", "cfg+frames", "frames", "views", "cfg+views"],
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "replica", "cfg", "cfg+frames", "frames", "views", "cfg+views", "cfg+views+frames"],
                     help="N > 1: auto (default) = replica as the headline + cfg+frames reported under strong_scaling in the same "
                          "line; replica = one sample per rank (the reference's strategy, weak scaling); cfg = one "
                          "sample per rank pair (CFG halves, one all-gather per step); cfg+frames = one sample over "

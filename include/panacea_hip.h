@@ -271,6 +271,12 @@ int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int C,
                         int pix_per_chunk, const float* partial,
                         const float* gamma, const float* beta, float eps, int silu,
                         void* y16, int ldy, void* y16_lo, int lo_fmt, void* stream);
+/* Chan-combine `parts` sets of chunk records, in[((s*F + f)*nchunk + c)*32 + g] = {count, mean, M2} (the all-gathered
+ * pnc_groupnorm_stats records of the bands of a view group), per (frame, group), in the fixed order (s, c):
+ * out[(f*nchunk + 0)*32 + g] = the combined record, every other slot of the frame {0, 0, 0} — an empty record leaves the
+ * combination of pnc_groupnorm_apply unchanged, so that kernel normalises a band with the statistics of the whole panorama.
+ *    -> nn.GroupNorm over the (H, 6w) panorama when its views live on several ranks (diffusionmodules/util.py:276-283) */
+int pnc_groupnorm_combine(const float* in, int parts, int F, int nchunk, float* out, void* stream);
 /* Temporal GroupNorm(32,C)+SiLU: statistics over the (C/32, T) slab of ONE pixel
  *    -> nn.GroupNorm applied on "(b h w) c t" (openaimodel.py:409-419,509-515) */
 int pnc_groupnorm_temporal_silu(const float* x, int B, int T, int Npix, int C,

@@ -6,6 +6,8 @@ oracle is run on the same data and must agree (fp32 vs fp32) before the file is 
     python -m oracle.gen_golden_full                         # t = 999, input salt 0 -> full_cfg3.npz
     python -m oracle.gen_golden_full --t 500 --no-oracle     # further pins (round 3): full_cfg3_t500.npz
     python -m oracle.gen_golden_full --t 39 --salt 1 --no-oracle   # second input seed:  full_cfg3_t39_s1.npz
+    python -m oracle.gen_golden_full --frames 1 --no-oracle        # BASELINE config 2 (round 4): full_cfg2.npz
+    python -m oracle.gen_golden_full --yaml-exact --no-oracle      # BASELINE config 5, sampler step 0: full_cfg5_step0.npz
 
 The extra pins skip the (6 minute) oracle leg: oracle vs reference is established by the first file and by the
 small configurations; what the extra files pin is the reference's eps at other noise levels / inputs.
@@ -29,10 +31,20 @@ if __name__ == "__main__":
     ap.add_argument("--t", type=int, default=999, help="timestep index of every frame")
     ap.add_argument("--salt", type=int, default=0, help="salt of the synthetic INPUTS (weights keep salt 0)")
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--frames", type=int, default=8, help="1 = BASELINE config 2: the YAML network built with num_frames = 1")
+    ap.add_argument("--yaml-exact", action="store_true",
+                    help="BASELINE config 5: last-frame concat conditioning + share-noise latent, t = 999 (sampler step 0)")
     args = ap.parse_args()
     tag = "" if (args.t == 999 and args.salt == 0) else f"_t{args.t}" + (f"_s{args.salt}" if args.salt else "")
+    stem = "full_cfg3"
+    if args.frames != 8:
+        assert args.frames == 1 and not args.yaml_exact
+        stem = "full_cfg2"
+    if args.yaml_exact:
+        assert args.t == 999
+        stem = "full_cfg5_step0"
     ns = ref_import.import_reference()
-    kw = configs.get("full")
+    kw = configs.with_frames(configs.get("full"), args.frames)
     t0 = time.time()
     net, wrapper = ref_import.build_reference_network(ns, kw)
     manifest = {k: list(v.shape) for k, v in net.state_dict().items()}
@@ -41,7 +53,11 @@ if __name__ == "__main__":
     del sd
     print(f"built + loaded in {time.time() - t0:.0f}s", flush=True)
     B, T, h, w = configs.SHAPES["full"]
-    inp = synth.synth_inputs(B, T, h, w, context_dim=kw["context_dim"], t_index=args.t, salt=args.salt)
+    T = args.frames
+    if args.yaml_exact:
+        inp = synth.yaml_exact_step0_inputs(T, h, w, context_dim=kw["context_dim"], salt=args.salt)
+    else:
+        inp = synth.synth_inputs(B, T, h, w, context_dim=kw["context_dim"], t_index=args.t, salt=args.salt)
     c = {k: inp[k].clone() for k in ("concat", "crossattn", "cond_feat")}
     t0 = time.time()
     with torch.no_grad():
@@ -58,7 +74,7 @@ if __name__ == "__main__":
         d = (eps - eps_o).abs().max().item()
         print(f"oracle forward {t_or:.1f}s; oracle vs reference max-abs {d:.3e}", flush=True)
         assert d <= 1e-4
-    np.savez_compressed(GOLDEN / f"full_cfg3{tag}.npz", eps_s7=eps.reshape(-1)[::7].numpy(),
+    np.savez_compressed(GOLDEN / f"{stem}{tag}.npz", eps_s7=eps.reshape(-1)[::7].numpy(),
                         t_index=np.int32(args.t), input_salt=np.int32(args.salt),
                         eps_rms=np.float32(eps.pow(2).mean().sqrt().item()),
                         eps_max=np.float32(eps.abs().max().item()),

@@ -337,6 +337,44 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Chan-combine the chunk records of `parts` record sets (the all-gathered partials of a view group's bands) per (frame, group):
+// 8 thread slices walk every 8th record in the fixed order (set, chunk), one thread per group merges the slices — the
+// arithmetic of gn_apply_kernel's own combination.  Slot 0 of the frame receives the result, the other slots an empty record.
+__global__ __launch_bounds__(256) void gn_combine_kernel(const float* __restrict__ in, int parts, int F, int nchunk,
+                                                         float* __restrict__ out) {
+    __shared__ float s_pn[8 * GROUPS], s_pm[8 * GROUPS], s_p2[8 * GROUPS];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int g = tid & 31, part = tid >> 5;
+    const int nrec = parts * nchunk;
+    float n = 0.0f, mean = 0.0f, m2 = 0.0f;
+    for (int r = part; r < nrec; r += 8) {
+        const int s = r / nchunk, c = r - s * nchunk;
+        const float* q = in + ((((int64_t)s * F + f) * nchunk + c) * GROUPS + g) * 3;
+        const float nb = q[0], mb = q[1], m2b = q[2];
+        const float nt = n + nb, d = mb - mean;
+        const float w = nb / fmaxf(nt, 1.0f);
+        mean = fmaf(d, w, mean);
+        m2 += m2b + d * d * (n * w);
+        n = nt;
+    }
+    s_pn[part * GROUPS + g] = n; s_pm[part * GROUPS + g] = mean; s_p2[part * GROUPS + g] = m2;
+    __syncthreads();
+    if (tid < GROUPS) {
+        float tn = 0.0f, tm = 0.0f, t2 = 0.0f;
+        for (int k = 0; k < 8; ++k) {
+            const float nb = s_pn[k * GROUPS + tid], mb = s_pm[k * GROUPS + tid], m2b = s_p2[k * GROUPS + tid];
+            const float nt = tn + nb, d = mb - tm;
+            const float w = nb / fmaxf(nt, 1.0f);
+            tm = fmaf(d, w, tm);
+            t2 += m2b + d * d * (tn * w);
+            tn = nt;
+        }
+        float* o = out + ((int64_t)f * nchunk * GROUPS + tid) * 3;
+        o[0] = tn; o[1] = tm; o[2] = t2;
+    }
+    for (int i = GROUPS * 3 + tid; i < nchunk * GROUPS * 3; i += 256) out[(int64_t)f * nchunk * GROUPS * 3 + i] = 0.0f;
+}
+
 }  // namespace
 
 constexpr int GN_MAXC = 4 * 64 * 12;       // J <= 12 float4 vectors per lane
@@ -378,6 +416,12 @@ extern "C" int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int
     half_t* y = reinterpret_cast<half_t*>(y16);
     PNC_GN_DISPATCH(gn_apply_kernel, dim3(nchunk, F), dim3(256), lds, st, x, ldx, Npix, C, pix_per_chunk, partial,
                     gamma, beta, eps, silu, y, ldy, y16_lo, lo_fmt);
+    return pnc_launch_status();
+}
+
+extern "C" int pnc_groupnorm_combine(const float* in, int parts, int F, int nchunk, float* out, void* stream) {
+    if (!in || !out || parts < 1 || F < 1 || nchunk < 1) return PNC_EINVAL;
+    hipLaunchKernelGGL(gn_combine_kernel, dim3(F), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, parts, F, nchunk, out);
     return pnc_launch_status();
 }
 

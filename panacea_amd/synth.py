@@ -76,3 +76,19 @@ def synth_inputs(B: int, T: int, h: int, w: int, context_dim: int = 1024, hint_c
     cond_feat = hint.repeat(B, 1, 1, 1)            # the uc / c halves share the layout hint
     t = torch.full((F,), int(t_index), dtype=torch.int64)
     return {"x": x, "t": t, "concat": concat, "crossattn": crossattn, "cond_feat": cond_feat}
+
+
+def yaml_exact_step0_inputs(T: int, h: int, w: int, context_dim: int = 1024, salt: int = 0,
+                            share_noise_level: float = 0.07) -> dict:
+    """The network-level inputs of sampler step 0 of BASELINE config 5 (configs/inference_nuscenes.yaml): `concat` is the
+    `final_cond_zero` pattern (nuscenes_datasets_video.py:559-572: the conditioning image sits in the LAST frame, every other
+    frame encodes a zero image, i.e. one constant latent per channel) for BOTH CFG halves, the latent of every frame is
+    `randn + share_noise_level * concat[-1]` (diffusion.py:242-249) — at step 0 the denoiser's c_in exactly undoes the
+    sampler's sqrt(1 + sigma_0^2) — and t = 999.  Same tensor convention as `synth_inputs` (uncond half first)."""
+    inp = synth_inputs(2, T, h, w, context_dim=context_dim, t_index=999, salt=salt)
+    cc = inp["concat"][T:].clone()
+    cc[:-1] = cc[0:1].mean(dim=(2, 3), keepdim=True).expand(-1, -1, h, w)
+    x0 = inp["x"][T:] + cc[-1].unsqueeze(0) * share_noise_level
+    inp["concat"] = torch.cat([cc, cc], dim=0)
+    inp["x"] = torch.cat([x0, x0], dim=0)
+    return inp

@@ -311,6 +311,17 @@ def groupnorm_stats(x32, ldx, F, Npix, Cch, ppc, partial):
         P[:, c, :, 2] = ((xs - mean[..., None]) ** 2).sum(-1)
 
 
+def groupnorm_combine(parts_in, parts, F, nchunk, out):
+    P = parts_in.reshape(-1)[: parts * F * nchunk * 96].view(parts, F, nchunk, 32, 3).double()
+    P = P.permute(1, 0, 2, 3, 4).reshape(F, parts * nchunk, 32, 3)
+    n = P[..., 0].sum(1)
+    mean = (P[..., 0] * P[..., 1]).sum(1) / n
+    m2 = (P[..., 2] + P[..., 0] * (P[..., 1] - mean[:, None]) ** 2).sum(1)
+    O = out.reshape(-1)[: F * nchunk * 96].view(F, nchunk, 32, 3)
+    O.zero_()
+    O[:, 0] = torch.stack([n, mean, m2], dim=-1).to(O.dtype)
+
+
 def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy, y16_lo=None):
     nchunk = (Npix + ppc - 1) // ppc
     P = partial.reshape(-1)[: F * nchunk * 32 * 3].view(F, nchunk, 32, 3).double()

@@ -164,3 +164,35 @@ def test_operand_policy_follows_the_network_unless_set():
     assert engine.precision("precise").lo8 and not engine.precision("precise-f16lo").lo8
     with pytest.raises(ValueError):
         t1.precision = "fastest"
+
+
+def test_view_and_frame_shard_loop_back_on_one_process():
+    """engine.ViewShard(1, 0) / FrameShard(1, 0) without a process group: the band is the whole panorama and its own circular
+    neighbour, the frame group is the rank itself.  Drives every exchange site of the tiny network in ONE process (the GPU suite
+    runs the same at the full network's width): the frame loop-back only moves data (same bits), the view loop-back runs every
+    3x3 conv over the map widened by zero halo columns and applies GroupNorm records combined by `groupnorm_combine`."""
+    from panacea_amd import parallel
+    kw = configs.with_frames(configs.get("tiny"), 2)
+    w, _, _ = product_network("tiny", kw=kw)
+    inp = step_inputs("tiny", kw, t_index=500, shape=(2, 2, 8, 96))
+    with E.use_backend(emu), torch.no_grad():
+        ref = w(inp["x"], inp["t"], cond(inp))
+        sh = E.FrameShard(1, 0, None)
+        parallel.apply_frame_shard(w, sh)
+        got_f = w(inp["x"], inp["t"], cond(inp))
+        vs = E.ViewShard(1, 0, None)
+        parallel.apply_view_shard(w, vs)
+        got_vf = w(inp["x"], inp["t"], cond(inp))
+        parallel.apply_frame_shard(w, None)
+        got_v = w(inp["x"], inp["t"], cond(inp))
+        # the exchange against its definition: what arrives from the left is what went to the right (and vice versa)
+        a, b = torch.randn(3, 5), torch.randn(2, 7).half()
+        (fl, fl2), (fr, fr2) = vs._exchange([a, b], [a + 1, b + 1])
+    assert torch.equal(fl, a + 1) and torch.equal(fl2, b + 1) and torch.equal(fr, a) and torch.equal(fr2, b)
+    assert torch.equal(got_f, ref) and sh.exchanges > 20 and vs.exchanges > 50 and vs.bytes_sent == 0
+    # torch's conv over the widened map sums in another order than over the panorama: decorrelated fp16 operand roundings
+    for got in (got_v, got_vf):
+        d = (got - ref).abs()
+        assert d.max().item() <= 2e-3 and d.mean().item() <= 2.5e-4, (d.max().item(), d.mean().item())
+    with pytest.raises(ValueError):
+        E.ViewShard(2, 0, None)

@@ -128,6 +128,14 @@ def test_full_width_single_frame_config2_vs_oracle():
     print("full network, T=1, 16x192:", w.diffusion_model.precision, st)
     assert st["ref_max"] > 1.0
     assert st["max_abs"] <= CONFIG2_TOL[0] and st["mean_abs"] <= CONFIG2_TOL[1], st
+    # ... and at the workload BASELINE config 2 names — 6 views x 1 frame at 256x512 = a 32x384 latent, CFG batch 2 — against
+    # the REFERENCE's own forward (round 4 pin: oracle/gen_golden_full.py --frames 1 -> tests/golden/full_cfg2.npz)
+    g2 = np.load(GOLDEN / "full_cfg2.npz")
+    gi = step_inputs("full", kw, DEV, shape=(2, 1, 32, 384))
+    st2 = err_stats(w(gi["x"], gi["t"], cond(gi)).reshape(-1)[::7], g2["eps_s7"])
+    print("config 2 (T=1, 32x384) vs reference:", st2)
+    measured("full_cfg2", max_abs=st2["max_abs"], mean_abs=st2["mean_abs"])
+    assert st2["max_abs"] <= CONFIG2_TOL[0] and st2["mean_abs"] <= CONFIG2_TOL[1], st2
 
 
 def test_full_network_small_panorama_vs_oracle():
@@ -199,6 +207,16 @@ def test_full_size_properties_and_golden(full_net):
             measured("full_cfg3", t=t_index, salt=salt, max_abs=st2["max_abs"], mean_abs=st2["mean_abs"])
             assert st2["max_abs"] <= NORTH_STAR and st2["mean_abs"] <= 2e-4, (fname, st2)
             del gi
+        # BASELINE config 5 (round 4 pin): the reference's own forward on the YAML-exact inputs of sampler step 0 — last-frame
+        # `concat` conditioning (final_cond_zero), share-noise latent, t = 999 (oracle/gen_golden_full.py --yaml-exact)
+        from panacea_amd import synth
+        g5 = np.load(GOLDEN / "full_cfg5_step0.npz")
+        gi = {k: v.to(DEV) for k, v in synth.yaml_exact_step0_inputs(8, 32, 384, context_dim=kw["context_dim"]).items()}
+        st5 = err_stats(w(gi["x"], gi["t"], cond(gi)).reshape(-1)[::7], g5["eps_s7"])
+        print("config 5 (yaml-exact step 0) vs reference:", st5)
+        measured("full_cfg5_step0", max_abs=st5["max_abs"], mean_abs=st5["mean_abs"])
+        assert st5["max_abs"] <= NORTH_STAR and st5["mean_abs"] <= 2e-4, st5
+        del gi
         w.diffusion_model.precision = "fast"
         st = err_stats(w(inp["x"], inp["t"], cond(inp)).reshape(-1)[::7], g["eps_s7"])
         w.diffusion_model.precision = "precise"

@@ -251,13 +251,14 @@ def _views_worker(rank, world, port, out_dir, cfg, V, T, network):
     nchunk = (H * wl + ppc - 1) // ppc
     part = torch.empty(Fx * nchunk * 32 * 3)
     emu.groupnorm_stats(x32, 64, Fx, H * wl, 64, ppc, part)
-    rec = vs.combine_stats(part, Fx, nchunk).view(Fx, nchunk, 32, 3)
+    rec = vs.combine_stats(part, Fx, nchunk, emu).view(Fx, nchunk, 32, 3)
     allx = [torch.empty_like(x32) for _ in range(V)]
     dist.all_gather(allx, x32, group=groups.view_group)
     pano = torch.cat([a.view(Fx, H * wl, 32, 2) for a in allx], dim=1).permute(0, 2, 1, 3).reshape(Fx, 32, -1).double()
     assert torch.allclose(rec[:, 0, :, 1].double(), pano.mean(-1), atol=1e-5)
     assert torch.allclose(rec[:, 0, :, 2].double() / rec[:, 0, :, 0].double(), pano.var(-1, unbiased=False), rtol=1e-4)
-    assert torch.equal(rec[:, 0], rec[:, -1])
+    assert nchunk > 1 and not rec[:, 1:].any()            # one combined record per frame, the other slots empty
+    assert torch.allclose(rec[:, 0, :, 0], torch.full((Fx, 32), float(V * H * wl * 2)))
     # --- (1c) neighbour views + local segments: every local view finds exactly the views INTER_SEGS names
     tag = torch.arange(6, dtype=torch.float32).repeat_interleave(W // 6)                 # view id per panorama column
     k4 = tag[vg * wl:(vg + 1) * wl].view(1, 1, wl, 1).expand(1, 2, wl, 3).contiguous()
@@ -358,5 +359,94 @@ def test_view_group_sharding_reproduces_the_single_process_eps(world, cfg, V, T)
     assert (lo.sample, lo.half, lo.view_group) == (1, 0, 1) and lo.view_group_ranks(1, 0) == [6, 7, 8]
     assert lo.cfg_pair_ranks(1, 1) == [7, 10]
     assert layout_for(4, 3, "cfg+views").views == 2 and layout_for(6, 0, "views").views == 6
-    with pytest.raises(ValueError):
-        RankLayout(8, 0, cfg=2, frames=2, views=2)
+    assert RankLayout(8, 0, cfg=2, frames=2, views=2).per_sample == 8          # round 4: the two splits compose
+
+
+# ------------------------------------------------------------------------ cfg x view groups x frame groups (SURVEY §8e's 8-GPU grid)
+def _grid_worker(rank, world, port, out_dir, cfg, G, V, T):
+    """rank grid cfg x G frame groups x V view groups over ONE sample of the tiny network: every rank holds T/G frames of a band
+    of W/V columns of its half; one eps evaluation and a 2-step schedule"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import emu
+    from helpers import cond as cond_of, product_network, step_inputs
+    from panacea_amd import configs, engine as E, parallel, sampling as S
+    parallel.init_distributed("gloo")
+    lo = parallel.RankLayout(world, rank, cfg=cfg, frames=G, views=V)
+    assert lo.samples == 1 and "frames" in lo.name and "views" in lo.name
+    groups = parallel.Groups(lo)
+    shard, vs = groups.frame_shard(), groups.view_shard()
+    assert (shard.G, shard.index, vs.G, vs.index) == (G, lo.frame_group, V, lo.view_group)
+    # the two groups of a rank are orthogonal: same (sample, half), one coordinate fixed each
+    assert lo.frame_group_ranks(lo.sample, lo.half, lo.view_group)[lo.frame_group] == rank
+    assert lo.view_group_ranks(lo.sample, lo.half, lo.frame_group)[lo.view_group] == rank
+    kw = configs.with_frames(configs.get("tiny"), T)
+    net, _, _ = product_network("tiny", kw=kw)
+    inp = step_inputs("tiny", kw, t_index=500, shape=(2, T, 8, 96))
+    halves = [lo.half] if cfg == 2 else [0, 1]
+    tl = T // G
+
+    def pick(t):
+        v = t.view(2, T, *t.shape[1:])[halves][:, lo.frame_group * tl:(lo.frame_group + 1) * tl].reshape(-1, *t.shape[1:])
+        return parallel.local_views(v, lo) if v.dim() == 4 else v.contiguous()
+    loc = {"x": pick(inp["x"]), "t": pick(inp["t"]), "concat": pick(inp["concat"]), "cond_feat": pick(inp["cond_feat"]),
+           "crossattn": inp["crossattn"][halves]}
+    parallel.apply_frame_shard(net, shard)
+    parallel.apply_view_shard(net, vs)
+    with E.use_backend(emu), torch.no_grad():
+        eps_loc = net(loc["x"], loc["t"], cond_of(loc))
+        assert shard.exchanges > 0 and vs.exchanges > 0
+        torch.save({"eps": eps_loc, "halves": halves, "fg": lo.frame_group, "vg": lo.view_group,
+                    "frame_exchanges": shard.exchanges, "view_exchanges": vs.exchanges}, Path(out_dir) / f"eps{rank}.pt")
+        cond = {"crossattn": inp["crossattn"][1:2], "concat": inp["concat"][T:], "cond_feat": inp["cond_feat"][T:]}
+        uc = {"crossattn": inp["crossattn"][0:1], "concat": inp["concat"][:T], "cond_feat": inp["cond_feat"][:T]}
+        den = S.DiscreteDenoiser()
+        denoiser = lambda xi, sigma, cc: den(net, xi, sigma, cc)     # noqa: E731
+        smp = S.EulerEDMSampler(2, guider=groups.guider(5.0), device="cpu")
+        x0 = inp["x"][T:]
+        xs = smp(denoiser, parallel.local_views(parallel.local_frames(x0, lo, T), lo), parallel.shard_conditioning(cond, lo, T),
+                 parallel.shard_conditioning(uc, lo, T))
+        xs_all = parallel.gather_frames(parallel.gather_views(xs, groups), groups, T)
+        if rank == 0:
+            parallel.apply_frame_shard(net, None)
+            parallel.apply_view_shard(net, None)
+            eps_ref = net(inp["x"], inp["t"], cond_of(inp))
+            single = S.EulerEDMSampler(2, guider=S.VanillaCFG(5.0), device="cpu")
+            torch.save({"eps_ref": eps_ref, "traj": xs_all, "traj_ref": single(denoiser, x0.clone(), cond, uc)},
+                       Path(out_dir) / "ref.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+def test_cfg_x_views_x_frames_grid_world8_reproduces_the_single_process_eps():
+    """SURVEY §8(e)'s 8-GPU partitioning — 2 CFG halves x 2 view groups (3 views each) x 2 frame groups — as eight gloo ranks
+    on the tiny network (T = 4): every rank's (frames, band) block of eps and a 2-step trajectory equal the single-process
+    result within the band the view layout alone shows (decorrelated fp16 operand roundings, tests above)."""
+    from panacea_amd.parallel import RankLayout, layout_for
+    world, cfg, G, V, T = 8, 2, 2, 2, 4
+    port = 29500 + ((os.getpid() * 5 + 311) % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_grid_worker, args=(world, port, d, cfg, G, V, T), nprocs=world, join=True)
+        ref = torch.load(Path(d) / "ref.pt")
+        eps_ref = ref["eps_ref"].view(2, T, *ref["eps_ref"].shape[1:])
+        tl, wl = T // G, eps_ref.shape[-1] // V
+        worst = mean = 0.0
+        for r in range(world):
+            e = torch.load(Path(d) / f"eps{r}.pt")
+            want = eps_ref[e["halves"]][:, e["fg"] * tl:(e["fg"] + 1) * tl, ..., e["vg"] * wl:(e["vg"] + 1) * wl].reshape(e["eps"].shape)
+            diff = (e["eps"] - want).abs()
+            worst, mean = max(worst, diff.max().item()), max(mean, diff.mean().item())
+        print(f"world 8 = cfg 2 x frames 2 x views 2: |eps_sharded - eps_single| max {worst:.3e} mean {mean:.3e}; "
+              f"{e['frame_exchanges']} frame + {e['view_exchanges']} view exchanges per evaluation")
+        assert worst <= 2e-3 and mean <= 2.5e-4
+        err = (ref["traj"] - ref["traj_ref"]).abs().max().item()
+        assert err <= 5e-3 * ref["traj_ref"].abs().max().item(), err
+    lo = RankLayout(8, 5, cfg=2, frames=2, views=2)
+    assert (lo.sample, lo.half, lo.frame_group, lo.view_group) == (0, 1, 0, 1)
+    assert lo.frame_group_ranks(0, 1, 1) == [5, 7] and lo.view_group_ranks(0, 1, 0) == [4, 5] and lo.cfg_pair_ranks(0, 1) == [1, 5]
+    assert layout_for(8, 5, "cfg+views+frames") == lo
+    assert layout_for(16, 0, "cfg+views+frames").frames == 4

@@ -366,6 +366,9 @@ def main():
     ap.add_argument("--gemm-group-m", type=int, default=0,
                     help="A/B: PNC_OPT_GEMM_GROUP_M (0 = auto, 1 = plain tile order, k = groups of k row panels); same result")
     ap.add_argument("--no-modes", action="store_true", help="do not time the other operand policy (profiling runs)")
+    ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B: pnc_set_option before the run, e.g. ATTN_VARIANT=42, ATTN_DEFER_MAX=0, GEMM_PERSIST=0 (hip.OPT_<NAME>); "
+                         "recorded in the output line under config.options")
     ap.add_argument("--ff-chain", action="store_true",
                     help="A/B: level-0 feed-forwards through the fused pnc_ff_chain_f16 launch (off by default: measured no faster)")
     ap.add_argument("--hoist", action="store_true",
@@ -423,6 +426,9 @@ def main():
         hip.set_option(hip.OPT_GEMM_GROUP_M, args.gemm_group_m)
     if args.ff_chain:
         engine.FUSE_FF_CHAIN = True
+    for kv in args.set_option:
+        name, _, val = kv.partition("=")
+        hip.set_option(getattr(hip, "OPT_" + name.upper()), int(val))
     primary = "replica" if args.parallelism == "auto" else args.parallelism
     layout = parallel.layout_for(world, rank, primary)
     groups = parallel.Groups(layout) if (layout.per_sample > 1) else None
@@ -571,7 +577,7 @@ def main():
                                 (", last-frame concat conditioning, share-noise init (inference_nuscenes.yaml)" if args.yaml_exact else ""))
                                if args.config == "full" else "tiny",
                    "precision": E_precision_name(args.precision),
-                   "frames_per_step": 2 * T, "parallelism": layout.name,
+                   "frames_per_step": 2 * T, "parallelism": layout.name, **({"options": args.set_option} if args.set_option else {}),
                    "ranks_per_sample": layout.per_sample, "per_sample_latency_ms": ms_per_step,
                    "graph": bool(args.graph), "streams": 1 if args.one_stream else 2,
                    "hoisted_step_invariants": bool(args.hoist), "fused_step_tail": bool(smp.fuse and shard is None and vshard is None and layout.cfg == 1)},

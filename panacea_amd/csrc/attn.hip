@@ -36,8 +36,13 @@ __device__ __attribute__((aligned(16))) half_t g_attn_zero_chunk[8];   // zero-i
 // with global_load_lds_dwordx4, no VGPR round trip and no ds_write; wv_shift = log2(view width) when it is a power of
 // two (every level: 64 / 32 / 16 / 8) so that the per-lane key -> (row, column) split of each tile is a shift, not an
 // integer division.  Staging was 25-30 % of the kernel at level 0 (ablation: tools/exp, profiles/round1).
+// 4 waves x 2 blocks is compiled for TWO waves per SIMD (<= 256 registers, second launch-bounds argument = waves per EU): two
+// such workgroups share a CU without sharing a barrier, so the softmax (VALU) phase of one can run under the MFMA phases of
+// the other — the 8-wave workgroup's waves are re-aligned by its barrier every tile (profiles/round2/attn_pmc_l0_intra_r2m.txt:
+// VALU 64 % + MFMA 29 % of the SIMD time, one after the other).
 template <int NW, int QB, bool DMA>
-__global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams p, const int wv_shift) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_views_kernel(const PncAttnParams p, const int wv_shift,
+                                                                                          const float defer_thr, const int dma_mode) {
     constexpr int QT = NW * QB * 32;
     constexpr int ROWS_PER_IT = NW * 8;          // K / V^T rows staged per iteration (8 rows per wave)
     constexpr int ST_IT = 64 / ROWS_PER_IT;      // 2 (4 waves) or 1 (8 waves)
@@ -148,12 +153,40 @@ __global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams
         }
     };
 
+    // Incremental DMA addresses (round 4): when a tile covers whole rows of the key view (KT % view width == 0: every level of the
+    // network) and the view holds whole tiles, a lane's K row / V^T chunk of tile (segment s, tile tt) is a LANE constant plus a
+    // WAVE-UNIFORM offset tt * (KT / Wv) * kvW + seg[s] * Wv (in rows of K, in keys of V^T): the per-tile key -> (row, column)
+    // split, the bound tests and the 64-bit multiplies (~50 VALU per tile and wave, next to ~280 of softmax) leave the loop;
+    // what remains is scalar arithmetic and one 64-bit add per DMA instruction.  Same addresses: bit-identical.
+    const bool inc_addr = DMA && dma_mode == 1 && wv_shift >= 0 && kvWv <= KT && (Nkv % KT) == 0 && nseg <= 2;
+    const half_t* kptr[ST_IT];
+    const half_t* vptr[ST_IT];
+#pragma unroll
+    for (int i = 0; i < ST_IT; ++i) {
+        const int r = sr + ROWS_PER_IT * i;
+        const int sh = wv_shift < 0 ? 0 : wv_shift;
+        kptr[i] = K + ((int64_t)kvg * p.kv_rows_per_group + (int64_t)(r >> sh) * p.kvW + (r & ((1 << sh) - 1))) * p.ldk + hc + sc8 * 8;
+        vptr[i] = VT + (int64_t)kvg * p.vt_gstride + (int64_t)(hc + r) * p.ldvt + (int64_t)((sc8 * 8) >> sh) * p.kvW + ((sc8 * 8) & ((1 << sh) - 1));
+    }
+    const int rows_per_tile_kvW = (wv_shift >= 0 ? (KT >> wv_shift) : 0) * p.kvW;
+    // (the segment's view index is read ONCE: indexed per tile it is a scalar load + lgkmcnt(0) in front of every tile's DMA)
+    const int seg_off0 = p.seg[view][0] * kvWv, seg_off1 = p.seg[view][nseg > 1 ? 1 : 0] * kvWv;
     auto dma_tile = [&](int t, int stage) {        // DMA path: same addresses, destination = this wave's 8 rows
+        char* sk = smem + stage * (2 * KT * 128) + wave * 1024;
+        char* sv = sk + KT * 128;
+        if (inc_addr) {                            // (uniform)
+            const int s1 = t >= tiles_per_seg ? 1 : 0, tt1 = t - s1 * tiles_per_seg;
+            const int64_t urow = (int64_t)tt1 * rows_per_tile_kvW + (s1 ? seg_off1 : seg_off0);
+#pragma unroll
+            for (int i = 0; i < ST_IT; ++i) {
+                glds16(kptr[i] + urow * p.ldk, sk + i * (ROWS_PER_IT * 128));
+                glds16(vptr[i] + urow, sv + i * (ROWS_PER_IT * 128));
+            }
+            return;
+        }
         const int s = t / tiles_per_seg, tt = t - s * tiles_per_seg;
         const int kview = p.seg[view][s];
         const int key0 = tt * KT;
-        char* sk = smem + stage * (2 * KT * 128) + wave * 1024;
-        char* sv = sk + KT * 128;
 #pragma unroll
         for (int i = 0; i < ST_IT; ++i) {
             const int key = key0 + sr + ROWS_PER_IT * i;
@@ -228,11 +261,16 @@ __global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             if (key0 + KT > p.kv_valid) {
+                // keys at or beyond kv_valid are padding: tile-local key index kh*32 + r (compile-time) against ONE per-lane limit.
+                // The limit is kept opaque inside the branch: hipcc otherwise speculates the whole index / compare chain (32 v_or +
+                // 61 v_cmp per tile) out of it into EVERY tile's instruction stream, where only the last tile of a segment masks.
+                int lim = p.kv_valid - key0 - grp * 16;
+                asm volatile("" : "+v"(lim));
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (key0 + kh * 32 + grp * 16 + r >= p.kv_valid) s[qb][kh][r] = -1e30f;
+                        if (kh * 32 + r >= lim) s[qb][kh][r] = -1e30f;
             }
             float tmax = -1e30f;
 #pragma unroll
@@ -240,8 +278,12 @@ __global__ __launch_bounds__(64 * NW) void attn_views_kernel(const PncAttnParams
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[qb][kh][r]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sc;          // scaled (exp2) domain; masked -> -inf-ish
-            // running max: rescale the accumulators only when some query of the wave actually raised its max
-            if (__builtin_amdgcn_ballot_w64(tmax > mrun[qb]) != 0) {
+            // running max: rescale the accumulators only when some query of the wave raised its max by more than defer_thr (exp2
+            // domain).  Until then the old max stays the reference — P = exp2(s - m_old) <= 2^defer_thr, exact in fp32 and far
+            // inside fp16 — and the 64 accumulator multiplies + the alpha exp are skipped: on i.i.d. data some lane of a wave
+            // raises its max in most tiles (64 lanes x 1/t each), by more than 8 almost never after the first tile
+            // (PNC_OPT_ATTN_DEFER_MAX; the first tile always rescales: mrun starts at -1e30)
+            if (__builtin_amdgcn_ballot_w64(tmax > mrun[qb] + defer_thr) != 0) {
                 const float mnew = fmaxf(mrun[qb], tmax);
                 const float alpha = __builtin_amdgcn_exp2f(mrun[qb] - mnew);
                 mrun[qb] = mnew;
@@ -440,17 +482,21 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     // per CU hide its latencies better than one of 8 waves — 4 x 1: 90 / 48 / 30 us at levels 0-2 vs 100 / 53 / 37 for 8 x 2
     // (profiles/round3/attn_text_variants_r3p.txt).
     const int kv_keys = p.kv_valid * 2;                           // at most two K/V segments per view
-    const int variant = force ? force : (kv_keys <= 256 ? 41 : (Nq >= 512 ? 82 : (Nq >= 256 ? 81 : 41)));
+    // force = 1: the size heuristic with the two-workgroups-per-CU shape (42) where it would pick 82 (whole-step A/B)
+    const int big = force == 1 ? 42 : 82;
+    const int variant = force >= 41 ? force : (kv_keys <= 256 ? 41 : (Nq >= 512 ? big : (Nq >= 256 ? 81 : 41)));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const bool dma = ((kvWv & 7) == 0) && ((p.kvW & 7) == 0) && ((p.ldvt & 7) == 0) && ((p.vt_gstride & 7) == 0) &&
-                     pnc_get_option(PNC_OPT_ATTN_DMA) != 0;
+    const int dma_mode = pnc_get_option(PNC_OPT_ATTN_DMA);
+    const bool dma = ((kvWv & 7) == 0) && ((p.kvW & 7) == 0) && ((p.ldvt & 7) == 0) && ((p.vt_gstride & 7) == 0) && dma_mode != 0;
     int wv_shift = -1;
     if (kvWv > 0 && (kvWv & (kvWv - 1)) == 0) { wv_shift = 0; while ((1 << wv_shift) < kvWv) ++wv_shift; }
+    int dopt = pnc_get_option(PNC_OPT_ATTN_DEFER_MAX);
+    const float defer_thr = (float)(dopt < 0 ? 0 : (dopt > 14 ? 14 : dopt));
 #define PNC_ATTN_LAUNCH(NW_, QB_, QTILE_)                                                                         \
     do {                                                                                                          \
         dim3 grid((Nq + (QTILE_) - 1) / (QTILE_), p.views, p.groups * p.heads);                                   \
-        if (dma) hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, true>), grid, dim3(64 * NW_), 0, st, p, wv_shift);  \
-        else hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, false>), grid, dim3(64 * NW_), 0, st, p, wv_shift);   \
+        if (dma) hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, true>), grid, dim3(64 * NW_), 0, st, p, wv_shift, defer_thr, dma_mode);  \
+        else hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, false>), grid, dim3(64 * NW_), 0, st, p, wv_shift, defer_thr, dma_mode);   \
     } while (0)
     if (variant == 42) PNC_ATTN_LAUNCH(4, 2, 256);
     else if (variant == 82) PNC_ATTN_LAUNCH(8, 2, 512);

@@ -183,6 +183,7 @@ def load():
 
 OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA, OPT_GEMM_FUSE_LN, OPT_GEMM_GROUP_M, OPT_STENCIL_TILES = 0, 1, 2, 3, 4, 5, 6
 OPT_GEMM_PERSIST = 7
+OPT_ATTN_DEFER_MAX = 8
 
 
 def build_digest() -> str:
@@ -192,7 +193,7 @@ def build_digest() -> str:
 
 def set_option(option: int, value: int) -> int:
     """pnc_set_option: process-global tuning / test switch of the library; returns the previous value."""
-    if not 0 <= option <= OPT_GEMM_PERSIST:
+    if not 0 <= option <= OPT_ATTN_DEFER_MAX:
         raise PncError(f"unknown library option {option}")
     return load().pnc_set_option(option, value)
 

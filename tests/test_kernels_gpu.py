@@ -668,6 +668,83 @@ def test_attn_views_every_variant(variant, G, H, W, heads, segs):
         hip.set_option(hip.OPT_ATTN_VARIANT, prev)
 
 
+@pytest.mark.parametrize("variant", [0, 41, 81, 42, 82])
+@pytest.mark.parametrize("G,H,W,heads,segs", [(2, 8, 96, 2, CROSS), (1, 16, 192, 1, CROSS), (1, 32, 384, 1, INTRA), (1, 32, 384, 1, CROSS)])
+def test_attn_views_incremental_tile_addresses_are_bit_identical(variant, G, H, W, heads, segs):
+    """PNC_OPT_ATTN_DMA 1 (lane constant + wave-uniform tile offset, round 4) against 2 (key -> (row, column) split recomputed per
+    tile): the same addresses, hence the same bits — views of 16 / 32 / 64 columns (the network's levels 2 / 1 / 0), one and two
+    key segments, 2 .. 64 tiles per view; and against the emulation."""
+    C, N, views = heads * 64, H * W, len(segs)
+    q, k, _, vt = _qkv(G, N, C, 7)
+    kw = dict(groups=G, heads=heads, H=H, W=W, views=views, kvH=H, kvW=W, kv_views=views,
+              kv_rows_per_group=N, q_per_kv=1, kv_valid=H * (W // views), segs=segs, scale=0.125)
+    outs = []
+    pv = hip.set_option(hip.OPT_ATTN_VARIANT, variant)
+    try:
+        for mode in (1, 2):
+            pm = hip.set_option(hip.OPT_ATTN_DMA, mode)
+            o = torch.zeros(G * N, C, device=DEV, dtype=torch.float16)
+            hip.attn_views(q, C, k, C, vt, N, C * N, o, C, **kw)
+            hip.set_option(hip.OPT_ATTN_DMA, pm)
+            outs.append(o)
+    finally:
+        hip.set_option(hip.OPT_ATTN_VARIANT, pv)
+    oe = torch.zeros_like(outs[0])
+    emu.attn_views(q, C, k, C, vt, N, C * N, oe, C, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    check("attn_views_inc", outs[0], oe, 3e-3)
+
+
+@pytest.mark.parametrize("scale_q", [1.0, 4.0, 12.0])
+def test_attn_views_deferred_running_max(scale_q):
+    """PNC_OPT_ATTN_DEFER_MAX: the running maximum is only raised (and the accumulators rescaled) when some query of the wave
+    exceeds it by more than k in the exp2 domain; k = 0 is the classic online softmax.  Same softmax for every k — checked on
+    near-uniform, sharp and very sharp (one-hot-like: growth of the max by far more than k between tiles) score rows."""
+    G, H, W, heads = 1, 16, 192, 2
+    C, N = heads * 64, H * W
+    q, k, _, vt = _qkv(G, N, C, 13)
+    q = q * scale_q
+    kw = dict(groups=G, heads=heads, H=H, W=W, views=6, kvH=H, kvW=W, kv_views=6, kv_rows_per_group=N,
+              q_per_kv=1, kv_valid=H * (W // 6), segs=CROSS, scale=0.125)
+    oe = torch.zeros(G * N, C, device=DEV, dtype=torch.float16)
+    emu.attn_views(q, C, k, C, vt, N, C * N, oe, C, **kw)
+    for thr in (0, 8, 14):
+        prev = hip.set_option(hip.OPT_ATTN_DEFER_MAX, thr)
+        try:
+            oh = torch.zeros_like(oe)
+            hip.attn_views(q, C, k, C, vt, N, C * N, oh, C, **kw)
+            torch.cuda.synchronize()
+        finally:
+            hip.set_option(hip.OPT_ATTN_DEFER_MAX, prev)
+        check(f"attn_views_defer{thr}_q{scale_q}", oh, oe, 5e-3)
+
+
+def test_groupnorm_combine_kernel():
+    """pnc_groupnorm_combine (round 4): Chan combination of the all-gathered chunk records of a view group's bands, against the
+    float64 formula; the apply kernel fed with the combined records normalises with the statistics of the concatenation."""
+    F, Npix, C, ppc, parts = 2, 300, 320, 64, 3
+    nchunk = (Npix + ppc - 1) // ppc
+    xs = [rnd(F * Npix, C, seed=30 + s) * (1.0 + 0.5 * s) + 0.3 * s for s in range(parts)]
+    recs = torch.zeros(parts, F * nchunk * 96, device=DEV)
+    for s in range(parts):
+        hip.groupnorm_stats(xs[s], C, F, Npix, C, ppc, recs[s])
+    out_h, out_e = torch.full((F * nchunk * 96,), -1.0, device=DEV), torch.zeros(F * nchunk * 96, device=DEV)
+    hip.groupnorm_combine(recs.view(-1), parts, F, nchunk, out_h)
+    emu.groupnorm_combine(recs.view(-1), parts, F, nchunk, out_e)
+    torch.cuda.synchronize()
+    oh, oe = out_h.view(F, nchunk, 32, 3), out_e.view(F, nchunk, 32, 3)
+    assert not oh[:, 1:].any() and torch.equal(oh[:, 0, :, 0], oe[:, 0, :, 0])
+    assert torch.allclose(oh[:, 0, :, 1], oe[:, 0, :, 1], atol=1e-6) and torch.allclose(oh[:, 0, :, 2], oe[:, 0, :, 2], rtol=1e-5)
+    # band 0 normalised with the panorama's statistics == GroupNorm over the concatenated bands, band 0's rows
+    gamma, beta = rnd(C) * 0.5 + 1, rnd(C) * 0.3
+    y = torch.zeros(F * Npix, C, device=DEV, dtype=torch.float16)
+    hip.groupnorm_apply(xs[0], C, F, Npix, C, ppc, out_h, gamma, beta, 1e-5, 0, y, C)
+    pano = torch.cat([x.view(F, Npix, C) for x in xs], dim=1)
+    ref = torch.nn.functional.group_norm(pano.permute(0, 2, 1), 32, gamma, beta, 1e-5)[:, :, :Npix]
+    check("groupnorm_combined", y.view(F, Npix, C).permute(0, 2, 1), ref, 4e-3)
+
+
 def test_attn_views_sharp_softmax():
     # large-magnitude scores: exercises the running-max rescale across KV tiles
     G, H, W, heads = 1, 8, 96, 1

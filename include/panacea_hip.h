@@ -48,8 +48,8 @@ enum {
                                      (bit-identical to 0: rows of a GEMM are independent) */
     PNC_OPT_GEMM_TILE = 1,        /* 0 (default): score-based tile choice; 1 = 128x128, 2 = 256x128, 3 = 256x320,
                                      4 = 256x256 force a geometry where the shape allows it (kernel micro-benchmarks) */
-    PNC_OPT_ATTN_VARIANT = 2,     /* 0 (default): by view size; 41 / 81 / 42 / 82 = (waves, query blocks per wave); 42 runs two independent
-                                     4-wave workgroups per CU (<= 256 registers); 1 = by view size with 42 in the place of 82 */
+    PNC_OPT_ATTN_VARIANT = 2,     /* 0 (default): by view size; 41 / 81 / 42 / 82 = (waves, query blocks per wave); 42 (large views, default) runs two independent
+                                     4-wave workgroups per CU (<= 256 registers); 1 = by view size with 82 (round 3's choice) in the place of 42 */
     PNC_OPT_ATTN_DMA = 3,         /* 1 (default): LDS-DMA staging of K / V^T tiles where alignment allows, tile addresses kept as lane constant +
                                      wave-uniform offset; 2 = LDS-DMA with per-tile recomputed addresses (A/B); 0 = register staging.  Same results */
     PNC_OPT_GEMM_FUSE_LN = 4,     /* 1 (default): PncGemmParams.ln_* is reduced in the GEMM epilogue where a workgroup owns whole
@@ -61,9 +61,11 @@ enum {
                                      the input incl. its halo per 64-channel slice and read the nine taps from it (gemm_stencil_tile.hip);
                                      0 = always one gathered A tile per tap; 2 = wherever the shape allows (tests).  Bit-identical
                                      results either way */
-    PNC_OPT_GEMM_PERSIST = 7,     /* 1 (default): GEGLU GEMMs of >= 512 full 256x256 tiles run as ONE persistent workgroup per CU that
-                                     requests the next output tile's first K tile before its epilogue (same results); 0 = one tile per
-                                     workgroup */
+    PNC_OPT_GEMM_PERSIST = 7,     /* bit set, 3 (default).  Bit 0: GEGLU GEMMs of >= 512 full 256x256 tiles run as ONE persistent workgroup
+                                     per CU that requests the next output tile's first K tile before its epilogue; bit 1 (round 4): the
+                                     same for plain-A launches of >= 512 full 256x320 tiles with a row-major epilogue (residual in place,
+                                     fused LayerNorm, fp16 / channel-major outputs, e4m3 lo pass).  Same results either way; 0 = one
+                                     tile per workgroup */
     PNC_OPT_ATTN_DEFER_MAX = 8,   /* k (default 8): pnc_attn_views_f16 keeps a query's running softmax maximum — and skips the
                                      rescaling of its accumulators — until some query of the wave exceeds it by more than k in the
                                      exp2 domain (probabilities then reach at most 2^k: fp16-safe up to 15); 0 = rescale whenever a

@@ -1237,8 +1237,450 @@ int launch_geglu_persist(const PncGemmParams& p, hipStream_t st) {
 }
 // the persistent kernel serves this problem (and the switch is on)
 static inline bool geglu_persist_ok(const PncGemmParams& p) {
-    return pnc_get_option(PNC_OPT_GEMM_PERSIST) != 0 && p.geglu && p.a_mode == PNC_A_PLAIN && !p.A_lo && !p.out16_lo && p.out16 &&
+    return (pnc_get_option(PNC_OPT_GEMM_PERSIST) & 1) != 0 && p.geglu && p.a_mode == PNC_A_PLAIN && !p.A_lo && !p.out16_lo && p.out16 &&
            (p.M % 256) == 0 && (p.N % 256) == 0 && (p.K % 64) == 0 && p.K >= 64 && (p.M / 256) * (p.N / 256) >= 512;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the plain-A 256x320 GEMM for the fp32-epilogue families (round 4; PNC_OPT_GEMM_PERSIST bit 1): C x C
+// projections with the residual stream in place (+ fused LayerNorm), proj_in (+ position table) + norm1, FF2 — the launches
+// that are 0.09-0.25 of the MFMA peak because a 5-10 K-tile main loop and a 630 MB epilogue stream simply ADD
+// (profiles/round3/fixed_cost_per_tile_r3q.txt).  One workgroup per CU walks its share of the output tiles and requests the
+// FIRST K tile of the next output tile before the epilogue of the current one, as gemm_geglu_persist_kernel does for FF1.
+// What FF1 did not need: these epilogues stage fp32 slabs of 8.7 KB per wave INSIDE the operand ring (2 x 72 KB of the 160 KB;
+// no room for a staging array of its own), and hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS access it can see that may
+// alias an LDS-DMA in flight — which would drain the prefetch AND every residual load / store of the rolling pipeline (vmcnt
+// counts stores on gfx950).  So the epilogue's LDS traffic is written as inline asm (ds_write / ds_read + counted lgkmcnt
+// waits that carry the registers they guard): the staging lives in stage 0 (exactly its 73 728 bytes incl. the LayerNorm
+// row sums), the prefetch goes to stage 1, and the next tile's K loop starts there.  Same tiles, K order, MFMA order and
+// epilogue arithmetic as gemm_glds_kernel<PNC_A_PLAIN, 256, 320, 4, 2, 2, false, EPI>: bit-identical
+// (tests/test_kernels_gpu.py::test_gemm_persistent_kernel_is_bit_identical).
+__device__ __forceinline__ void alds_w32(unsigned a, float v, int off) {
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(off) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void alds_w32c(unsigned a, float v) { asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ float alds_r32c(unsigned a) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void alds_w128c(unsigned a, f32x4 v) { asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ f32x4 alds_r128c(unsigned a) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF = 0>
+__device__ __forceinline__ float2 alds_r64(unsigned a) {
+    float2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF = 0>
+__device__ __forceinline__ void alds_w64(unsigned a, float2 v) { asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF) : "memory"); }
+// wait until at most N of this wave's LDS operations are outstanding; the registers the wait guards are operands, so that no
+// use of them can be scheduled above it
+template <int N>
+__device__ __forceinline__ void alds_wait(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+__device__ __forceinline__ void alds_wait0(float2& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
+__device__ __forceinline__ void alds_wait0(float2& a, float2& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
+__device__ __forceinline__ void alds_wait0(f32x16& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
+__device__ __forceinline__ void alds_wait0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// epi_fast() of a full wave tile (every row / column inside the matrix: the host guarantees M % BM == 0, N % BN == 0) with all
+// LDS traffic in asm.  `ep`: LDS byte address of this wave's staging region (32 x EPITCH floats), `ln_mine` / `ln_partner`:
+// byte addresses of the two 64-row float2 statistics arrays of the wave pair that shares the rows.  One added stream at most
+// (res1 or the row bias).  The arithmetic — order of the additions, one-pass LayerNorm statistics — is epi_fast's.
+template <int MI, int NI, unsigned EPI>
+__device__ __forceinline__ void epi_fast_alds(const PncGemmParams& p, f32x16 (&acc)[MI][NI], unsigned ep, int lane_in,
+                                              int mw, int nw, unsigned ln_mine, unsigned ln_partner) {
+    // every lane constant of the epilogue hangs off this opaque copy: computed per call (= per output tile), not hoisted out of
+    // the persistent kernel's tile loop into ~40 more registers that live through the main loop
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    constexpr bool R1 = (EPI & E_R1) != 0, RB = (EPI & E_RB) != 0;
+    constexpr bool O32 = (EPI & E_O32) != 0, O16 = (EPI & E_O16) != 0, LN = (EPI & E_LN) != 0;
+    static_assert((EPI & (E_R2 | E_VT | E_GEGLU | E_GELU | E_GENERIC)) == 0, "persistent variants: one added stream, row-major outputs");
+    static_assert(!(R1 && RB), "one added stream");
+    static_assert(!LN || O32, "the fused LayerNorm normalises the fp32 output it has just written");
+    constexpr bool HAS_X = R1 || RB;
+    constexpr int ENI = 2, EPITCH = ENI * 32 + 4;
+    constexpr int NJ = (NI + ENI - 1) / ENI, NS = NJ * MI, NPMAX = 4;
+    half_t* out16 = reinterpret_cast<half_t*>(p.out16);
+    void* out16_lo = p.out16_lo;
+    const bool silu = (!HAS_X) && (p.act == PNC_ACT_SILU);
+    const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 x0[NPMAX], x1[NPMAX];
+    // E_LN: the final fp32 values of the wave tile stay in registers between the two passes, in the ROW-MAJOR layout the passes
+    // work in (8 consecutive columns of one row per lane and pass) — they take the place of the accumulator blocks, which are dead
+    // once staged.  (epi_fast writes them back to the slab and reloads the MFMA layout, then stages a second time: 72 more LDS
+    // instructions per slab, and the reload keeps all 160 accumulator registers live through pass 1.)
+    float fin[LN ? NS : 1][NPMAX][8];
+    if constexpr (LN) {
+        if (lane < MI * 32) alds_w64(ln_mine + (unsigned)lane * 8u, make_float2(0.0f, 0.0f));
+    }
+    // staging addresses: a lane WRITES accumulator register r of column block j at row mfma32_row(r, lane), column j*32 + (lane & 31)
+    // and READS 8 consecutive columns cl*8 of row ps*RPP + rl; everything but the lane part is an instruction offset
+    const unsigned wbase = ep + (unsigned)((4 * (lane >> 5)) * EPITCH + (lane & 31)) * 4u;
+
+    auto load_x = [&](auto s_, auto ps_) {
+        constexpr int s = decltype(s_)::value, ps = decltype(ps_)::value;
+        constexpr int jc = (s / MI) * ENI, i = s % MI, cw = (NI - jc) < ENI ? (NI - jc) : ENI;
+        constexpr int CPL = cw * 4, RPP = 64 / CPL;
+        const int cl = lane % CPL, rl = lane / CPL;
+        const int ncol = nw + jc * 32 + cl * 8;
+        const int m = mw + i * 32 + ps * RPP + rl;
+        const float* xp = R1 ? p.res1 + (int64_t)m * p.ldr1 + ncol
+                             : p.rowbias + (int64_t)((m / p.rb_rows) % p.rb_mod) * p.N + ncol;
+        x0[ps] = ld4(xp); x1[ps] = ld4(xp + 4);
+    };
+
+    static_for<NS>([&](auto s_) {
+        constexpr int s = decltype(s_)::value, jc = (s / MI) * ENI, i = s % MI;
+        constexpr int cw = (NI - jc) < ENI ? (NI - jc) : ENI;
+        constexpr int CPL = cw * 4, RPP = 64 / CPL, NP = 32 / RPP;
+        const int cl = lane % CPL, rl = lane / CPL;
+        const int ncol = nw + jc * 32 + cl * 8;
+        const unsigned rbase = ep + (unsigned)(rl * EPITCH + cl * 8) * 4u;
+        f32x4 b0 = z4, b1 = z4;
+        if (p.bias) { b0 = ld4(p.bias + ncol); b1 = ld4(p.bias + ncol + 4); }
+        static_for<cw>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            static_for<16>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                alds_w32c<(((r & 3) + 8 * (r >> 2)) * EPITCH + j * 32) * 4>(wbase, acc[i][jc + j][r]);
+            });
+        });
+        if constexpr (s == 0 && HAS_X) {
+            static_for<NP>([&](auto ps_) { load_x(std::integral_constant<int, 0>{}, ps_); });
+        }
+        // (a wave's LDS operations execute in order: the reads below see the writes above without a wait in between)
+        // The passes run in batches of NB: their staged rows are read together, consumed under counted waits.  (All NP passes
+        // at once hold 32 registers of staged values next to the 32 of the rolling stream prefetch and the 160 accumulators:
+        // the LayerNorm variants then spilled 40-80 VGPRs.)
+        constexpr int NB = (NP < 2 || (LN && HAS_X)) ? 1 : 2;     // (LayerNorm + added stream: one pass at a time, no spill)
+        static_for<NP / NB>([&](auto bt_) {
+        constexpr int bt = decltype(bt_)::value;
+        f32x4 a0[NB], a1[NB];
+        static_for<NB>([&](auto q_) {
+            constexpr int q = decltype(q_)::value, ps = bt * NB + q;
+            a0[q] = alds_r128c<ps * RPP * EPITCH * 4>(rbase);
+            a1[q] = alds_r128c<ps * RPP * EPITCH * 4 + 16>(rbase);
+        });
+        static_for<NB>([&](auto q_) {
+            constexpr int q = decltype(q_)::value, ps = bt * NB + q;
+            std::integral_constant<int, ps> ps_;
+            alds_wait<2 * (NB - 1 - q)>(a0[q], a1[q]);
+            const int m = mw + i * 32 + ps * RPP + rl;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a0[q][e] + b0[e]; v[e + 4] = a1[q][e] + b1[e]; }
+            if constexpr (HAS_X) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += x0[ps][e]; v[e + 4] += x1[ps][e]; }
+            } else {
+                if (silu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                }
+            }
+            if constexpr (HAS_X && s + 1 < NS) {
+                constexpr int jn = ((s + 1) / MI) * ENI, cwn = (NI - jn) < ENI ? (NI - jn) : ENI;
+                constexpr int NPn = 32 / (64 / (cwn * 4));
+                if constexpr (ps < NPn) load_x(std::integral_constant<int, s + 1>{}, ps_);
+            }
+            if constexpr (LN) {
+                float sm = 0.0f, sq = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sm += v[e]; sq = fmaf(v[e], v[e], sq); }
+#pragma unroll
+                for (int o = 1; o < CPL; o <<= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }
+                if (cl == 0) {
+                    const unsigned la = ln_mine + (unsigned)rl * 8u;           // + (i * 32 + ps * RPP) rows as the instruction offset
+                    float2 t = alds_r64<(i * 32 + ps * RPP) * 8>(la);
+                    alds_wait0(t);
+                    t.x += sm; t.y += sq;
+                    alds_w64<(i * 32 + ps * RPP) * 8>(la, t);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fin[s][ps][e] = v[e];
+            }
+            if constexpr (O32) {
+                float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
+                *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+            if constexpr (O16) store_h8(out16, out16_lo, (int64_t)m * p.ldc16 + ncol, v, p.out_lo_fmt);
+        });
+        });
+    });
+    if constexpr (LN) {
+        alds_wait0();
+        __builtin_amdgcn_s_barrier();             // both halves of every row have their statistics in LDS
+        half_t* lnout = reinterpret_cast<half_t*>(p.ln_out16);
+        const float invn = 1.0f / (float)p.N;
+        static_for<NS>([&](auto s_) {
+            constexpr int s = decltype(s_)::value, jc = (s / MI) * ENI, i = s % MI;
+            constexpr int cw = (NI - jc) < ENI ? (NI - jc) : ENI;
+            constexpr int CPL = cw * 4, RPP = 64 / CPL, NP = 32 / RPP;
+            const int cl = lane % CPL, rl = lane / CPL;
+            const int ncol = nw + jc * 32 + cl * 8;
+            const f32x4 g0 = ld4(p.ln_gamma + ncol), g1 = ld4(p.ln_gamma + ncol + 4);
+            const f32x4 h0 = ld4(p.ln_beta + ncol), h1 = ld4(p.ln_beta + ncol + 4);
+            constexpr int NB = NP < 2 ? NP : 2;
+            static_for<NP / NB>([&](auto bt_) {
+            constexpr int bt = decltype(bt_)::value;
+            float2 sa[NB], sb[NB];
+            static_for<NB>([&](auto q_) {
+                constexpr int q = decltype(q_)::value, ps = bt * NB + q;
+                sa[q] = alds_r64<(i * 32 + ps * RPP) * 8>(ln_mine + (unsigned)rl * 8u);
+                sb[q] = alds_r64<(i * 32 + ps * RPP) * 8>(ln_partner + (unsigned)rl * 8u);
+            });
+            static_for<NB>([&](auto q_) {
+                constexpr int q = decltype(q_)::value, ps = bt * NB + q;
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(sa[q]), "+v"(sb[q]) : "n"(2 * (NB - 1 - q)) : "memory");
+                const int m = mw + i * 32 + ps * RPP + rl;
+                const float mean = (sa[q].x + sb[q].x) * invn;
+                const float var = fmaxf((sa[q].y + sb[q].y) * invn - mean * mean, 0.0f);
+                const float rs = rsqrtf(var + p.ln_eps);
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = fmaf((fin[s][ps][e] - mean) * rs, g0[e], h0[e]);
+                    y[e + 4] = fmaf((fin[s][ps][e + 4] - mean) * rs, g1[e], h1[e]);
+                }
+                store_h8(lnout, nullptr, (int64_t)m * p.ldln + ncol, y);
+            });
+            });
+        });
+    }
+}
+
+template <unsigned EPI>
+__global__ __launch_bounds__(512) void gemm_persist_kernel(const PncGemmParams pin, const int group_m) {
+    PncGemmParams p = pin;
+    constexpr int BM = 256, BN = 320, WGM = 4, WGN = 2;
+    constexpr int NW = WGM * WGN, MI = BM / WGM / 32, NI = BN / WGN / 32, RPI = NW * 8, A_IT = BM / RPI, B_IT = BN / RPI;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int EPITCH = 2 * 32 + 4;
+    static_assert(NW * (32 * EPITCH * 4 + 64 * 8) <= STAGE, "the epilogue's staging (+ LayerNorm row sums) lives in stage 0");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const half_t* __restrict__ A = reinterpret_cast<const half_t*>(p.A);
+    const half_t* __restrict__ Wt = reinterpret_cast<const half_t*>(p.W);
+    const int tiles_n = p.N / BN, tiles_m = p.M / BM, ntile = tiles_m * tiles_n;
+    const bool lo8 = p.A_lo != nullptr;                       // (host: e4m3 lo planes only)
+    const int ntiles = p.K / BK;
+    const int nt_lo = lo8 ? (p.K + BK8 - 1) / BK8 : 0;
+    const int ntot = ntiles + nt_lo;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    auto tile_origin = [&](int v, int& m0, int& n0) {         // the XCD-contiguous ranges and the grouped order of gemm_glds_kernel
+        const int tile = xcd_remap(v, ntile);
+        int tn, tm;
+        if (group_m > 0) {
+            const int width = group_m * tiles_n;
+            const int gid = tile / width, first_m = gid * group_m;
+            const int gsz = min(tiles_m - first_m, group_m);
+            const int in = tile - gid * width;
+            tm = first_m + in % gsz; tn = in / gsz;
+        } else {
+            tn = tile % tiles_n; tm = tile / tiles_n;
+        }
+        m0 = tm * BM; n0 = tn * BN;
+    };
+    f32x16 acc[MI][NI];
+    // the lane constants of the operand DMA and of the fragment reads (row / chunk split, per-lane window offsets, LDS row
+    // addresses: ~25 VGPRs) are derived from an opaque copy of the lane id INSIDE the tile loop: hoisted out of it they stay live
+    // through the epilogue, next to 160 accumulator registers and the epilogue's own 64, and the LayerNorm variants spilled 80
+    auto lane_consts = [&](int& srow, int& schunk, int& frow, int& fk) {
+        int lt = lane;
+        asm volatile("" : "+v"(lt));
+        srow = wave * 8 + (lt >> 3);
+        schunk = (lt & 7) ^ ((srow >> 1) & 7);
+        frow = lt & 31; fk = lt >> 5;
+    };
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    int v = blockIdx.x;
+    if (v >= ntile) return;
+    int m0, n0, sp = 0;
+    tile_origin(v, m0, n0);
+    bool first = true;
+    const unsigned smem_lds = (unsigned)(uintptr_t)smem;
+    const unsigned ep = smem_lds + (unsigned)wave * (32 * EPITCH * 4);
+    const unsigned lnb = smem_lds + NW * (32 * EPITCH * 4);
+    const bool late = wave >= 4 && ntot >= 8;
+    while (true) {
+        int srow, schunk, frow, fk;
+        lane_consts(srow, schunk, frow, fk);
+        unsigned aoff[A_IT], woff[B_IT];                          // per-lane byte offsets inside a tile's windows: the same for every tile
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) aoff[i] = (unsigned)((i * RPI + srow) * p.lda + schunk * 8) * 2u;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) woff[i] = (unsigned)((i * RPI + srow) * p.ldw + schunk * 8) * 2u;
+        // K tile kt_local of the output tile at (m0, n0) into `stage`: e4m3 lo tiles first (128 k per 128-byte row), then the fp16 tiles
+        auto issue = [&](int m0, int n0, int kt_local, int stage) {
+            char* sa = smem + stage * STAGE + wave * 1024;
+            char* sb = sa + A_BYTES;
+            if (kt_local < nt_lo) {
+                int schunk8 = schunk, srow8 = srow;
+                asm volatile("" : "+v"(schunk8), "+v"(srow8));
+                const buffer_rsrc_t rs_alo = make_rsrc(reinterpret_cast<const char*>(p.A_lo) + (int64_t)m0 * p.lda, 0x7FFFFF00u);
+                const buffer_rsrc_t rs_wlo = make_rsrc(reinterpret_cast<const char*>(p.W_lo) + (int64_t)n0 * p.ldw_lo, 0x7FFFFF00u);
+                const int kc8 = kt_local * BK8 + schunk8 * 16;
+                const unsigned ks8 = (unsigned)kt_local * BK8;
+                // chunks of the last tile beyond K: bit 31 of the lane offset puts them past the resource's bound (zeros) — as an
+                // OR, not a select: hipcc turns the select into two DMA instructions under complementary EXEC masks per piece
+                const unsigned oob = (unsigned)(p.K - 1 - kc8) & 0x80000000u;
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i)
+                    glds16_buf(rs_alo, ((aoff[i] >> 1) + (unsigned)schunk8 * 8u) | oob, ks8, sa + i * (RPI * 128));
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i)
+                    glds16_buf(rs_wlo, (unsigned)((i * RPI + srow8) * p.ldw_lo + schunk8 * 16) | oob, ks8, sb + i * (RPI * 128));
+                return;
+            }
+            const buffer_rsrc_t rs_a = make_rsrc(A + (int64_t)m0 * p.lda, 0x7FFFFF00u);
+            const buffer_rsrc_t rs_w = make_rsrc(Wt + (int64_t)n0 * p.ldw, 0x7FFFFF00u);
+            const unsigned ks = (unsigned)(kt_local - nt_lo) * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) glds16_buf(rs_a, aoff[i], ks, sa + i * (RPI * 128));
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) glds16_buf(rs_w, woff[i], ks, sb + i * (RPI * 128));
+        };
+
+        // fp16 K tile: the non-pipelined fragment order of the 256x320 geometry (gemm_glds_kernel, PIPE = false)
+        auto compute = [&](int stage, int m0, int n0, int mid_kt, int mid_stage) {
+            const char* sa = smem + stage * STAGE;
+            const char* sb = sa + A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                half8v af[MI], bf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[i] = *reinterpret_cast<const half8v*>(sa + lds_off128(wm * (MI * 32) + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    bf[j] = *reinterpret_cast<const half8v*>(sb + lds_off128(wn * (NI * 32) + j * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                if (ks == 1 && mid_kt >= 0) issue(m0, n0, mid_kt, mid_stage);
+            }
+        };
+        auto compute8 = [&](int stage, int kt_local) {
+            const char* sa = smem + stage * STAGE;
+            const char* sb = sa + A_BYTES;
+            const int nwin = (p.K - kt_local * BK8) > 64 ? 2 : 1;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                if (w < nwin) {
+                    i32x8 af[MI];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int row = wm * (MI * 32) + i * 32 + frow;
+                        const i32x4 a0 = *reinterpret_cast<const i32x4*>(sa + lds_off128(row, w * 4 + fk * 2));
+                        const i32x4 a1 = *reinterpret_cast<const i32x4*>(sa + lds_off128(row, w * 4 + fk * 2 + 1));
+                        af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int row = wn * (NI * 32) + j * 32 + frow;
+                        const i32x4 b0 = *reinterpret_cast<const i32x4*>(sb + lds_off128(row, w * 4 + fk * 2));
+                        const i32x4 b1 = *reinterpret_cast<const i32x4*>(sb + lds_off128(row, w * 4 + fk * 2 + 1));
+                        const i32x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf, acc[i][j], 0, 0, 0, E8M0_LO_INV, 0, p.w_lo_exp);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        };
+
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        if (first) { issue(m0, n0, 0, 0); first = false; }      // (uniform) every later tile's first K tile was prefetched
+        __syncthreads();                        // K tile 0 of this output tile has landed; the previous epilogue's staging is retired
+        for (int kt = 0; kt < nt_lo; ++kt) {
+            if (kt + 1 < ntot) issue(m0, n0, kt + 1, (sp + kt + 1) & 1);
+            compute8((sp + kt) & 1, kt);
+            __syncthreads();
+        }
+        for (int kt = nt_lo; kt < ntot; ++kt) {
+            const bool nxt = kt + 1 < ntot;
+            if (nxt && !late) issue(m0, n0, kt + 1, (sp + kt + 1) & 1);
+            compute((sp + kt) & 1, m0, n0, (nxt && late) ? kt + 1 : -1, (sp + kt + 1) & 1);
+            __syncthreads();
+        }
+        // every wave is past the last K tile: the ring is free.  The next output tile's first K tile goes to stage 1; the
+        // epilogue stages in stage 0 through asm LDS operations, which the compiler does not order against the DMA
+        const int vn = v + gridDim.x;
+        int m1 = 0, n1 = 0;
+        if (vn < ntile) {
+            tile_origin(vn, m1, n1);
+            issue(m1, n1, 0, 1);
+        }
+        if constexpr ((EPI & E_VT) != 0) {
+            // column tiles at or beyond n_split go channel-major straight from the accumulators (no LDS at all)
+            if (n0 >= p.n_split) epi_vt<MI, NI>(p, acc, lane, m0 + wm * (MI * 32), n0 + wn * (NI * 32));
+            else epi_fast_alds<MI, NI, (EPI & ~E_VT)>(p, acc, ep, lane, m0 + wm * (MI * 32), n0 + wn * (NI * 32), 0u, 0u);
+        } else {
+            epi_fast_alds<MI, NI, EPI>(p, acc, ep, lane, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lnb + (unsigned)wave * 512u,
+                                       lnb + (unsigned)(wave ^ 1) * 512u);
+        }
+        if (vn >= ntile) break;
+        alds_wait0();                           // this wave's staging reads have returned before it meets the others at the barrier
+        v = vn; m0 = m1; n0 = n1; sp = 1;
+    }
+}
+
+// the persistent plain-A kernel serves this problem (PNC_OPT_GEMM_PERSIST bit 1)
+static inline bool plain_persist_ok(const PncGemmParams& p, unsigned epi) {
+    if ((pnc_get_option(PNC_OPT_GEMM_PERSIST) & 2) == 0 || p.a_mode != PNC_A_PLAIN) return false;
+    if ((p.M % 256) || (p.N % 320) || (p.K % 64) || p.K < 64) return false;
+    if (p.A_lo && (p.a_lo_fmt != PNC_LO_E4M3 || (p.lda % 16))) return false;
+    if ((epi & E_LN) && p.N != 320) return false;
+    if ((epi & E_VT) && ((p.n_split % 320) || (p.M % 8) || (p.t_rows % 8))) return false;
+    return (p.M / 256) * (p.N / 320) >= 512;                 // at least two output tiles per workgroup
+}
+
+template <unsigned EPI>
+int launch_plain_persist(const PncGemmParams& p, hipStream_t st) {
+    constexpr int lds = 2 * (256 + 320) * 128;
+    static std::atomic<unsigned char> attr_done[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto kern = gemm_persist_kernel<EPI>;
+    if (!attr_done[dev & 63].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done[dev & 63].store(1, std::memory_order_release);
+    }
+    const int tiles_n = p.N / 320, tiles_m = p.M / 256, tiles = tiles_m * tiles_n;
+    const int gopt = pnc_get_option(PNC_OPT_GEMM_GROUP_M);
+    int group_m = gopt > 0 ? gopt : (tiles_n > 8 ? 4 : 0);
+    if (group_m > tiles_m) group_m = tiles_m;
+    if (tiles_n < 2) group_m = 0;
+    static std::atomic<int> ncu_of[64];
+    int ncu = ncu_of[dev & 63].load(std::memory_order_relaxed);
+    if (ncu == 0) {
+        int v = 0;
+        ncu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        ncu_of[dev & 63].store(ncu, std::memory_order_relaxed);
+    }
+    const int blocks = tiles < ncu ? tiles : ncu;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, p, group_m);
+    return pnc_launch_status();
 }
 
 template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE, unsigned EPI>

@@ -20,6 +20,20 @@ int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st, bool* l
         else epi &= ~E_LN;                      // the caller runs the LayerNorm kernel after this GEMM instead
     }
     if (tc.tile == T_128x32 && epi != E_O16 && epi != E_O32) epi = E_GENERIC;     // narrow-N: two fast variants
+    if (tc.tile == T_256x320 && tc.ksplit == 1 && plain_persist_ok(p, epi)) {
+        // level-0 launches of the fp32-epilogue families: one persistent workgroup per CU, next tile's first K tile under the epilogue
+        switch (epi) {
+            case E_O16: return launch_plain_persist<E_O16>(p, st);
+            case E_O16 | E_VT: return launch_plain_persist<E_O16 | E_VT>(p, st);
+            case E_O32: return launch_plain_persist<E_O32>(p, st);
+            case E_R1 | E_O32: return launch_plain_persist<E_R1 | E_O32>(p, st);
+            case E_R1 | E_O16: return launch_plain_persist<E_R1 | E_O16>(p, st);
+            case E_O32 | E_LN: return launch_plain_persist<E_O32 | E_LN>(p, st);
+            case E_RB | E_O32 | E_LN: return launch_plain_persist<E_RB | E_O32 | E_LN>(p, st);
+            case E_R1 | E_O32 | E_LN: return launch_plain_persist<E_R1 | E_O32 | E_LN>(p, st);
+            default: break;
+        }
+    }
     if (epi == (E_O16 | E_GELU) && tc.tile != T_256x256 && tc.tile != T_128x128) epi = E_GENERIC;
     switch (epi) {
         case E_O16: return launch_tile<AM, E_O16>(p, st, tc);                       // q (text), qkv (temporal), text K

@@ -155,6 +155,73 @@ def test_gemm_geglu_persistent_kernel_is_bit_identical(M, C, bias):
     assert torch.equal(o_per, o_ref) and o_ref.abs().max().item() > 0.1
 
 
+@pytest.mark.parametrize("variant", ["res_ln", "res_ln_lo8", "ln_lo8", "pos_ln", "res", "res_lo8", "o32", "ff2_o16_lo8", "q_o16", "qkv_vt"])
+def test_gemm_persistent_kernel_is_bit_identical(variant):
+    """PNC_OPT_GEMM_PERSIST bit 1 (round 4): plain-A launches of >= 512 full 256x320 tiles run as one persistent workgroup per CU
+    that requests the next output tile's first K tile before its epilogue; the epilogue's LDS staging is inline asm (it shares the
+    operand ring with the DMA in flight).  Same tiles, K order, MFMA order, epilogue arithmetic (incl. the fused LayerNorm's
+    one-pass statistics): bit-identical to the one-tile-per-workgroup kernel for every epilogue variant the network uses at
+    level 0 — residual in place + LayerNorm, proj_in (+ position table) + norm1 with an e4m3 lo pass, FF2 with fp16 + e4m3
+    outputs, the q projection, QKV with the channel-major V^T."""
+    from panacea_amd import engine
+    C = 320
+    K = 4 * C if variant.startswith("ff2") else C
+    N = 3 * C if variant == "qkv_vt" else C
+    M = 256 * (512 if N == C else 176)
+    assert (M // 256) * (N // 320) >= 512
+    a32 = rnd(M, K, seed=41)
+    a = a32.half()
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=42)
+    bias = rnd(N, seed=43)
+    kw = dict(M=M, N=N, K=K, lda=K, bias=bias)
+    if "lo8" in variant:
+        alo = torch.zeros(M, K, device=DEV, dtype=torch.uint8)
+        hip.cast_f16(a32, M * K, torch.zeros_like(a), alo)
+        kw.update(a16_lo=alo, w_lo=engine.pk_lo8(w))
+    gamma, beta = rnd(N, seed=44) * 0.5 + 1, rnd(N, seed=45) * 0.3
+    res0 = rnd(M, N, seed=46)
+
+    def run():
+        o = {}
+        k2 = dict(kw)
+        if variant in ("res_ln", "res_ln_lo8", "res", "res_lo8"):
+            o["x"] = res0.clone()                                  # the residual stream, updated in place
+            k2.update(res1=o["x"], ldr1=N, out32=o["x"], ldc32=N)
+        if variant in ("ln_lo8", "pos_ln", "o32"):
+            o["x"] = torch.zeros(M, N, device=DEV)
+            k2.update(out32=o["x"], ldc32=N)
+        if variant == "pos_ln":
+            k2.update(rowbias=rnd(8, N, seed=47), rb_rows=M // 16, rb_mod=8)
+        if "ln" in variant:
+            o["ln"] = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+            k2.update(ln_gamma=gamma, ln_beta=beta, ln_out16=o["ln"], ldln=N)
+        if variant == "ff2_o16_lo8":
+            o["h"], o["lo"] = torch.zeros(M, N, device=DEV, dtype=torch.float16), torch.zeros(M, N, device=DEV, dtype=torch.uint8)
+            k2.update(res1=res0, ldr1=N, out16=o["h"], ldc16=N, out16_lo=o["lo"])
+        if variant == "q_o16":
+            o["h"] = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+            k2.update(out16=o["h"], ldc16=N)
+        if variant == "qkv_vt":
+            t_rows = M // 4
+            o["qk"], o["vt"] = torch.zeros(M, 2 * C, device=DEV, dtype=torch.float16), torch.zeros(4, C, t_rows, device=DEV, dtype=torch.float16)
+            k2.update(out16=o["qk"], ldc16=2 * C, out16t=o["vt"], ldt=t_rows, t_rows=t_rows, t_gstride=C * t_rows, n_split=2 * C)
+            k2["bias"] = None
+        hip.gemm(a, w, **k2)
+        return o
+    prev = hip.set_option(hip.OPT_GEMM_PERSIST, 1)
+    try:
+        ref = run()
+        hip.set_option(hip.OPT_GEMM_PERSIST, 3)
+        got = run()
+        got2 = run()                                               # twice: no state left behind
+        torch.cuda.synchronize()
+    finally:
+        hip.set_option(hip.OPT_GEMM_PERSIST, prev)
+    for k in ref:
+        assert torch.equal(got[k], ref[k]) and torch.equal(got2[k], ref[k]), (variant, k, (got[k].float() - ref[k].float()).abs().max().item())
+        assert ref[k].float().abs().max().item() > 0.1
+
+
 @pytest.mark.parametrize("G,t_rows,C", [(2, 128, 64), (3, 96, 128), (2, 80, 64), (2, 192, 320)])
 def test_gemm_split_transposed_output(G, t_rows, C):
     # q|k row-major for n < 2C, V^T channel-major for n >= 2C  (QKV projection epilogue)

@@ -369,8 +369,6 @@ def main():
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: pnc_set_option before the run, e.g. ATTN_VARIANT=42, ATTN_DEFER_MAX=0, GEMM_PERSIST=0 (hip.OPT_<NAME>); "
                          "recorded in the output line under config.options")
-    ap.add_argument("--ff-chain", action="store_true",
-                    help="A/B: level-0 feed-forwards through the fused pnc_ff_chain_f16 launch (off by default: measured no faster)")
     ap.add_argument("--hoist", action="store_true",
                     help="sampler mode (SURVEY §8 f1): text K/V + ControlNet hint stem computed once per schedule, outside "
                          "the timed steps.  NOT the headline: the default re-evaluates the whole path every step")
@@ -424,8 +422,6 @@ def main():
         hip.set_option(hip.OPT_STENCIL_TILES, args.stencil_tiles)
     if args.gemm_group_m:
         hip.set_option(hip.OPT_GEMM_GROUP_M, args.gemm_group_m)
-    if args.ff_chain:
-        engine.FUSE_FF_CHAIN = True
     for kv in args.set_option:
         name, _, val = kv.partition("=")
         hip.set_option(getattr(hip, "OPT_" + name.upper()), int(val))

@@ -33,8 +33,9 @@ extern "C" {
 
 /* library / build identification: returns "panacea_hip <version> gfx950" */
 const char* pnc_version(void);
-/* ABI revision of this header (bumped whenever a parameter struct or a prototype changes): 3 */
-#define PNC_ABI_VERSION 3
+/* ABI revision of this header (bumped whenever a parameter struct or a prototype changes): 4
+ * (round 4: + pnc_groupnorm_combine, + PNC_OPT_ATTN_DEFER_MAX, PNC_OPT_GEMM_PERSIST is a bit set, - pnc_ff_chain_*) */
+#define PNC_ABI_VERSION 4
 int pnc_abi_version(void);
 /* hex SHA-256 of the sources + compile flags the library was built from (panacea_amd/build.py computes the same digest over
  * the checkout): a loader compares the two and refuses a library built from other sources instead of calling it with
@@ -189,42 +190,6 @@ int pnc_gemm_f16(const PncGemmParams* p, void* stream);
 int pnc_gemm_fuses_layernorm(const PncGemmParams* p);
 /* floats of workspace with which pnc_gemm_f16 would split K for this problem (0: it would not) */
 int64_t pnc_gemm_workspace_floats(const PncGemmParams* p);
-
-/* ------------------------------------------------------------------------- *
- * 1b. Feed-forward of a BasicTransformerBlock in one launch (round 3):
- *        out = x + W2 . geglu(W1 . LayerNorm(x) + b1) + b2
- *     -> x = self.ff(self.norm3(x)) + x   (sgm/modules/attention.py:91-117 FeedForward / GEGLU, :726-747 the block)
- *     A row stays on chip from its fp32 input to its output (registers: the contractions are computed transposed, a lane owns a
- *     token); only the weights move, as a TAPE the caller packs once (panacea_amd/engine.py: pk_ff_chain) in the order and
- *     register image the MFMAs consume:
- *        fragment (1 KB) = 64 lanes x 8 fp16; lane l = 32 g + n of the fragment (rows R .. R+31 of a weight matrix W[.][K],
- *        k-step s) holds W[R + n][16 s + PERM16[8 g + j]], j = 0..7, PERM16 = {0,1,2,3, 8,9,10,11, 4,5,6,7, 12,13,14,15};
- *        stage (20 fragments) A_c / B_c = k-steps 0..9 / 10..19 of rows 32c.. of W1, value and gate rows interleaved per k-step
- *        (value fragment of k-step s, then the gate fragment = W1 rows inner + 32c .. of the same k-step);
- *        T_c = W2[rows 32 b ..][columns 32 c + 16 h ..] in the order (h, b), h = 0..1, b = 0..C/32-1;
- *        tape = A_0 B_0 | A_1 B_1 T_0 | A_2 B_2 T_1 | ... | A_last B_last T_last-1 | T_last.
- *     b1 is W1's bias in its ORIGINAL order ([0, inner) values, [inner, 2 inner) gates).  Supported: C = 320, M % 128 == 0,
- *     inner % 128 == 0, inner <= 1536 (pnc_ff_chain_supported); other shapes run the GEMM pair of section 1.
- * ------------------------------------------------------------------------- */
-typedef struct PncFfChainParams {
-    const float* x32; int32_t ldx;      /* [M][ldx] fp32 stream */
-    int32_t M, C, inner;                /* rows, channels, hidden width (4 C) */
-    float ln_eps;
-    const float* ln_gamma;              /* [C] LayerNorm weight / bias */
-    const float* ln_beta;
-    const void* tape;                   /* pnc_ff_chain_tape_bytes(C, inner) bytes, layout above */
-    const float* b1;                    /* [2 inner] */
-    const float* b2;                    /* [C] */
-    float* out32; int32_t ldo32;        /* fp32 result or NULL (may alias x32: every workgroup reads its rows before it writes them) */
-    int32_t ldo16;
-    void* out16;                        /* fp16 result or NULL */
-    void* out16_lo;                     /* lo plane of the fp16 result (PNC_LO_* in out_lo_fmt) or NULL */
-    int32_t out_lo_fmt;
-    int32_t struct_bytes;               /* sizeof(PncFfChainParams) as the caller compiled it */
-} PncFfChainParams;
-int pnc_ff_chain_f16(const PncFfChainParams* p, void* stream);
-int pnc_ff_chain_supported(int M, int C, int inner);
-int64_t pnc_ff_chain_tape_bytes(int C, int inner);
 
 /* ------------------------------------------------------------------------- *
  * 2. View-sliced flash attention, head dim 64, fp16 in/out, fp32 softmax/acc.

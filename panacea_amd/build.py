@@ -19,7 +19,7 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libpanacea_hip.so"
-SOURCES = ["gemm.hip", "gemm_plain.hip", "gemm_conv3x3.hip", "gemm_stencil_tile.hip", "gemm_conv1d.hip", "ff_chain.hip", "attn.hip", "norm.hip", "misc.hip"]
+SOURCES = ["gemm.hip", "gemm_plain.hip", "gemm_conv3x3.hip", "gemm_stencil_tile.hip", "gemm_conv1d.hip", "attn.hip", "norm.hip", "misc.hip"]
 HEADERS = [CSRC / "common.h", CSRC / "gemm_kernel.h", ROOT / "include" / "panacea_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", str(ROOT / "include"), "-I", str(CSRC)]

@@ -200,7 +200,7 @@ extern "C" int pnc_cfg_euler_step(const float* eps_tok, int ld, int T, int Npix,
     return pnc_launch_status();
 }
 
-extern "C" const char* pnc_version(void) { return "panacea_hip 0.3.0 gfx950"; }
+extern "C" const char* pnc_version(void) { return "panacea_hip 0.4.0 gfx950"; }
 // the digest of the sources this object was compiled from (panacea_amd/build.py passes it to this translation unit)
 #ifndef PNC_BUILD_DIGEST
 #define PNC_BUILD_DIGEST "unstamped"

@@ -42,14 +42,6 @@ def use_backend(be):
         _BACKEND = old
 
 
-# x = ff(norm3(x)) + x of a BasicTransformerBlock as ONE launch (pnc_ff_chain_f16) where the library serves the shape (level 0:
-# C = 320).  OFF by default: correct (tests/test_ff_chain_gpu.py, whole-network parity 7.8e-4) but not faster than the launch
-# sequence it replaces — 860-920 us vs 866-891 us at M = 196 608 in both versions measured (profiles/round3/ffchain_*): with the
-# tokens in registers a workgroup is 4 waves = ONE instruction stream per SIMD, and the tape's DMA issues (1 KB per 4 MFMAs and wave,
-# ~80 % of a CU's LDS-DMA rate), the fragment reads and the GEGLU arithmetic serialise with the MFMAs in it.
-# bench.py --ff-chain switches it on for A/B runs.
-FUSE_FF_CHAIN = False
-
 TEXT_PAD = 80          # 77 text tokens padded to a multiple of 8 rows (zero rows, masked in the kernel)
 
 
@@ -560,27 +552,6 @@ def mfma_a_fragments(w16: torch.Tensor) -> torch.Tensor:
     R, S = w16.shape[0] // 32, w16.shape[1] // 16
     wp = w16.reshape(R, 32, S, 16)[..., list(PERM16)]
     return wp.reshape(R, 32, S, 2, 8).permute(0, 2, 3, 1, 4).reshape(R, S, 64, 8).contiguous()
-
-
-def pk_ff_chain(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
-    """The weight tape of pnc_ff_chain_f16 (include/panacea_hip.h section 1b): w1 = GEGLU projection [2 inner, C] (value rows, then
-    gate rows: attention.py:97), w2 = output projection [C, inner].  -> fp16 [3 * inner / 32, 20, 64, 8] (stages x fragments)."""
-    inner, C = w1.shape[0] // 2, w1.shape[1]
-    if C % 32 or inner % 64 or (C // 16) % 2 or 2 * (C // 32) != 20:
-        raise ValueError("pk_ff_chain: built for C = 320 (20 k-steps, 10 row blocks)")
-    fv = mfma_a_fragments(pk_f16(w1[:inner]))                  # [nch, 20, 64, 8]
-    fg = mfma_a_fragments(pk_f16(w1[inner:]))
-    f2 = mfma_a_fragments(pk_f16(w2))                          # [C / 32, inner / 16, 64, 8]
-    nch, half = inner // 32, C // 32
-    w1s = torch.stack([fv, fg], dim=2).reshape(nch, 2, half * 2, 64, 8)          # [c, k-half, (s, v|g), 64, 8]: stages A_c, B_c
-    t = f2.reshape(C // 32, nch, 2, 64, 8).permute(1, 2, 0, 3, 4).reshape(nch, 2 * (C // 32), 64, 8)   # T_c: (h, b)
-    stages = []
-    for c in range(nch):
-        stages += [w1s[c, 0], w1s[c, 1]]
-        if c > 0:
-            stages.append(t[c - 1])
-    stages.append(t[nch - 1])
-    return torch.stack(stages, dim=0).contiguous()
 
 
 class Packable:

@@ -20,7 +20,7 @@ HEADER = PKG.parent / "include" / "panacea_hip.h"
 
 A_PLAIN, A_CONV3X3, A_CONV1D_T = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 3          # PNC_ABI_VERSION of include/panacea_hip.h this binding was written against
+ABI_VERSION = 4          # PNC_ABI_VERSION of include/panacea_hip.h this binding was written against
 LO_F16, LO_E4M3 = 0, 1   # PNC_LO_*: storage format of the lo plane of a precise operand
 # dtype of a lo-plane tensor <-> format: an fp16 tensor holds fp16(r), a uint8 tensor OCP e4m3 bytes (one per element)
 LO_DTYPE = {LO_F16: torch.float16, LO_E4M3: torch.uint8}
@@ -70,19 +70,6 @@ class GemmParams(C.Structure):
     ]
 
 
-class FfChainParams(C.Structure):
-    _fields_ = [
-        ("x32", C.c_void_p), ("ldx", C.c_int32),
-        ("M", C.c_int32), ("C", C.c_int32), ("inner", C.c_int32),
-        ("ln_eps", C.c_float),
-        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
-        ("tape", C.c_void_p), ("b1", C.c_void_p), ("b2", C.c_void_p),
-        ("out32", C.c_void_p), ("ldo32", C.c_int32), ("ldo16", C.c_int32),
-        ("out16", C.c_void_p), ("out16_lo", C.c_void_p),
-        ("out_lo_fmt", C.c_int32), ("struct_bytes", C.c_int32),
-    ]
-
-
 class AttnParams(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("ldq", C.c_int32),
@@ -107,9 +94,6 @@ _SIGNATURES = {
     "pnc_gemm_f16": (_I, [C.POINTER(GemmParams), _P]),
     "pnc_gemm_workspace_floats": (_L, [C.POINTER(GemmParams)]),
     "pnc_gemm_fuses_layernorm": (_I, [C.POINTER(GemmParams)]),
-    "pnc_ff_chain_f16": (_I, [C.POINTER(FfChainParams), _P]),
-    "pnc_ff_chain_supported": (_I, [_I, _I, _I]),
-    "pnc_ff_chain_tape_bytes": (_L, [_I, _I]),
     "pnc_attn_views_f16": (_I, [C.POINTER(AttnParams), _P]),
     "pnc_softmax_rows_f16": (_I, [_P, _L, _I, _I, _F, _I, _I, _P, _L, _P]),
     "pnc_attn_temporal_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
@@ -327,29 +311,6 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
     _check(_timed(fam, 2.0 * M * N * K, 0.0, lib.pnc_gemm_f16, C.byref(p), _stream()), "pnc_gemm_f16")
     if trailing_ln:
         layernorm(out32, ldc32, M, N, ln_gamma, ln_beta, ln_eps, ln_out16, ldln)
-
-
-def ff_chain_supported(M: int, Cch: int, inner: int) -> bool:
-    """pnc_ff_chain_supported: the fused feed-forward serves this shape (C = 320, M % 128 == 0, ...)"""
-    return bool(load().pnc_ff_chain_supported(M, Cch, inner))
-
-
-def ff_chain(x32, ldx, M, Cch, inner, ln_gamma, ln_beta, ln_eps, tape, b1, b2, out32=None, ldo32=0, out16=None, ldo16=0,
-             out16_lo=None):
-    """out = x + W2 geglu(W1 LN(x) + b1) + b2 in one launch (pnc_ff_chain_f16); `tape` = engine.pk_ff_chain(w1, w2)"""
-    p = FfChainParams()
-    p.struct_bytes = C.sizeof(FfChainParams)
-    f16, f32 = torch.float16, torch.float32
-    p.x32, p.ldx, p.M, p.C, p.inner, p.ln_eps = _ptr(x32, f32, "x32"), ldx, M, Cch, inner, ln_eps
-    p.ln_gamma, p.ln_beta = _ptr(ln_gamma, f32, "ln_gamma"), _ptr(ln_beta, f32, "ln_beta")
-    if tape.numel() * tape.element_size() != load().pnc_ff_chain_tape_bytes(Cch, inner):
-        raise PncError("ff_chain: the weight tape does not have the size of this (C, inner)")
-    p.tape, p.b1, p.b2 = _ptr(tape, f16, "tape"), _ptr(b1, f32, "b1"), _ptr(b2, f32, "b2")
-    p.out32, p.ldo32, p.out16, p.ldo16 = _ptr(out32, f32, "out32"), ldo32, _ptr(out16, f16, "out16"), ldo16
-    p.out_lo_fmt = lo_fmt(out16_lo)
-    p.out16_lo = _ptr(out16_lo, LO_DTYPE[p.out_lo_fmt], "out16_lo")
-    nb = M * Cch * (4.0 + (4.0 if out32 is not None else 0.0) + (2.0 + _lo_bytes(out16_lo) if out16 is not None else 0.0))
-    _check(_timed("ff_chain", 2.0 * M * Cch * inner * 3, nb, load().pnc_ff_chain_f16, C.byref(p), _stream()), "pnc_ff_chain_f16")
 
 
 def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H, W, views,

@@ -81,20 +81,6 @@ class FeedForward(nn.Module, Packable):
         w1, b1 = E.pk_geglu(self.net[0].proj.weight, self.net[0].proj.bias)
         return dict(w1=w1, b1=b1, w2=E.pk_linear(self.net[2].weight), b2=E.pk_f32(self.net[2].bias))
 
-    def chain_ok(self, rt: Runtime, M: int) -> bool:
-        """the fused feed-forward launch (pnc_ff_chain_f16) serves this block at M rows"""
-        return E.FUSE_FF_CHAIN and self.dim_out == self.dim and rt.be.ff_chain_supported(M, self.dim, self.inner_dim)
-
-    def _run_chain(self, rt: Runtime, x32, M, ln, out32=None, out16=None, out16_lo=None):
-        """out = x32 + FF(LayerNorm(x32)) in one launch; `ln` = (gamma, beta) of the norm in front (norm3 of the block)"""
-        pk = self.packed()
-        if "tape" not in pk:            # the weight tape of the fused launch, packed on first use (level-0 blocks only)
-            with torch.no_grad():
-                pk["tape"] = E.pk_ff_chain(self.net[0].proj.weight, self.net[2].weight)
-                pk["b1raw"] = E.pk_f32(self.net[0].proj.bias)
-        rt.be.ff_chain(x32, self.dim, M, self.dim, self.inner_dim, ln[0], ln[1], 1e-5, pk["tape"], pk["b1raw"], pk["b2"],
-                       out32=out32, ldo32=self.dim, out16=out16, ldo16=self.dim, out16_lo=out16_lo)
-
     def _run(self, rt: Runtime, x16, M, res32, out32=None, out16=None, out16_lo=None):
         """out = FF(x16) + res32 -> out32 (may alias res32) and/or out16 (+ lo plane of a precise operand)."""
         pk = self.packed()
@@ -314,18 +300,12 @@ class BasicTransformerBlock(nn.Module, Packable):
                 raise NotImplementedError("plain spatial self-attention spans the whole panorama; a view shard serves the "
                                           "intra-view / inter-view kinds")
             x16 = self.attn1._run_views(rt, x16, F, H, W, [[0]], t32, t32, ln=ln2)
-        # x = ff(norm3(x)) + x: one launch where the library fuses it (level 0) — norm3 is then computed inside, from the fp32
-        # stream, and the text-attention output projection in front no longer writes it
-        chain = self.ff.chain_ok(rt, M)
-        x16 = self.attn2._run_text(rt, x16, F, H, W, t32, t32, ln=None if chain else ln3)
+        x16 = self.attn2._run_text(rt, x16, F, H, W, t32, t32, ln=ln3)
         out16 = out16lo = None
         if last:
             out16 = rt.empty((M, C), torch.float16)
             out16lo = rt.lo_plane((M, C), "ff_out")
-        if chain:
-            self.ff._run_chain(rt, t32, M, ln3, out32=None if last else t32, out16=out16, out16_lo=out16lo)
-        else:
-            self.ff._run(rt, x16, M, t32, out32=None if last else t32, out16=out16, out16_lo=out16lo)
+        self.ff._run(rt, x16, M, t32, out32=None if last else t32, out16=out16, out16_lo=out16lo)
         return (out16, out16lo) if last else None
 
 

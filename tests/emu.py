@@ -207,46 +207,6 @@ def _unfrag(fr: torch.Tensor) -> torch.Tensor:
     return wp[..., inv].reshape(R * 32, S * 16)
 
 
-def unpack_ff_chain(tape: torch.Tensor, Cch: int, inner: int):
-    """the weight tape of pnc_ff_chain_f16 (include/panacea_hip.h section 1b) back to (w1 [2 inner, C], w2 [C, inner])"""
-    nch, nb = inner // 32, Cch // 32
-    st = tape.reshape(3 * nch, 20, 64, 8)
-    a_idx, t_idx, i = [], [], 0
-    for c in range(nch):
-        a_idx.append((i, i + 1)); i += 2
-        if c > 0:
-            t_idx.append(i); i += 1
-    t_idx.append(i)
-    w1s = torch.stack([torch.stack([st[a], st[b]], 0) for a, b in a_idx], 0)            # [c, k-half, 20, 64, 8]
-    w1s = w1s.reshape(nch, 2, 10, 2, 64, 8).permute(0, 3, 1, 2, 4, 5).reshape(nch, 2, 20, 64, 8)   # [c, v|g, s, 64, 8]
-    wv, wg = _unfrag(w1s[:, 0].contiguous()), _unfrag(w1s[:, 1].contiguous())
-    t = torch.stack([st[j] for j in t_idx], 0).reshape(nch, 2, nb, 64, 8).permute(2, 0, 1, 3, 4).reshape(nb, 2 * nch, 64, 8)
-    return torch.cat([wv, wg], 0), _unfrag(t.contiguous())
-
-
-def ff_chain_supported(M, Cch, inner):
-    return Cch == 320 and M > 0 and M % 128 == 0 and inner % 128 == 0 and 0 < inner <= 1536
-
-
-def ff_chain(x32, ldx, M, Cch, inner, ln_gamma, ln_beta, ln_eps, tape, b1, b2, out32=None, ldo32=0, out16=None, ldo16=0,
-             out16_lo=None):
-    if not ff_chain_supported(M, Cch, inner):
-        raise PncError("pnc_ff_chain_f16 failed: PNC_EINVAL (unsupported shape/argument)")
-    w1, w2 = unpack_ff_chain(tape, Cch, inner)
-    X = _mat(x32, M, Cch, ldx).float()
-    a = r16(TF.layer_norm(X, (Cch,), ln_gamma.reshape(-1)[:Cch], ln_beta.reshape(-1)[:Cch], ln_eps), 'ff_chain.ln')
-    v = a.float() @ w1.float().t() + b1.reshape(-1)[: 2 * inner].float()
-    hid = r16(v[:, :inner] * TF.gelu(v[:, inner:]), 'ff_chain.geglu')
-    y = X + hid.float() @ w2.float().t() + b2.reshape(-1)[:Cch].float()
-    if out32 is not None:
-        _mat(out32, M, Cch, ldo32).copy_(y)
-    if out16 is not None:
-        h = r16(y, 'ff_chain.out16')
-        _mat(out16, M, Cch, ldo16).copy_(h)
-        if out16_lo is not None:
-            _mat(out16_lo, M, Cch, ldo16).copy_(_lo(y, h, out16_lo))
-
-
 def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H, W, views, kvH, kvW,
                kv_views, kv_rows_per_group, q_per_kv, kv_valid, segs, scale):
     Cc = heads * 64

@@ -143,32 +143,3 @@ def test_mx8_lo_plane_format_reference():
     assert z.eq(0).all() and zs.item() == 0
 
 
-def test_ff_chain_tape_round_trip_and_emulation_equals_the_launch_pair():
-    """engine.pk_ff_chain -> emu.unpack_ff_chain restores the weights; emu.ff_chain (the fused launch) equals LayerNorm + GEGLU GEMM
-    + output GEMM of the emulation on the same data"""
-    import torch
-    from panacea_amd import engine as E
-    import emu
-    g = torch.Generator().manual_seed(3)
-    C, inner, M = 320, 256, 256
-    w1 = (torch.randn(2 * inner, C, generator=g) * C ** -0.5).half().float()
-    w2 = (torch.randn(C, inner, generator=g) * inner ** -0.5).half().float()
-    tape = E.pk_ff_chain(w1, w2)
-    assert tape.shape == (3 * inner // 32, 20, 64, 8) and tape.dtype == torch.float16
-    u1, u2 = emu.unpack_ff_chain(tape, C, inner)
-    assert torch.equal(u1.float(), w1) and torch.equal(u2.float(), w2)
-    # fragment semantics of the header: lane l = 32 g + n, element j of the fragment (row block, k-step s) = W[n][16 s + PERM16[8 g + j]]
-    l, j, s_ = 45, 6, 7
-    assert float(tape[0, 2 * s_, l, j]) == float(w1[l % 32, 16 * s_ + E.PERM16[8 * (l // 32) + j]])          # stage A_0: value, k-step 7
-    assert float(tape[1, 2 * 3 + 1, l, j]) == float(w1[inner + l % 32, 16 * 13 + E.PERM16[8 * (l // 32) + j]])   # B_0: gate, k-step 13
-    x = torch.randn(M, C, generator=g) * 1.3
-    b1, b2 = torch.randn(2 * inner, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
-    gam, bet = torch.randn(C, generator=g) * 0.1 + 1, torch.randn(C, generator=g) * 0.1
-    fused = torch.zeros(M, C)
-    emu.ff_chain(x, C, M, C, inner, gam, bet, 1e-5, tape, b1, b2, out32=fused, ldo32=C)
-    a16, hid, ref = torch.zeros(M, C).half(), torch.zeros(M, inner).half(), x.clone()
-    w1i, b1i = E.pk_geglu(w1, b1)
-    emu.layernorm(x, C, M, C, gam, bet, 1e-5, a16, C)
-    emu.gemm(a16, w1i, M=M, N=2 * inner, K=C, lda=C, bias=b1i, geglu=True, out16=hid, ldc16=inner)
-    emu.gemm(hid, w2.half(), M=M, N=C, K=inner, lda=inner, bias=b2, res1=ref, ldr1=C, out32=ref, ldc32=C)
-    assert (fused - ref).abs().max().item() < 2e-6

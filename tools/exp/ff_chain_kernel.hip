@@ -1,3 +1,7 @@
+// EXPERIMENT RECORD, not part of libpanacea_hip.so since round 4 (64 spilled VGPRs and 5 s of every build for a launch
+// the product never took).  Round 3 built this fused feed-forward, pinned it green and measured it no faster than the launch
+// sequence; the source stays here with its probe (ffchain_probe.hip: hipcc -I ../../include -I ../../panacea_amd/csrc).
+// The packing helper engine.pk_ff_chain and the C-ABI entry pnc_ff_chain_f16 are in the history (commit 07bbb9c).
 // ff_chain.hip — the feed-forward of a BasicTransformerBlock in ONE launch (gfx950):
 //
 //     out = x + W2 · geglu(W1 · LN(x) + b1) + b2            (attention.py:91-117, 726-747:  x = ff(norm3(x)) + x)

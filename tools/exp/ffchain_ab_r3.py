@@ -1,4 +1,5 @@
-"""fused feed-forward launch (pnc_ff_chain_f16) vs LayerNorm + GEGLU GEMM + output GEMM at the level-0 shape of BASELINE config 3"""
+"""(round-3 record: needs the library of commit 07bbb9c, which still exported pnc_ff_chain_f16)
+fused feed-forward launch (pnc_ff_chain_f16) vs LayerNorm + GEGLU GEMM + output GEMM at the level-0 shape of BASELINE config 3"""
 import sys
 from pathlib import Path
 import torch

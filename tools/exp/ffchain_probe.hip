@@ -3,7 +3,7 @@
 //           panacea_amd/lib/misc.o ... -o tools/exp/ffchain_probe && tools/exp/ffchain_probe
 // Times ff_chain_kernel<ABL> for the ablation masks of the kernel (1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no GEGLU,
 // 16 no barriers, 32 no prologue loads / epilogue stores) at the level-0 shape of BASELINE config 3 (M = 196 608, C = 320).
-#include "../../panacea_amd/csrc/ff_chain.hip"
+#include "ff_chain_kernel.hip"
 #include <cstdio>
 #include <vector>
 

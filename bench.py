@@ -602,6 +602,7 @@ def main():
             out["roofline"]["basis"] = "sum of 2MNK over the contractions launched in one step (HIP-event pass) / measured step time"
     if parity:
         out["parity"] = parity
+        out["parity"]["contract"] = net.diffusion_model.eps_contract      # the bound stated for this network + policy
     if args.emulate_kernels:
         out["emulated_kernels"] = True
         out["metric"] += " [HARNESS SELF-TEST on the CPU emulation of the C-ABI: not a measurement]"

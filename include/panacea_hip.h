@@ -108,7 +108,14 @@ enum { PNC_A_PLAIN = 0, PNC_A_CONV3X3 = 1, PNC_A_CONV1D_T = 2 };
  *   PNC_LO_E4M3 : OCP fp8 e4m3 of r clamped to +-448, ONE byte per element, same leading dimension IN ELEMENTS.  |r| <= |v|, so
  *                 no block scale is needed: e4m3 resolves r to 2^-4, i.e. the pair to ~2^-15 of v, and what falls below its
  *                 smallest subnormal (2^-9) is below 2^-20 absolute.  The consumer GEMM runs the lo K loop on the block-scaled
- *                 fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 rate on half the bytes) with the 2^-11 as the A scale */
+ *                 fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 rate on half the bytes) with the 2^-11 as the A scale.
+ *                 RANGE: r reaches 2^e for |v| in [2^e, 2^(e+1)), so from |v| >= 512 on the clamp at 448 can bite: there the pair
+ *                 degrades gracefully (no NaN / Inf) from ~2^-15 of v towards the plain fp16 operand's 2^-11 — for |v| in
+ *                 [512, 1024) only the residuals in the top eighth of the rounding interval clamp, from 2048 on most do.
+ *                 The denoiser's split operands are normalised activations and fp16 copies of the residual stream; the three
+ *                 parity pins (synthetic weights) do not probe the range, and the published checkpoint is not available offline
+ *                 to measure its stream.  A caller whose operands reach the hundreds keeps PNC_LO_F16 for them
+ *                 (engine.Precision(lo8=False), policy "precise-f16lo").  tests/test_lo8_gpu.py holds values of 700, 1200, 60000. */
 enum { PNC_LO_F16 = 0, PNC_LO_E4M3 = 1 };
 enum { PNC_ACT_NONE = 0, PNC_ACT_SILU = 1, PNC_ACT_GELU = 2 /* erf GELU: open_clip text-tower MLP */ };
 

@@ -414,7 +414,9 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
                 if (!(col_on && m < p.M)) continue;
                 const float2 a = ln_mine[r], b = ln_partner[r];
                 const float mean = (a.x + b.x) * invn;
-                const float var = fmaxf((a.y + b.y) * invn - mean * mean, 0.0f);
+                // E[x^2] - mean^2 with the subtraction's product fused, written out: left to the compiler's contraction the two
+                // kernels that hold this epilogue fused different products (1 fp16 ulp apart in 3e-5 of the outputs)
+                const float var = fmaxf(fmaf(-mean, mean, (a.y + b.y) * invn), 0.0f);
                 const float rs = rsqrtf(var + p.ln_eps);
                 float y[8];
 #pragma unroll
@@ -1445,7 +1447,7 @@ __device__ __forceinline__ void epi_fast_alds(const PncGemmParams& p, f32x16 (&a
                 asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(sa[q]), "+v"(sb[q]) : "n"(2 * (NB - 1 - q)) : "memory");
                 const int m = mw + i * 32 + ps * RPP + rl;
                 const float mean = (sa[q].x + sb[q].x) * invn;
-                const float var = fmaxf((sa[q].y + sb[q].y) * invn - mean * mean, 0.0f);
+                const float var = fmaxf(fmaf(-mean, mean, (sa[q].y + sb[q].y) * invn), 0.0f);     // = epi_fast's, written out
                 const float rs = rsqrtf(var + p.ln_eps);
                 float y[8];
 #pragma unroll

@@ -159,8 +159,14 @@ def test_operand_policy_follows_the_network_unless_set():
     assert any("precise-all" in str(x.message) and "1e-3" in str(x.message) for x in w)
     full1 = build_network(configs.with_frames(configs.get("full"), 1)).diffusion_model  # 320 channels: 10 values per group
     assert full1.precision == "precise"
+    # the stated bound per configuration: 1e-3 from 4 values per group on, 2.5e-3 below
+    assert net.eps_contract["eps_max_abs"] == 1e-3 and full1.eps_contract == {"policy": "precise", "eps_max_abs": 1e-3,
+                                                                                "values_per_temporal_group": 10}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert t1.eps_contract["eps_max_abs"] == 2.5e-3 and t1.eps_contract["values_per_temporal_group"] == 2
     t1.precision = "fast"                                                   # an explicit choice always wins
-    assert t1.precision == "fast" and t1.controlnet.precision == "fast"
+    assert t1.precision == "fast" and t1.controlnet.precision == "fast" and t1.eps_contract["eps_max_abs"] is None
     assert engine.precision("precise").lo8 and not engine.precision("precise-f16lo").lo8
     with pytest.raises(ValueError):
         t1.precision = "fastest"

@@ -209,7 +209,8 @@ int64_t pnc_gemm_workspace_floats(const PncGemmParams* p);
  *    Only the first kv_valid keys of each kv view exist (rest masked).
  *     -> xformers.ops.memory_efficient_attention (attention.py:469 intra-view,
  *        :590 inter-view incl. the view-5 quirk, :363) and
- *        F.scaled_dot_product_attention (attention.py:281) for text keys.
+ *        F.scaled_dot_product_attention (attention.py:281) for text keys; with `causal`, the attention of the OpenCLIP
+ *        text tower's residual blocks (all heads of all prompts in one launch).
  * ------------------------------------------------------------------------- */
 typedef struct PncAttnParams {
     const void* q;  int32_t ldq;    /* fp16, head h at column h*64 */
@@ -226,6 +227,8 @@ typedef struct PncAttnParams {
     int32_t nseg[8];                /* per q view */
     int32_t seg[8][2];              /* kv view ids */
     float scale;                    /* softmax scale (d^-0.5) */
+    int32_t causal;                 /* 1: query i of a view attends keys j <= i of each kv view only (view-local indices) —
+                                       the text tower's causal mask (open_clip build_attention_mask; modules.py:559-632); 0 else */
 } PncAttnParams;
 
 int pnc_attn_views_f16(const PncAttnParams* p, void* stream);

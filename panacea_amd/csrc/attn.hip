@@ -67,6 +67,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_vi
 
     // ---- this lane's queries (columns of S^T / O^T): one per query block ----
     bool qok[QB];
+    int qloc[QB];                     // view-local query index of this lane (the causal limit)
     int64_t qrow[QB];
     half8v qf[QB][4];
 #pragma unroll
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_vi
         const int ql = qtile * QT + (wave * QB + qb) * 32 + (lane & 31);   // view-local query index
         qok[qb] = ql < Nq;
         const int qlc = qok[qb] ? ql : (Nq - 1);
+        qloc[qb] = qlc;
         const int qy = qlc / Wv, qx = view * Wv + (qlc - qy * Wv);
         qrow[qb] = ((int64_t)g * p.H + qy) * p.W + qx;
 #pragma unroll
@@ -260,11 +262,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_vi
         half8v pf[QB][2][2];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            if (key0 + KT > p.kv_valid) {
+            if (key0 + KT > p.kv_valid || p.causal) {
                 // keys at or beyond kv_valid are padding: tile-local key index kh*32 + r (compile-time) against ONE per-lane limit.
                 // The limit is kept opaque inside the branch: hipcc otherwise speculates the whole index / compare chain (32 v_or +
                 // 61 v_cmp per tile) out of it into EVERY tile's instruction stream, where only the last tile of a segment masks.
+                // (causal: keys beyond the lane's own query index as well — PncAttnParams.causal, the text tower)
                 int lim = p.kv_valid - key0 - grp * 16;
+                if (p.causal) lim = min(lim, qloc[qb] + 1 - key0 - grp * 16);
                 asm volatile("" : "+v"(lim));
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh)
@@ -468,6 +472,7 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     if ((uintptr_t)p.o & 7) return PNC_EALIGN;
     if (p.q_per_kv < 1 || p.groups < 1 || p.heads < 1) return PNC_EINVAL;
     if (p.kv_valid < 1 || p.kv_valid > p.kvH * kvWv) return PNC_EINVAL;
+    if (p.causal != 0 && p.causal != 1) return PNC_EINVAL;
     for (int v = 0; v < p.views; ++v) {
         if (p.nseg[v] < 1 || p.nseg[v] > 2) return PNC_EINVAL;
         for (int s = 0; s < p.nseg[v]; ++s)

@@ -81,7 +81,7 @@ class AttnParams(C.Structure):
         ("kvH", C.c_int32), ("kvW", C.c_int32), ("kv_views", C.c_int32),
         ("kv_rows_per_group", C.c_int32), ("q_per_kv", C.c_int32), ("kv_valid", C.c_int32),
         ("nseg", C.c_int32 * 8), ("seg", (C.c_int32 * 2) * 8),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("causal", C.c_int32),
     ]
 
 
@@ -314,7 +314,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
 
 
 def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H, W, views,
-               kvH, kvW, kv_views, kv_rows_per_group, q_per_kv, kv_valid, segs, scale):
+               kvH, kvW, kv_views, kv_rows_per_group, q_per_kv, kv_valid, segs, scale, causal=False):
     p = AttnParams()
     p.q, p.ldq, p.k, p.ldk = _ptr(q), ldq, _ptr(k), ldk
     p.vt, p.ldvt, p.vt_gstride, p.o, p.ldo = _ptr(vt), ldvt, vt_gstride, _ptr(o), ldo
@@ -325,7 +325,7 @@ def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H
         p.nseg[v] = len(s)
         for j, u in enumerate(s):
             p.seg[v][j] = u
-    p.scale = scale
+    p.scale, p.causal = scale, int(causal)
     nq = H * (W // views)
     nkeys = sum(len(sv) for sv in segs) * kv_valid
     _check(_timed("attn_views", 4.0 * groups * heads * nq * nkeys * 64, 0.0, load().pnc_attn_views_f16,

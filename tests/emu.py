@@ -208,7 +208,7 @@ def _unfrag(fr: torch.Tensor) -> torch.Tensor:
 
 
 def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H, W, views, kvH, kvW,
-               kv_views, kv_rows_per_group, q_per_kv, kv_valid, segs, scale):
+               kv_views, kv_rows_per_group, q_per_kv, kv_valid, segs, scale, causal=False):
     Cc = heads * 64
     Wv, kvWv = W // views, kvW // kv_views
     Q = _mat(q, groups * H * W, Cc, ldq).float().view(groups, H, W, heads, 64)
@@ -230,6 +230,11 @@ def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H
         kc = torch.cat(ks, dim=2)[gidx]
         vc = torch.cat(vs, dim=2)[gidx]
         s = torch.einsum("ghqd,ghkd->ghqk", qv, kc) * scale
+        if causal:          # view-local key index <= view-local query index, in every key segment
+            nk = min(kv_valid, kvH * kvWv)
+            kidx = torch.arange(nk, device=s.device).repeat(len(segs[v]))
+            qidx = torch.arange(H * Wv, device=s.device)
+            s = s.masked_fill(kidx[None, :] > qidx[:, None], float("-inf"))
         pr = torch.softmax(s, dim=-1)
         ov = torch.einsum("ghqk,ghkd->ghqd", pr, vc)   # [g, heads, q, 64]
         ov = ov.permute(0, 2, 1, 3).reshape(groups, H, Wv, Cc)

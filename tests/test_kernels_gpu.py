@@ -812,6 +812,26 @@ def test_groupnorm_combine_kernel():
     check("groupnorm_combined", y.view(F, Npix, C).permute(0, 2, 1), ref, 4e-3)
 
 
+@pytest.mark.parametrize("G,L,Lp,heads", [(2, 77, 80, 16), (1, 200, 200, 2), (3, 33, 40, 1)])
+def test_attn_views_causal_text_tower(G, L, Lp, heads):
+    """PncAttnParams.causal (round 4): query i attends keys j <= i — the OpenCLIP text tower's mask, all heads of all prompts in one
+    launch (a prompt = a group of one view with Lp padded rows, L valid keys)"""
+    C = heads * 64
+    qk = rnd(G * Lp, 2 * C, dtype=torch.float16, seed=51)
+    v = rnd(G * Lp, C, dtype=torch.float16, seed=52)
+    vt = v.view(G, Lp, C).permute(0, 2, 1).contiguous()
+    kw = dict(groups=G, heads=heads, H=1, W=Lp, views=1, kvH=1, kvW=Lp, kv_views=1, kv_rows_per_group=Lp, q_per_kv=1,
+              kv_valid=L, segs=[[0]], scale=0.125, causal=True)
+    oh = torch.zeros(G * Lp, C, device=DEV, dtype=torch.float16)
+    oe = torch.zeros_like(oh)
+    hip.attn_views(qk, 2 * C, qk[:, C:], 2 * C, vt, Lp, C * Lp, oh, C, **kw)
+    emu.attn_views(qk, 2 * C, qk.reshape(-1)[C:], 2 * C, vt, Lp, C * Lp, oe, C, **kw)
+    torch.cuda.synchronize()
+    check("attn_views_causal", oh, oe, 3e-3)
+    # row 0 of every prompt attends key 0 only: its output is v[0]
+    assert torch.equal(oh.view(G, Lp, C)[:, 0], v.view(G, Lp, C)[:, 0])
+
+
 def test_attn_views_sharp_softmax():
     # large-magnitude scores: exercises the running-max rescale across KV tiles
     G, H, W, heads = 1, 8, 96, 1

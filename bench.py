@@ -287,8 +287,8 @@ def run_text_tower(args, dev):
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                       "config": {"workload": "FrozenOpenCLIPEmbedder penultimate layer, width 1024, 23 blocks, 16 heads, (2, 77) tokens",
                                  "stage": "text-tower", "GFLOP": round(flops / 1e9, 1),
-                                 "note": "154 rows: a launch-bound stage (one (sample, head) attention problem per launch), "
-                                         "run once per sample"}}), flush=True)
+                                 "note": "154 rows, run once per sample; one causal pnc_attn_views_f16 launch per block since round 4 "
+                                         "(round 3: one launch chain per (prompt, head), 25.5 ms)"}}), flush=True)
 
 
 def spawn_ranks(args) -> int:

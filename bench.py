@@ -576,7 +576,7 @@ def main():
                    "frames_per_step": 2 * T, "parallelism": layout.name, **({"options": args.set_option} if args.set_option else {}),
                    "ranks_per_sample": layout.per_sample, "per_sample_latency_ms": ms_per_step,
                    "graph": bool(args.graph), "streams": 1 if args.one_stream else 2,
-                   "hoisted_step_invariants": bool(args.hoist), "fused_step_tail": bool(smp.fuse and shard is None and vshard is None and layout.cfg == 1)},
+                   "hoisted_step_invariants": bool(args.hoist), "fused_step_tail": bool(smp.fuse)},
     }
     if args.config == "full":
         ach = ALGO_TFLOP_PER_STEP * (value / world) if T == 8 else None     # per GPU

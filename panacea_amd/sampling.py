@@ -152,9 +152,11 @@ class EulerEDMSampler:
             return False
         model = getattr(denoiser.network, "diffusion_model", None)
         den = denoiser.denoiser
-        return (hasattr(model, "denoise_tokens") and getattr(model, "frame_shard", None) is None
-                and getattr(model, "view_shard", None) is None
-                and type(self.guider) in (VanillaCFG, type(None)) and isinstance(den, DiscreteDenoiser)
+        # frame- / view-sharded networks fuse as well (round 4): the entry and exit kernels are elementwise over whatever frames /
+        # band the rank holds; a CFG pair (parallel.ShardedCFG: `half`, `group`) all-gathers its eps halves in front of the
+        # exit kernel instead of the denoised halves behind it
+        guider_ok = type(self.guider) in (VanillaCFG, type(None)) or (isinstance(self.guider, VanillaCFG) and hasattr(self.guider, "half"))
+        return (hasattr(model, "denoise_tokens") and guider_ok and isinstance(den, DiscreteDenoiser)
                 and isinstance(den.scaling, EpsScaling) and den.quantize_c_noise
                 and "concat" in cond and cond.get("vector") is None)
 
@@ -168,8 +170,12 @@ class EulerEDMSampler:
         sig_q = den.idx_to_sigma(idx)                                 # denoiser.py:24
         c_in = 1 / (sig_q ** 2 + 1.0) ** 0.5
         c_noise = den.sigma_to_idx(sig_q)                             # quantised c_noise = the table index
+        half = getattr(self.guider, "half", None)
         if self.guider is None:
             cat, inv, nh = cond, cond.get("_invariants"), 1
+        elif half is not None:
+            # one CFG half per rank: this rank evaluates its half; the pair's eps tokens are gathered for the exit kernel
+            cat, inv, nh = (uc if half == 0 else cond), cond.get("_invariants"), 1
         else:
             pre = cond.get("_cat")
             if pre is not None:
@@ -187,7 +193,16 @@ class EulerEDMSampler:
                                    cat["cond_feat"], invariants=inv)
         x32 = x.detach().to(torch.float32).contiguous()
         out = torch.empty_like(x32)
-        E.backend().cfg_euler_step(eps.f32, eps.C, T, eps.N, x.shape[1], nh == 2, float(self.guider.scale) if nh == 2 else 0.0,
+        eps32, cfg = eps.f32, nh == 2
+        if half is not None:
+            import torch.distributed as dist
+            mine = eps32.contiguous()
+            stage = dist.get_backend(self.guider.group) == "gloo" and mine.is_cuda       # two processes on one GPU (tests)
+            send = mine.cpu() if stage else mine
+            both = torch.empty((2 * send.shape[0], send.shape[1]), dtype=send.dtype, device=send.device)   # [uncond half; cond half]
+            dist.all_gather_into_tensor(both, send, group=self.guider.group)
+            eps32, cfg = both.to(mine.device), True
+        E.backend().cfg_euler_step(eps32, eps.C, T, eps.N, x.shape[1], cfg, float(self.guider.scale) if cfg else 0.0,
                                    x32, (-sig_q).contiguous(), sigma.contiguous(), next_sigma.contiguous(), out)
         return out.to(x.dtype)
 

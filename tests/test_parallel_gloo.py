@@ -138,6 +138,15 @@ def _frames_worker(rank, world, port, out_dir, cfg, G, T):
         xs = smp(denoiser, parallel.local_frames(x0, lo, T), parallel.shard_conditioning(cond, lo, T),
                  parallel.shard_conditioning(uc, lo, T))
         xs_all = parallel.gather_frames(xs, groups, T)
+        # fused sampler tail on the frame-sharded network (cfg = 1: both halves on the rank; cfg = 2: the pair gathers its eps)
+        x_l = parallel.local_frames(x0, lo, T)
+        c_l, u_l = parallel.shard_conditioning(cond, lo, T), parallel.shard_conditioning(uc, lo, T)
+        sig = smp.sigmas()
+        s_in = x_l.new_ones([x_l.shape[0]])
+        xin = x_l * torch.sqrt(1.0 + sig[0] ** 2.0)
+        plain = smp.sampler_step(s_in * sig[0], s_in * sig[1], denoiser, xin, c_l, u_l)
+        fused = smp._fused_step(s_in * sig[0], s_in * sig[1], S.BoundDenoiser(den, net), xin, c_l, u_l)
+        assert torch.equal(plain, fused), (plain - fused).abs().max().item()
         if rank == 0:
             parallel.apply_frame_shard(net, None)
             eps_ref = net(inp["x"], inp["t"], cond_of(inp))
@@ -410,6 +419,16 @@ def _grid_worker(rank, world, port, out_dir, cfg, G, V, T):
         xs = smp(denoiser, parallel.local_views(parallel.local_frames(x0, lo, T), lo), parallel.shard_conditioning(cond, lo, T),
                  parallel.shard_conditioning(uc, lo, T))
         xs_all = parallel.gather_frames(parallel.gather_views(xs, groups), groups, T)
+        # the fused sampler tail in a sharded layout (round 4): entry + exit kernels on this rank's (frames, band) block, the
+        # CFG pair's eps halves all-gathered in front of the exit kernel — same bits as the plain step of the same layout
+        x_l = parallel.local_views(parallel.local_frames(x0, lo, T), lo)
+        c_l, u_l = parallel.shard_conditioning(cond, lo, T), parallel.shard_conditioning(uc, lo, T)
+        sig = smp.sigmas()
+        s_in = x_l.new_ones([x_l.shape[0]])
+        xin = x_l * torch.sqrt(1.0 + sig[0] ** 2.0)
+        plain = smp.sampler_step(s_in * sig[0], s_in * sig[1], denoiser, xin, c_l, u_l)
+        fused = smp._fused_step(s_in * sig[0], s_in * sig[1], S.BoundDenoiser(den, net), xin, c_l, u_l)
+        assert torch.equal(plain, fused), (plain - fused).abs().max().item()
         if rank == 0:
             parallel.apply_frame_shard(net, None)
             parallel.apply_view_shard(net, None)

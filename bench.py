@@ -582,8 +582,8 @@ def main():
         ach = ALGO_TFLOP_PER_STEP * (value / world) if T == 8 else None     # per GPU
         # HBM-side bytes per step come from separate rocprofv3 --pmc passes of this same command (they cannot be collected
         # inside a timed run).  The record names the build it was measured on: a stale record reports null, not a number.
-        traffic, tnote = None, "no PMC record for this build (tools/pmc_traffic.py writes profiles/round3/pmc_traffic.json)"
-        pmc = ROOT / "profiles" / "round3" / "pmc_traffic.json"
+        traffic, tnote = None, "no PMC record for this build (tools/pmc_traffic.py writes profiles/round4/pmc_traffic.json)"
+        pmc = ROOT / "profiles" / "round4" / "pmc_traffic.json"
         if pmc.exists() and T == 8:
             rec = json.loads(pmc.read_text())
             cur = hip.build_digest()               # the digest compiled into the loaded library

@@ -246,13 +246,15 @@ def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, 
            "collective_backend": f"{args.backend} ({'RCCL over xGMI' if args.backend == 'nccl' else 'CPU self-test'}), {world} ranks",
            "cfg_all_gathers_per_step": 1 if layout.cfg > 1 else 0}
     if shard is not None:
-        rec["exchange"] = {"all_to_all_per_step": shard.exchanges // max(1, nsteps),
+        rec["exchange"] = {"frame_exchanges_per_step": shard.exchanges // max(1, nsteps),
                            "MB_sent_per_rank_and_step": round(shard.bytes_sent / max(1, nsteps) / 1e6, 1),
-                           "note": "engine.FrameShard: temporal sites run pixel-sharded (DESIGN.md section 9)"}
+                           "note": f"engine.FrameShard(resblock={shard.resblock!r}): ResBlock3D temporal sites = statistics all-reduce + one "
+                                   "halo frame per neighbour; STT temporal branch pixel-sharded (DESIGN.md section 9)"}
     if vshard is not None:
-        rec["exchange"] = {"neighbour_exchanges_per_step": vshard.exchanges // max(1, nsteps),
-                           "MB_sent_per_rank_and_step": round(vshard.bytes_sent / max(1, nsteps) / 1e6, 1),
-                           "note": "engine.ViewShard: conv halos, panorama GroupNorm statistics, neighbour views (DESIGN.md section 9)"}
+        rec["view_exchange" if shard is not None else "exchange"] = {
+            "neighbour_exchanges_per_step": vshard.exchanges // max(1, nsteps),
+            "MB_sent_per_rank_and_step": round(vshard.bytes_sent / max(1, nsteps) / 1e6, 1),
+            "note": "engine.ViewShard: conv halos, panorama GroupNorm statistics, neighbour views (DESIGN.md section 9)"}
     return rec
 
 
@@ -628,12 +630,13 @@ def main():
             dog.cancel()
     if shard is not None:
         nsteps = args.steps + args.warmup
-        out["config"]["exchange"] = {"all_to_all_per_step": shard.exchanges // max(1, nsteps),
+        out["config"]["exchange"] = {"frame_exchanges_per_step": shard.exchanges // max(1, nsteps),
                                      "MB_sent_per_rank_and_step": round(shard.bytes_sent / max(1, nsteps) / 1e6, 1),
-                                     "note": "engine.FrameShard: temporal sites run pixel-sharded (DESIGN.md §9)"}
+                                     "note": f"engine.FrameShard(resblock={shard.resblock!r}): ResBlock3D temporal sites = statistics "
+                                             "all-reduce + one halo frame per neighbour; STT temporal branch pixel-sharded (DESIGN.md §9)"}
     if vshard is not None:
         nsteps = args.steps + args.warmup
-        out["config"]["exchange"] = {"neighbour_exchanges_per_step": vshard.exchanges // max(1, nsteps),
+        out["config"]["view_exchange" if shard is not None else "exchange"] = {"neighbour_exchanges_per_step": vshard.exchanges // max(1, nsteps),
                                      "MB_sent_per_rank_and_step": round(vshard.bytes_sent / max(1, nsteps) / 1e6, 1),
                                      "note": "engine.ViewShard: conv halos, panorama GroupNorm statistics, neighbour views (DESIGN.md §9)"}
 

@@ -188,7 +188,10 @@ typedef struct PncGemmParams {
     int32_t ldw_lo;             /* bytes between rows of W_lo (0 = K) */
     const void* W_lo;
     int32_t w_lo_exp;
-    int32_t reserved1;
+    /* PNC_A_CONV1D_T: 1 = A (and A_lo) hold T + 2 frames per sample, row (b, t, pixel) at ((b (T + 2) + t + 1) Npix + pixel): the
+     * frame before the first and after the last of the T frames the rows speak of are present — a frame group's halo frames
+     * (engine.FrameShard: the neighbour rank's frame, zeros at the two ends of the clip) — and no tap is padded */
+    int32_t t_halo;
 } PncGemmParams;
 
 int pnc_gemm_f16(const PncGemmParams* p, void* stream);
@@ -265,6 +268,15 @@ int pnc_groupnorm_combine(const float* in, int parts, int F, int nchunk, float* 
 int pnc_groupnorm_temporal_silu(const float* x, int B, int T, int Npix, int C,
                                 const float* gamma, const float* beta, float eps,
                                 void* y16, void* y16_lo, int lo_fmt, void* stream);
+/* The same split over the ranks of a frame group (engine.FrameShard, round 4), for the T local frames of every pixel:
+ *   mode 1: stats[((b*Npix + p)*32 + g)*2 + {0,1}] = {sum, sum of squares} over the (C/32, T) values this rank holds;
+ *   mode 2: normalise + SiLU with `stats` = those sums added over the ranks and T_total = frames per sample over all ranks;
+ *           t_pad = 1 writes y into the (T + 2)-frame layout PncGemmParams.t_halo reads (frame t at slot t + 1).
+ *    -> the same nn.GroupNorm on "(b h w) c t" when the T frames of a pixel live on several ranks */
+int pnc_groupnorm_temporal_part(const float* x, int B, int T, int Npix, int C,
+                                const float* gamma, const float* beta, float eps,
+                                float* stats, int mode, int T_total,
+                                void* y16, void* y16_lo, int lo_fmt, int t_pad, void* stream);
 /* LayerNorm over C (eps 1e-5) -> nn.LayerNorm (attention.py:699-701) */
 int pnc_layernorm(const float* x, int ldx, int M, int C,
                   const float* gamma, const float* beta, float eps,

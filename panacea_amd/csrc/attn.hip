@@ -55,9 +55,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_vi
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA destinations (M0) and wave-row tests stay on the SALU
-    const int qtile = blockIdx.x, view = blockIdx.y;
-    const int g = blockIdx.z / p.heads, head = blockIdx.z % p.heads;
+    // Workgroups that read the same K / V^T — the query tiles of one (view, frame, head), and the neighbouring views of the cross-view
+    // launch — get CONSECUTIVE virtual ids inside one XCD (round 4).  Hardware hands linear workgroup ids to the 8 XCDs round-robin,
+    // so as a 3-D grid the 4-8 query tiles of a view landed on 4-8 different XCDs and every one of their L2s fetched that view's
+    // keys and values from the fabric for itself (profiles/round4: 26 -> 50 GB per step when the tiles went from 512 to 256 queries).
     const int Wv = p.W / p.views, Nq = p.H * Wv;
+    const int nqt = (Nq + QT - 1) / QT;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int qtile = vb % nqt, view = (vb / nqt) % p.views;
+    const int gh = vb / (nqt * p.views);
+    const int g = gh / p.heads, head = gh % p.heads;
     const int kvWv = p.kvW / p.kv_views;
     const int Nkv = p.kvH * kvWv;                    // keys per kv view
     const bool vec_v = ((kvWv & 7) == 0) && ((p.kvW & 7) == 0) && ((p.ldvt & 7) == 0) && ((p.vt_gstride & 7) == 0);
@@ -503,7 +510,7 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     const float defer_thr = (float)(dopt < 0 ? 0 : (dopt > 14 ? 14 : dopt));
 #define PNC_ATTN_LAUNCH(NW_, QB_, QTILE_)                                                                         \
     do {                                                                                                          \
-        dim3 grid((Nq + (QTILE_) - 1) / (QTILE_), p.views, p.groups * p.heads);                                   \
+        dim3 grid(((Nq + (QTILE_) - 1) / (QTILE_)) * p.views * p.groups * p.heads);                               \
         if (dma) hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, true>), grid, dim3(64 * NW_), 0, st, p, wv_shift, defer_thr, dma_mode);  \
         else hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, false>), grid, dim3(64 * NW_), 0, st, p, wv_shift, defer_thr, dma_mode);   \
     } while (0)

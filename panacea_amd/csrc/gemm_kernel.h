@@ -74,6 +74,9 @@ template <int AMODE>
 __device__ __forceinline__ int64_t a_window_origin(const PncGemmParams& p, int m0) {
     if (AMODE == PNC_A_PLAIN) return (int64_t)m0 * p.lda;
     if (AMODE == PNC_A_CONV3X3) return (int64_t)(m0 / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin;
+    // t_halo: A holds T + 2 frames per sample (a halo frame either side of the T the rows speak of): the row of (b, t, pixel) is
+    // m + (2 b + 1) Npix, and one frame before the tile's first row always exists
+    if (p.t_halo) return (int64_t)(m0 + 2 * ((m0 / p.Npix) / p.T) * p.Npix) * p.Cin;
     return (int64_t)max(0, m0 - p.Npix) * p.Cin;
 }
 
@@ -92,7 +95,8 @@ __device__ __forceinline__ RowState make_row(const PncGemmParams& p, int m, int 
     } else {
         const int f = mm / p.Npix;
         s.y = f % p.T; s.x = 0;
-        s.rel = (mm - max(0, m0 - p.Npix)) * p.Cin;
+        if (p.t_halo) s.rel = (mm - m0 + (2 * (f / p.T - (m0 / p.Npix) / p.T) + 1) * p.Npix) * p.Cin;
+        else s.rel = (mm - max(0, m0 - p.Npix)) * p.Cin;
     }
     return s;
 }
@@ -152,8 +156,8 @@ __device__ __forceinline__ unsigned a_chunk_off(const PncGemmParams& p, const Ro
         } else {
             tap = kc / p.Cin; ci = kc - tap * p.Cin;
         }
-        const int tt = s.y + tap - 1;
-        return (tt < 0 || tt >= p.T) ? PNC_BUF_OOB : (unsigned)(s.rel + (tap - 1) * p.Npix * p.Cin + ci) * ESZ;
+        const int tt = s.y + tap - 1;      // (t_halo: frames -1 and T exist in A — the neighbour rank's, or zeros at the clip's ends)
+        return (!p.t_halo && (tt < 0 || tt >= p.T)) ? PNC_BUF_OOB : (unsigned)(s.rel + (tap - 1) * p.Npix * p.Cin + ci) * ESZ;
     }
 }
 

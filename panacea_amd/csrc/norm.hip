@@ -180,11 +180,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 // loads), kept in registers across the statistics phase and written back as 8-byte fp16 vectors (the first version
 // re-read x for the second phase and moved 8 / 4 bytes per access: 3.7 TB/s).  Statistics are accumulated per channel
 // PAIR in LDS (C/32 channels per group is even but not always a multiple of 4: 10 at C = 320).
-template <int T>
+// MODE 0: statistics + normalisation over the T frames of a pixel (all of them are here).  MODE 1 / 2 (round 4): the frames of a
+// pixel are spread over the ranks of a frame group — 1 writes this rank's {sum, sum of squares} per (pixel, group), 2 normalises
+// the local frames with the sums added over the ranks (n = values per group over ALL T_total frames); t_pad: output frame t of
+// sample b goes to slot t + 1 of a (T + 2)-frame layout, the halo frames of the temporal conv around it.
+template <int T, int MODE = 0>
 __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restrict__ x, int B, int Npix, int C,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
-                                                          half_t* __restrict__ y, void* __restrict__ ylo, int lo_fmt, int PB) {
+                                                          half_t* __restrict__ y, void* __restrict__ ylo, int lo_fmt, int PB,
+                                                          float* __restrict__ stats = nullptr, int T_total = T, int t_pad = 0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [PB][C/2][2] sums, then [PB][32][2] stats
     const int CP = C >> 1, C4 = C >> 2, cpg2 = (C / GROUPS) >> 1;
     float* s_part = sm;                           // PB*CP*2
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restric
     const int64_t total = (int64_t)B * Npix;
     const int nwork = PB * C4;                      // <= 512 (host picks PB)
     f32x4 v[2][T];
-    int64_t off[2];
+    int64_t off[2], offo[2];
     bool live[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -203,10 +208,11 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restric
         const int64_t bp = bp0 + pl;
         live[it] = (wi < nwork) && (bp < total);
         float s0 = 0.0f, q0 = 0.0f, s1 = 0.0f, q1 = 0.0f;
-        off[it] = 0;
+        off[it] = 0; offo[it] = 0;
         if (live[it]) {
             const int64_t b = bp / Npix, pix = bp - b * Npix;
             off[it] = ((b * T) * Npix + pix) * C + c4 * 4;
+            offo[it] = ((b * (T + 2 * t_pad) + t_pad) * Npix + pix) * C + c4 * 4;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 v[it][t] = *reinterpret_cast<const f32x4*>(x + off[it] + (int64_t)t * Npix * C);
@@ -227,11 +233,21 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restric
             const int wi = pl * CP + g * cpg2 + j;
             s += s_part[wi * 2]; q += s_part[wi * 2 + 1];
         }
-        const float n = (float)(cpg2 * 2 * T);
+        if constexpr (MODE == 1) {                 // this rank's partial sums: the frame group adds them up
+            const int64_t bp = bp0 + pl;
+            if (bp < total) { stats[(bp * GROUPS + g) * 2] = s; stats[(bp * GROUPS + g) * 2 + 1] = q; }
+            continue;
+        }
+        if constexpr (MODE == 2) {                 // the sums over all ranks' frames
+            const int64_t bp = bp0 + pl;
+            if (bp < total) { s = stats[(bp * GROUPS + g) * 2]; q = stats[(bp * GROUPS + g) * 2 + 1]; }
+        }
+        const float n = (float)(cpg2 * 2 * (MODE == 2 ? T_total : T));
         const float mean = s / n;
         const float var = fmaxf(q / n - mean * mean, 0.0f);
         s_stat[gi * 2] = mean; s_stat[gi * 2 + 1] = rsqrtf(var + eps);
     }
+    if constexpr (MODE == 1) return;
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -249,8 +265,8 @@ __global__ __launch_bounds__(256) void gn_temporal_kernel(const float* __restric
             const float o[4] = {silu_f(fmaf(v[it][t][0] - ma, g0, bt[0])), silu_f(fmaf(v[it][t][1] - ma, g1, bt[1])),
                                 silu_f(fmaf(v[it][t][2] - mb, g2, bt[2])), silu_f(fmaf(v[it][t][3] - mb, g3, bt[3]))};
             const half4v h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-            *reinterpret_cast<half4v*>(y + off[it] + (int64_t)t * Npix * C) = h;
-            if (ylo) store_lo4(ylo, lo_fmt, off[it] + (int64_t)t * Npix * C, o, h);
+            *reinterpret_cast<half4v*>(y + offo[it] + (int64_t)t * Npix * C) = h;
+            if (ylo) store_lo4(ylo, lo_fmt, offo[it] + (int64_t)t * Npix * C, o, h);
         }
     }
 }
@@ -440,12 +456,41 @@ extern "C" int pnc_groupnorm_temporal_silu(const float* x, int B, int T, int Npi
     const size_t lds = ((size_t)PB * CP * 2 + (size_t)PB * GROUPS * 2) * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     half_t* y = reinterpret_cast<half_t*>(y16);
-#define PNC_GNT(TT) case TT: hipLaunchKernelGGL(gn_temporal_kernel<TT>, dim3(blocks), dim3(256), lds, st, \
-                                               x, B, Npix, C, gamma, beta, eps, y, y16_lo, lo_fmt, PB); break;
+#define PNC_GNT(TT) case TT: hipLaunchKernelGGL((gn_temporal_kernel<TT, 0>), dim3(blocks), dim3(256), lds, st, \
+                                               x, B, Npix, C, gamma, beta, eps, y, y16_lo, lo_fmt, PB, (float*)nullptr, TT, 0); break;
     switch (T) {
         PNC_GNT(1) PNC_GNT(2) PNC_GNT(3) PNC_GNT(4) PNC_GNT(5) PNC_GNT(6) PNC_GNT(7) PNC_GNT(8)
     }
 #undef PNC_GNT
+    return pnc_launch_status();
+}
+
+extern "C" int pnc_groupnorm_temporal_part(const float* x, int B, int T, int Npix, int C,
+                                           const float* gamma, const float* beta, float eps,
+                                           float* stats, int mode, int T_total,
+                                           void* y16, void* y16_lo, int lo_fmt, int t_pad, void* stream) {
+    if (!x || !stats || B < 1 || Npix < 1 || (mode != 1 && mode != 2)) return PNC_EINVAL;
+    if (C % 64 || C > 2048 || T < 1 || T > 8 || T_total < T || (t_pad != 0 && t_pad != 1)) return PNC_EINVAL;
+    if (mode == 2 && (!gamma || !beta || !y16 || (lo_fmt != PNC_LO_F16 && lo_fmt != PNC_LO_E4M3))) return PNC_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) return PNC_EALIGN;
+    if (((uintptr_t)y16 | (uintptr_t)y16_lo | (uintptr_t)stats) & 7) return PNC_EALIGN;
+    const int CP = C / 2;
+    int PB = 512 / (C / 4); if (PB < 1) PB = 1; if (PB > 16) PB = 16;
+    const int64_t total = (int64_t)B * Npix;
+    const unsigned blocks = (unsigned)((total + PB - 1) / PB);
+    const size_t lds = ((size_t)PB * CP * 2 + (size_t)PB * GROUPS * 2) * sizeof(float);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    half_t* y = reinterpret_cast<half_t*>(y16);
+#define PNC_GNTP(TT) case TT:                                                                                              \
+        if (mode == 1) hipLaunchKernelGGL((gn_temporal_kernel<TT, 1>), dim3(blocks), dim3(256), lds, st, x, B, Npix, C, gamma, beta, \
+                                          eps, y, y16_lo, lo_fmt, PB, stats, T_total, t_pad);                              \
+        else hipLaunchKernelGGL((gn_temporal_kernel<TT, 2>), dim3(blocks), dim3(256), lds, st, x, B, Npix, C, gamma, beta, eps, y, \
+                                y16_lo, lo_fmt, PB, stats, T_total, t_pad);                                                \
+        break;
+    switch (T) {
+        PNC_GNTP(1) PNC_GNTP(2) PNC_GNTP(3) PNC_GNTP(4) PNC_GNTP(5) PNC_GNTP(6) PNC_GNTP(7) PNC_GNTP(8)
+    }
+#undef PNC_GNTP
     return pnc_launch_status();
 }
 

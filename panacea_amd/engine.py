@@ -156,12 +156,15 @@ class FrameShard:
     `gather_rows` all-gathers tiny per-frame rows (the timestep embedding).  RCCL over xGMI on MI355X ("nccl"), gloo in
     the CPU tests; `group=None` with G = 1 is the loop-back used by the single-device GPU test."""
 
-    def __init__(self, G: int, index: int, group=None):
+    def __init__(self, G: int, index: int, group=None, resblock: str = "halo"):
         if G < 1 or not (0 <= index < G):
             raise ValueError(f"bad frame shard {index} of {G}")
         if G > 1 and group is None:
             raise ValueError("a frame shard over more than one rank needs its process group")
-        self.G, self.index, self.group = G, index, group
+        if resblock not in ("halo", "transpose"):
+            raise ValueError("resblock: 'halo' (statistics all-reduce + neighbour frames, round 4) or 'transpose' (round 2: the "
+                             "fp32 stream to the pixel sharding and back)")
+        self.G, self.index, self.group, self.resblock = G, index, group, resblock
         self.bytes_sent = 0                       # accounting for bench / DESIGN §9 (this rank, since construction)
         self.exchanges = 0
 
@@ -215,6 +218,79 @@ class FrameShard:
         if work is not None:
             work.wait()
         return recv.permute(1, 2, 0, 3, 4).contiguous().view(B * Tl * N, C)
+
+    # ---- round 4: the ResBlock3D temporal sites WITHOUT moving the fp32 stream.  The temporal GroupNorm only
+    #      needs per-(pixel, group) sums over all T frames: every rank reduces its frames, the frame group adds the partial sums
+    #      (256 B per pixel, whatever C and T); the k = 3 temporal conv only needs ONE frame of the normalised fp16 operand from
+    #      each neighbour rank.  Sent per pixel-channel and site at G = 4: ~5.7 B instead of 12 (fp32 h to the pixel layout and back).
+    def allreduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        """in-place sum over the frame group (the temporal GroupNorm's partial sums)"""
+        self.exchanges += 1
+        if self.group is None:          # loop-back (G = 1 without a process group)
+            return t
+        import torch.distributed as dist
+        host = dist.get_backend(self.group) == "gloo" and t.device.type != "cpu"
+        buf = t.cpu() if host else t
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        self.bytes_sent += 2 * t.numel() * t.element_size() * (self.G - 1) // self.G          # ring all-reduce: 2 (G-1)/G of the payload
+        if host:
+            t.copy_(buf)
+        return t
+
+    def halo_frames(self, planes, B: int, Tl: int):
+        """planes: tensors of [B, Tl + 2, N, C] (the (T + 2)-frame layout of PncGemmParams.t_halo; hi and lo plane of one operand)
+        whose frames 1 .. Tl are this rank's.  Fills frame 0 with the previous rank's last frame and frame Tl + 1 with the next
+        rank's first frame — zeros at the two ends of the clip (the conv's own zero padding in time, openaimodel.py:418,469).  One
+        all_to_all_single inside the frame group (split sizes name the one or two neighbours; nothing for the other ranks)."""
+        G, me = self.G, self.index
+        views = [p.view(B, Tl + 2, -1) for p in planes]
+        to_prev = [v[:, 1] for v in views]
+        to_next = [v[:, Tl] for v in views]
+        self.exchanges += 1
+        if G == 1:
+            for v in views:
+                v[:, 0].zero_()
+                v[:, Tl + 1].zero_()
+            if self.group is None:
+                return
+        dev = planes[0].device
+
+        def pack(ts):
+            return torch.cat([t.contiguous().view(-1).view(torch.uint8) for t in ts])
+        bp, bn = pack(to_prev), pack(to_next)
+        nb = bp.numel()
+        has_prev, has_next = me > 0, me < G - 1
+        in_split, out_split = [0] * G, [0] * G
+        parts = []
+        if has_prev:
+            in_split[me - 1] = out_split[me - 1] = nb
+            parts.append(bp)                             # (rank me - 1 < me + 1: already ordered by destination)
+        if has_next:
+            in_split[me + 1] = out_split[me + 1] = nb
+            parts.append(bn)
+        send = torch.cat(parts) if parts else bp[:0]
+        self.bytes_sent += send.numel()
+        import torch.distributed as dist
+        stage = dist.get_backend(self.group) == "gloo" and dev.type != "cpu"
+        if stage:
+            send = send.cpu()
+        recv = torch.empty(sum(out_split), dtype=torch.uint8, device=send.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=self.group)
+        if stage:
+            recv = recv.to(dev)
+        o = 0
+        from_prev = recv[o:o + nb] if has_prev else None
+        o += nb if has_prev else 0
+        from_next = recv[o:o + nb] if has_next else None
+        for slot, buf in ((0, from_prev), (Tl + 1, from_next)):
+            off = 0
+            for v in views:
+                n1 = v[:, slot].numel() * v.element_size()
+                if buf is None:
+                    v[:, slot].zero_()
+                else:
+                    v[:, slot] = buf[off:off + n1].view(v.dtype).view(v[:, slot].shape)
+                off += n1
 
     def gather_rows(self, x: torch.Tensor, B: int) -> torch.Tensor:
         """[B*T_l, D] per-frame rows -> [B*T, D] (frames of a sample in global order)"""
@@ -620,6 +696,20 @@ def gn_temporal(rt: Runtime, x32: torch.Tensor, N: int, C: int, gamma, beta, eps
     y = rt.empty((rt.B * rt.T * N, C), torch.float16)
     ylo = rt.lo_plane((rt.B * rt.T * N, C), "gnt")
     rt.be.groupnorm_temporal_silu(x32, rt.B, rt.T, N, C, gamma, beta, eps, y, ylo)
+    return y, ylo
+
+
+def gn_temporal_sharded(rt: Runtime, sh: "FrameShard", x32: torch.Tensor, N: int, C: int, gamma, beta, eps: float):
+    """The temporal GroupNorm + SiLU of a frame-sharded run in the FRAME layout: x32 holds this rank's T_local frames of N pixels per
+    sample.  -> (y16, y16_lo) in the (T_local + 2)-frame layout of the temporal conv (PncGemmParams.t_halo), halo frames filled."""
+    B, Tl = rt.B, rt.T_local
+    stats = rt.empty((B * N * 64,), torch.float32)
+    rt.be.groupnorm_temporal_part(x32, B, Tl, N, C, gamma, beta, eps, stats, 1, rt.T)
+    sh.allreduce_sum(stats)
+    y = rt.empty((B * (Tl + 2) * N, C), torch.float16)
+    ylo = rt.lo_plane((B * (Tl + 2) * N, C), "gnt")
+    rt.be.groupnorm_temporal_part(x32, B, Tl, N, C, gamma, beta, eps, stats, 2, rt.T, y, ylo, 1)
+    sh.halo_frames([y] + ([ylo] if ylo is not None else []), B, Tl)
     return y, ylo
 
 

@@ -66,7 +66,7 @@ class GemmParams(C.Structure):
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out16", C.c_void_p),
         ("ldln", C.c_int32), ("a_lo_fmt", C.c_int32),
         ("out_lo_fmt", C.c_int32), ("ldw_lo", C.c_int32),
-        ("W_lo", C.c_void_p), ("w_lo_exp", C.c_int32), ("reserved1", C.c_int32),
+        ("W_lo", C.c_void_p), ("w_lo_exp", C.c_int32), ("t_halo", C.c_int32),
     ]
 
 
@@ -100,6 +100,7 @@ _SIGNATURES = {
     "pnc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "pnc_groupnorm_apply": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P, _I, _P]),
     "pnc_groupnorm_combine": (_I, [_P, _I, _I, _I, _P, _P]),
+    "pnc_groupnorm_temporal_part": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P, _P, _I, _I, _P]),
     "pnc_groupnorm_temporal_silu": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _I, _P]),
     "pnc_layernorm": (_I, [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P]),
     "pnc_linear_smallm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -290,6 +291,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
         p.conv_pad_br = int(conv.get("pad_br", 0))
     if tconv:
         p.Cin, p.T, p.Npix = tconv["C"], tconv["T"], tconv["Npix"]
+        p.t_halo = int(tconv.get("halo", 0))
     p.bias, p.rowbias, p.rb_rows, p.rb_mod = _ptr(bias, f32, "bias"), _ptr(rowbias, f32, "rowbias"), rb_rows, rb_mod
     p.res1, p.ldr1, p.res2, p.ldr2 = _ptr(res1, f32, "res1"), ldr1, _ptr(res2, f32, "res2"), ldr2
     p.out32, p.ldc32, p.out16, p.ldc16 = _ptr(out32, f32, "out32"), ldc32, _ptr(out16, f16, "out16"), ldc16
@@ -369,6 +371,14 @@ def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16, y16_lo=
     _check(_timed("groupnorm_temporal", 0.0, nb, load().pnc_groupnorm_temporal_silu,
                   _ptr(x32), B, T, Npix, Cch, _ptr(gamma), _ptr(beta), eps, _ptr(y16), _ptr(y16_lo), lo_fmt(y16_lo), _stream()),
            "pnc_groupnorm_temporal_silu")
+
+
+def groupnorm_temporal_part(x32, B, T, Npix, Cch, gamma, beta, eps, stats, mode, T_total, y16=None, y16_lo=None, t_pad=0):
+    """mode 1: this rank's {sum, sum of squares} per (pixel, group) over its T frames -> stats [B*Npix, 32, 2]; mode 2: normalise +
+    SiLU with the sums of the whole frame group (T_total frames per sample), into the (T + 2 t_pad)-frame layout"""
+    nb = (4.0 if mode == 1 else 6.0 + _lo_bytes(y16_lo)) * B * T * Npix * Cch
+    _check(_timed("groupnorm", 0.0, nb, load().pnc_groupnorm_temporal_part, _ptr(x32), B, T, Npix, Cch, _ptr(gamma), _ptr(beta), eps,
+                  _ptr(stats), mode, T_total, _ptr(y16), _ptr(y16_lo), lo_fmt(y16_lo), t_pad, _stream()), "pnc_groupnorm_temporal_part")
 
 
 def layernorm(x32, ldx, M, Cch, gamma, beta, eps, y16, ldy, y16_lo=None):

@@ -249,7 +249,19 @@ class ResBlock3D(TimestepBlock, Packable):
         # emb32 arrives as SiLU(emb): the activation of `emb_layers` is applied ONCE per network evaluation by
         # _time_embedding (32 ResBlocks x 16 x 1280 identical SiLUs otherwise), the Linear runs here
         s = None
-        if sh is not None:
+        halo = sh is not None and sh.resblock == "halo"
+        if halo:
+            # Round 4: the site stays in the FRAME layout.  The temporal GroupNorm's per-(pixel, group) sums are added over the frame
+            # group (256 B per pixel), the normalised fp16 operand gets ONE halo frame from each neighbour rank, and the temporal
+            # conv reads the (T_local + 2)-frame layout (PncGemmParams.t_halo); the fp32 stream h never leaves the rank.
+            emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
+            t16, t16lo = E.gn_temporal_sharded(rt, sh, h, N, Co, pk["gt1"], pk["bt1"], 1e-5)
+            tch = dict(C=Co, T=rt.T_local, Npix=N, halo=1)
+            rt.be.gemm(t16, pk["wt1"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tch, bias=pk["ct1"],
+                       rowbias=emb_out, rb_rows=N, rb_mod=F, res1=h, ldr1=Co, out32=h, ldc32=Co, a16_lo=t16lo,
+                       w_lo=E.wlo(pk, "wt1", t16lo))
+        elif sh is not None:
+            # (round 2's form, FrameShard(resblock="transpose"): the fp32 stream to the pixel sharding and back)
             # the exchange runs on the communicator's stream; what this site computes independently of it — the timestep
             # embedding's linear and the skip path — is enqueued under the transfer
             pend = sh.to_pixels_start(h, rt.B, N)
@@ -258,12 +270,13 @@ class ResBlock3D(TimestepBlock, Packable):
             h = pend.result()
         else:
             emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
-        t16, t16lo = E.gn_temporal(rt, h, Nt, Co, pk["gt1"], pk["bt1"], 1e-5)
-        rt.be.gemm(t16, pk["wt1"], M=Mt, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct1"],
-                   rowbias=emb_out, rb_rows=Nt, rb_mod=rt.B * rt.T, res1=h, ldr1=Co, out32=h, ldc32=Co, a16_lo=t16lo,
-                   w_lo=E.wlo(pk, "wt1", t16lo))
-        if sh is not None:
-            h = sh.to_frames(h, rt.B, N)
+        if not halo:
+            t16, t16lo = E.gn_temporal(rt, h, Nt, Co, pk["gt1"], pk["bt1"], 1e-5)
+            rt.be.gemm(t16, pk["wt1"], M=Mt, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct1"],
+                       rowbias=emb_out, rb_rows=Nt, rb_mod=rt.B * rt.T, res1=h, ldr1=Co, out32=h, ldc32=Co, a16_lo=t16lo,
+                       w_lo=E.wlo(pk, "wt1", t16lo))
+            if sh is not None:
+                h = sh.to_frames(h, rt.B, N)
         # out_layers: GN + SiLU + conv3x3
         a16, a16lo = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True, split="gn_res")
         g = run_conv3x3(rt, a16, F, H, W, Co, pk["w2"], pk["c2"], Co, x16_lo=a16lo).f32
@@ -273,9 +286,14 @@ class ResBlock3D(TimestepBlock, Packable):
         # return skip(x) + (g + conv1d_t(SiLU(GN_t(g))))                 (:533-542)
         o16 = rt.empty((M, Co), torch.float16) if want_f16 else None
         o16lo = rt.lo_plane((M, Co), "stream", on=want_f16)
-        if sh is None:
-            t16, t16lo = E.gn_temporal(rt, g, N, Co, pk["gt2"], pk["bt2"], 1e-5)
-            rt.be.gemm(t16, pk["wt2"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct2"],
+        if sh is None or halo:
+            if halo:
+                t16, t16lo = E.gn_temporal_sharded(rt, sh, g, N, Co, pk["gt2"], pk["bt2"], 1e-5)
+                tc2 = dict(C=Co, T=rt.T_local, Npix=N, halo=1)
+            else:
+                t16, t16lo = E.gn_temporal(rt, g, N, Co, pk["gt2"], pk["bt2"], 1e-5)
+                tc2 = tconv
+            rt.be.gemm(t16, pk["wt2"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tc2, bias=pk["ct2"],
                        res1=g, ldr1=Co, res2=s, ldr2=Co, out32=g, ldc32=Co, out16=o16, ldc16=Co, a16_lo=t16lo,
                        out16_lo=o16lo, w_lo=E.wlo(pk, "wt2", t16lo))
         else:

@@ -117,12 +117,14 @@ def _contract(a16, Wm, M, N, K, lda, a_mode, conv, tconv):
     else:
         Cc, T, Npix = tconv["C"], tconv["T"], tconv["Npix"]
         B = M // (T * Npix)
-        x = a16.reshape(-1)[: M * Cc].view(B, T, Npix, Cc).permute(0, 2, 3, 1).reshape(B * Npix, Cc, T).float()
+        halo = int(tconv.get("halo", 0))       # PncGemmParams.t_halo: A holds T + 2 frames per sample, no temporal padding
+        Ta = T + 2 * halo
+        x = a16.reshape(-1)[: B * Ta * Npix * Cc].view(B, Ta, Npix, Cc).permute(0, 2, 3, 1).reshape(B * Npix, Cc, Ta).float()
         if Cc % 64 == 0:      # K order (ci/64, dt, ci%64)
             w = Wm.view(N, Cc // 64, 3, 64).permute(0, 1, 3, 2).reshape(N, Cc, 3)
         else:                 # K order (dt, ci)
             w = Wm.view(N, 3, Cc).permute(0, 2, 1)
-        y = TF.conv1d(x, w, padding=1)                       # [B*Npix, N, T]
+        y = TF.conv1d(x, w, padding=0 if halo else 1)        # [B*Npix, N, T]
         acc = y.view(B, Npix, N, T).permute(0, 3, 1, 2).reshape(M, N)
     return acc
 
@@ -144,7 +146,7 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
         if K % 16 or cin % (16 if a_mode == A_PLAIN else 64):      # the library's PNC_EALIGN
             raise PncError("e4m3 lo pass: K % 16 == 0 and lda % 16 == 0 (plain) / Cin % 64 == 0 (conv gathers)")
         Wl = _mat(w_lo[0], N, K, w_lo[0].shape[-1]).view(torch.float8_e4m3fn).float() * (2.0 ** (int(w_lo[1]) - 127))
-        acc_lo = _contract(_lo_value(a16_lo.reshape(-1)[: a16.numel()]), Wl, M, N, K, lda, a_mode, conv, tconv) / LO_SCALE
+        acc_lo = _contract(_lo_value(a16_lo.reshape(-1)[: a16.numel()]).reshape(a16.shape), Wl, M, N, K, lda, a_mode, conv, tconv) / LO_SCALE
     elif a16_lo is not None:     # fp16 lo plane: A = hi + lo * 2^-11 (the kernel sums the two planes' products in fp32)
         a16 = _join(a16.reshape(-1), a16_lo.reshape(-1)[: a16.numel()])
     acc = _contract(a16, Wm, M, N, K, lda, a_mode, conv, tconv)
@@ -303,6 +305,27 @@ def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu
     _mat(y16, F * Npix, Cch, ldy).copy_(h)
     if y16_lo is not None:
         _mat(y16_lo, F * Npix, Cch, ldy).copy_(_lo(y, h, y16_lo))
+
+
+def groupnorm_temporal_part(x32, B, T, Npix, Cch, gamma, beta, eps, stats, mode, T_total, y16=None, y16_lo=None, t_pad=0):
+    X = x32.reshape(-1)[: B * T * Npix * Cch].view(B, T, Npix, 32, Cch // 32).float()
+    S = stats.reshape(-1)[: B * Npix * 64].view(B, Npix, 32, 2)
+    if mode == 1:
+        S[..., 0] = X.sum(dim=(1, 4))
+        S[..., 1] = (X * X).sum(dim=(1, 4))
+        return
+    n = float((Cch // 32) * T_total)
+    mean = S[..., 0].double() / n
+    var = (S[..., 1].double() / n - mean * mean).clamp_min(0.0)
+    rstd = (1.0 / torch.sqrt(var + eps)).float()
+    y = (X - mean.float()[:, None, :, :, None]) * rstd[:, None, :, :, None]
+    y = TF.silu(y.reshape(B, T, Npix, Cch) * gamma.reshape(-1)[:Cch] + beta.reshape(-1)[:Cch])
+    h = r16(y, 'groupnorm_temporal')
+    Y = y16.reshape(-1)[: B * (T + 2 * t_pad) * Npix * Cch].view(B, T + 2 * t_pad, Npix, Cch)
+    Y[:, t_pad:t_pad + T] = h
+    if y16_lo is not None:
+        L = y16_lo.reshape(-1)[: B * (T + 2 * t_pad) * Npix * Cch].view(B, T + 2 * t_pad, Npix, Cch)
+        L[:, t_pad:t_pad + T] = _lo(y, h, y16_lo)
 
 
 def groupnorm_temporal_silu(x32, B, T, Npix, Cch, gamma, beta, eps, y16, y16_lo=None):

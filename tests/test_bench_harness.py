@@ -43,7 +43,7 @@ def test_bench_explicit_sharded_modes(mode, name):
     assert "strong_scaling" not in d
     if mode == "frames":
         ex = d["config"]["exchange"]
-        assert ex["all_to_all_per_step"] > 0 and ex["MB_sent_per_rank_and_step"] > 0
+        assert ex["frame_exchanges_per_step"] > 0 and ex["MB_sent_per_rank_and_step"] > 0
     if mode == "views":
         ex = d["config"]["exchange"]
         assert ex["neighbour_exchanges_per_step"] > 0 and ex["MB_sent_per_rank_and_step"] > 0
@@ -58,7 +58,7 @@ def test_bench_gpus_8_is_the_drivers_scaling_command():
     s = d["strong_scaling"]
     assert "error" not in s, s
     assert s["parallelism"] == "cfg x2 . frames x4" and s["ranks_per_sample"] == 8 and s["samples_in_flight"] == 1
-    assert s["exchange"]["all_to_all_per_step"] > 0 and s["per_sample_latency_ms"] > 0
+    assert s["exchange"]["frame_exchanges_per_step"] > 0 and s["per_sample_latency_ms"] > 0
 
 
 def test_bench_yaml_exact_setup_runs_multi_rank():

@@ -195,7 +195,17 @@ def test_view_and_frame_shard_loop_back_on_one_process():
         a, b = torch.randn(3, 5), torch.randn(2, 7).half()
         (fl, fl2), (fr, fr2) = vs._exchange([a, b], [a + 1, b + 1])
     assert torch.equal(fl, a + 1) and torch.equal(fl2, b + 1) and torch.equal(fr, a) and torch.equal(fr2, b)
-    assert torch.equal(got_f, ref) and sh.exchanges > 20 and vs.exchanges > 50 and vs.bytes_sent == 0
+    # the frame loop-back runs the ResBlock3D temporal sites in their sharded form (partial sums + the halo-frame layout of the
+    # temporal conv: other roundings of the statistics than the fused kernel's), the STT temporal branch through its transposes
+    df = (got_f - ref).abs()
+    assert df.max().item() <= 2e-3 and df.mean().item() <= 2.5e-4, (df.max().item(), df.mean().item())
+    assert sh.exchanges > 20 and vs.exchanges > 50 and vs.bytes_sent == 0
+    # round 2's form of the ResBlock sites (the fp32 stream to the pixel sharding and back) only moves data: same bits
+    parallel.apply_view_shard(w, None)
+    sh2 = E.FrameShard(1, 0, None, resblock="transpose")
+    parallel.apply_frame_shard(w, sh2)
+    with E.use_backend(emu), torch.no_grad():
+        assert torch.equal(w(inp["x"], inp["t"], cond(inp)), ref) and sh2.exchanges > 20
     # torch's conv over the widened map sums in another order than over the panorama: decorrelated fp16 operand roundings
     for got in (got_v, got_vf):
         d = (got - ref).abs()

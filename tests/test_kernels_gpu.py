@@ -273,6 +273,75 @@ def test_gemm_conv1d_temporal(B, T, Npix, C):
     check("conv1d_t", h["o"], e["o"], 2e-3)
 
 
+@pytest.mark.parametrize("B,Tl,Npix,C,lo8", [(2, 2, 96, 64, False), (1, 4, 300, 320, True), (2, 1, 64, 128, False), (1, 2, 3072, 320, True)])
+def test_gemm_conv1d_temporal_halo_layout(B, Tl, Npix, C, lo8):
+    """PncGemmParams.t_halo (round 4, engine.FrameShard): A holds Tl + 2 frames per sample — the frame before and after the Tl the
+    rows speak of are a neighbour rank's (or zeros) — and no tap is padded.  Against the emulation, and BIT-equal to the plain
+    launch over the Tl + 2 frames restricted to the inner frames (same products in the same order)."""
+    from panacea_amd import engine
+    M, N, K = B * Tl * Npix, C, 3 * C
+    x32 = rnd(B * (Tl + 2) * Npix, C, seed=61)
+    x = x32.half()
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=62)
+    bias, emb, res = rnd(N, seed=63), rnd(B * Tl, N, seed=64), rnd(M, N, seed=65)
+    kw = dict(a16=x, w16=w, M=M, N=N, K=K, a_mode=hip.A_CONV1D_T, tconv=dict(C=C, T=Tl, Npix=Npix, halo=1), bias=bias,
+              rowbias=emb, rb_rows=Npix, rb_mod=B * Tl, ldr1=N, ldc32=N)
+    xlo = None
+    if lo8:
+        xlo = torch.zeros(B * (Tl + 2) * Npix, C, device=DEV, dtype=torch.uint8)
+        hip.cast_f16(x32, x32.numel(), torch.zeros_like(x), xlo)
+        kw.update(a16_lo=xlo, w_lo=engine.pk_lo8(w))
+    oh, oe = res.clone(), res.clone()
+    hip.gemm(res1=oh, out32=oh, **kw)
+    emu.gemm(res1=oe, out32=oe, **kw)
+    torch.cuda.synchronize()
+    check("conv1d_t_halo", oh, oe, 2e-3)
+    # the plain launch over all Tl + 2 frames computes the same inner frames (its outer two see zero padding instead of halos)
+    Mf = B * (Tl + 2) * Npix
+    full = torch.zeros(Mf, N, device=DEV)
+    kf = dict(kw, M=Mf, tconv=dict(C=C, T=Tl + 2, Npix=Npix), rowbias=None, rb_rows=0, rb_mod=0)
+    hip.gemm(out32=full, **kf)
+    plain = torch.zeros(M, N, device=DEV)
+    hip.gemm(out32=plain, **dict(kw, rowbias=None, rb_rows=0, rb_mod=0))
+    torch.cuda.synchronize()
+    assert torch.equal(plain.view(B, Tl, Npix, N), full.view(B, Tl + 2, Npix, N)[:, 1:Tl + 1])
+
+
+@pytest.mark.parametrize("B,T,Tl,Npix,C,lo8", [(2, 8, 2, 96, 64, False), (1, 4, 4, 77, 320, True), (2, 8, 4, 64, 1280, True), (1, 2, 1, 40, 128, False)])
+def test_groupnorm_temporal_in_parts(B, T, Tl, Npix, C, lo8):
+    """pnc_groupnorm_temporal_part (round 4): the T frames of a pixel on T / Tl ranks — every rank's partial {sum, sum of squares}
+    (mode 1), added up, then the normalisation of the local frames (mode 2) into the (Tl + 2)-frame layout — against the fused
+    kernel over all T frames"""
+    x = rnd(B * T * Npix, C, seed=71) * 1.3 - 0.4
+    gamma, beta = rnd(C, seed=72) * 0.5 + 1, rnd(C, seed=73) * 0.3
+    ref = torch.zeros(B * T * Npix, C, device=DEV, dtype=torch.float16)
+    ref_lo = torch.zeros(B * T * Npix, C, device=DEV, dtype=torch.uint8) if lo8 else None
+    hip.groupnorm_temporal_silu(x, B, T, Npix, C, gamma, beta, 1e-5, ref, ref_lo)
+    G = T // Tl
+    xv = x.view(B, T, Npix, C)
+    parts = [xv[:, g * Tl:(g + 1) * Tl].contiguous() for g in range(G)]
+    stats = [torch.zeros(B * Npix * 64, device=DEV) for _ in range(G)]
+    for g in range(G):
+        hip.groupnorm_temporal_part(parts[g], B, Tl, Npix, C, gamma, beta, 1e-5, stats[g], 1, T)
+    total = torch.stack(stats).sum(0)
+    es = torch.zeros_like(total)
+    emu.groupnorm_temporal_part(parts[0], B, Tl, Npix, C, gamma, beta, 1e-5, es, 1, T)
+    torch.cuda.synchronize()
+    assert torch.allclose(stats[0], es, rtol=1e-5, atol=1e-4)
+    for g in range(G):
+        y = torch.full((B, Tl + 2, Npix, C), 9.0, device=DEV, dtype=torch.float16)
+        ylo = torch.zeros(B, Tl + 2, Npix, C, device=DEV, dtype=torch.uint8) if lo8 else None
+        hip.groupnorm_temporal_part(parts[g], B, Tl, Npix, C, gamma, beta, 1e-5, total, 2, T, y, ylo, 1)
+        torch.cuda.synchronize()
+        assert (y[:, 0] == 9.0).all() and (y[:, -1] == 9.0).all()          # the halo slots are the exchange's, not the kernel's
+        want = ref.view(B, T, Npix, C)[:, g * Tl:(g + 1) * Tl]
+        check(f"gn_temporal_part[{g}]", y[:, 1:Tl + 1], want, 2e-3)
+        if lo8:
+            rec = y[:, 1:Tl + 1].float() + ylo[:, 1:Tl + 1].view(torch.float8_e4m3fn).float() / 2048.0
+            rr = want.float() + ref_lo.view(B, T, Npix, C)[:, g * Tl:(g + 1) * Tl].view(torch.float8_e4m3fn).float() / 2048.0
+            check(f"gn_temporal_part_lo[{g}]", rec, rr, 2e-4, 1e-4)
+
+
 @pytest.mark.parametrize("M,N,K,geglu", [(1000, 320, 640, False), (49152, 640, 640, False), (700, 1280, 320, True),
                                          (12288, 1280, 192, False)])
 def test_gemm_tail_row_split_is_bit_identical(M, N, K, geglu):

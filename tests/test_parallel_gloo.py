@@ -88,7 +88,7 @@ def test_cfg_sharding_and_replicas_world2():
 
 
 # ------------------------------------------------------------------------ frame-group sharding
-def _frames_worker(rank, world, port, out_dir, cfg, G, T):
+def _frames_worker(rank, world, port, out_dir, cfg, G, T, resblock="halo"):
     """rank grid cfg x G over one sample of the tiny network with T frames: one eps evaluation and a 3-step schedule"""
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
@@ -103,9 +103,26 @@ def _frames_worker(rank, world, port, out_dir, cfg, G, T):
     assert lo.samples == 1 and lo.name
     groups = parallel.Groups(lo)
     shard = groups.frame_shard()
+    shard.resblock = resblock
     kw = configs.with_frames(configs.get("tiny"), T)
     net, _, _ = product_network("tiny", kw=kw)
     inp = step_inputs("tiny", kw, t_index=500, shape=(2, T, 8, 96))
+    # --- (0) round 4: partial sums added over the frame group, halo frames from the neighbour ranks (zeros at the clip's ends)
+    tl0 = T // G
+    clip = torch.arange(2 * T * 6 * 4, dtype=torch.float32).view(2, T, 6, 4) + 1.0
+    pad16 = torch.zeros(2, tl0 + 2, 6, 4, dtype=torch.float16)
+    pad8 = torch.zeros(2, tl0 + 2, 6, 4, dtype=torch.uint8)
+    pad16[:, 1:tl0 + 1] = clip[:, lo.frame_group * tl0:(lo.frame_group + 1) * tl0].half()
+    pad8[:, 1:tl0 + 1] = (clip[:, lo.frame_group * tl0:(lo.frame_group + 1) * tl0] % 251).to(torch.uint8)
+    pad16[:, 0] = pad16[:, -1] = 7.0                     # stale values the exchange must overwrite
+    shard.halo_frames([pad16, pad8], 2, tl0)
+    want = torch.zeros(2, T + 2, 6, 4)
+    want[:, 1:T + 1] = clip
+    lo_f, hi_f = lo.frame_group * tl0, (lo.frame_group + 1) * tl0
+    assert torch.equal(pad16.float(), want[:, lo_f:hi_f + 2].half().float())
+    assert torch.equal(pad8, (want[:, lo_f:hi_f + 2] % 251).to(torch.uint8) * (want[:, lo_f:hi_f + 2] > 0))
+    part = torch.full((5,), float(lo.frame_group + 1))
+    assert torch.equal(shard.allreduce_sum(part), torch.full((5,), float(G * (G + 1) // 2)))
     # --- (1) the exchanges themselves: to_pixels / to_frames against the global tensor
     Bx, N, C = 2, 48, 8
     full = torch.arange(Bx * T * N * C, dtype=torch.float32).view(Bx, T, N, C)
@@ -158,16 +175,16 @@ def _frames_worker(rank, world, port, out_dir, cfg, G, T):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,cfg,G,T", [(2, 1, 2, 4), (4, 2, 2, 4), (4, 1, 4, 4)])
-def test_frame_group_sharding_reproduces_the_single_process_eps(world, cfg, G, T):
+@pytest.mark.parametrize("world,cfg,G,T,resblock", [(2, 1, 2, 4, "halo"), (4, 2, 2, 4, "halo"), (4, 1, 4, 4, "halo"), (2, 1, 2, 4, "transpose")])
+def test_frame_group_sharding_reproduces_the_single_process_eps(world, cfg, G, T, resblock):
     """Frames of a sample over G ranks (x CFG halves): eps of every rank's frames and a 3-step trajectory equal the
     single-process result.  Tolerance: the torch emulation is not batch-invariant (GEMMs over M/G rows round differently)
     and a 1e-7 difference decorrelates the fp16 operand rounding downstream — the bound is the stated eps tolerance
     (1e-3 max-abs, BASELINE.json north_star), the observed difference is ~1e-4."""
     from panacea_amd.parallel import RankLayout
-    port = 29500 + ((os.getpid() * 7 + world * 13 + G) % 2000)
+    port = 29500 + ((os.getpid() * 7 + world * 13 + G + len(resblock)) % 2000)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_frames_worker, args=(world, port, d, cfg, G, T), nprocs=world, join=True)
+        mp.spawn(_frames_worker, args=(world, port, d, cfg, G, T, resblock), nprocs=world, join=True)
         ref = torch.load(Path(d) / "ref.pt")
         eps_ref = ref["eps_ref"].view(2, T, *ref["eps_ref"].shape[1:])
         tl = T // G

@@ -132,13 +132,16 @@ def test_sharded_layouts_loop_back_at_full_width(tmp_path):
         parallel.apply_view_shard(w, None)
         got_f = w(inp["x"], inp["t"], cond(inp))
     torch.cuda.synchronize()
-    # the frame loop-back moves data only: bit-identical.  The view loop-back runs every 3x3 conv over a map two (three) columns
-    # wider: per output element the kernels are width-invariant, but tile choice / split K follow M, so a summation order may change
-    assert torch.equal(got_f, ref) and sh.exchanges >= 100
+    # The view loop-back runs every 3x3 conv over a map two (three) columns wider: per output element the kernels are
+    # width-invariant, but tile choice / split K follow M, so a summation order may change.  The frame loop-back runs the
+    # ResBlock3D temporal sites in their sharded form (partial sums of the temporal GroupNorm + the halo-frame layout of the
+    # temporal conv): other roundings of the statistics — both differ from the unsharded eps like two `precise` runs do
+    df = (got_f - ref).abs()
+    assert sh.exchanges >= 100 and df.max().item() <= 1.2e-3 and df.mean().item() <= 2e-4, (df.max().item(), df.mean().item())
     dv, dvf = (got_v - ref).abs(), (got_vf - ref).abs()
     print(f"full width 16x192 T=2: view loop-back max {dv.max().item():.3e} mean {dv.mean().item():.3e} ({vs.exchanges} exchanges); "
           f"views+frames max {dvf.max().item():.3e}")
-    measured("loopback_full_width", view_max=dv.max().item(), view_mean=dv.mean().item(), both_max=dvf.max().item(),
+    measured("loopback_full_width", frame_max=df.max().item(), view_max=dv.max().item(), view_mean=dv.mean().item(), both_max=dvf.max().item(),
              view_exchanges=vs.exchanges, frame_exchanges=sh.exchanges)
     assert vs.exchanges > 300
     assert dv.max().item() <= 1.2e-3 and dv.mean().item() <= 2.0e-4

@@ -701,6 +701,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     } else {
         tn = tile % tiles_n; tm = tile / tiles_n;
     }
+    if constexpr (AMODE == PNC_A_CONV1D_T) {
+        // Temporal conv: the three taps of a row panel are the panels of frames t - 1, t, t + 1 at the SAME pixels — with the row
+        // panels in memory order (frame-major) the panel of frame t is fetched again, ~48 panels later and mostly on another
+        // XCD, for frame t + 1 and t - 1: the operand crossed the fabric three times (profiles/round4: 11.2 GB per step for the
+        // first temporal site against 6.2 GB of operands).  Walk the panels FRAME-FASTEST instead (pixel block outer): the
+        // consecutive tile ids one XCD works through are the frames of one pixel block, and two of the three reads hit its L2.
+        // A permutation of the row panels: same tiles, same arithmetic.
+        const int pb_n = p.Npix / BM;                        // row panels per frame
+        if (pb_n * BM == p.Npix && pb_n > 1) {
+            const int nbt = tiles_m / pb_n;                  // frames (b, t) of the launch
+            tm = (tm % nbt) * pb_n + tm / nbt;
+        }
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int ntiles_all = (p.K + BK - 1) / BK;
     const int kt_begin = (int)((int64_t)kslice * ntiles_all / ksplit);

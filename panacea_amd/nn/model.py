@@ -117,16 +117,12 @@ class ResnetBlock(nn.Module, Packable):
             raise NotImplementedError("ResnetBlock with a timestep embedding is not on the first-stage path")
         if in_channels % 64 or out_channels % 64:
             raise NotImplementedError("GroupNorm(32) kernels need channel counts that are multiples of 64")
-        self.norm1 = Normalize(in_channels)
-        self.conv1 = torch.nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
-        self.norm2 = Normalize(out_channels)
+        self.norm1, self.conv1 = Normalize(in_channels), _conv(in_channels, out_channels)
+        self.norm2, self.conv2 = Normalize(out_channels), _conv(out_channels, out_channels)
         self.dropout = torch.nn.Dropout(dropout)
-        self.conv2 = torch.nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
-        if self.in_channels != self.out_channels:
-            if self.use_conv_shortcut:
-                self.conv_shortcut = torch.nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
-            else:
-                self.nin_shortcut = torch.nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+        if in_channels != out_channels:                              # the checkpoint names the shortcut by its kind
+            name, k = ("conv_shortcut", 3) if conv_shortcut else ("nin_shortcut", 1)
+            setattr(self, name, _conv(in_channels, out_channels, k))
         self._init_packable()
 
     def _pack(self):
@@ -215,6 +211,38 @@ def make_attn(in_channels, attn_type="vanilla", attn_kwargs=None, temporal=False
     raise NotImplementedError(f"attn_type {attn_type!r} is not on the first-stage path")
 
 
+def _conv(cin: int, cout: int, k: int = 3) -> nn.Conv2d:
+    return torch.nn.Conv2d(cin, cout, kernel_size=k, stride=1, padding=k // 2)
+
+
+def _level_widths(ch: int, ch_mult) -> List[int]:
+    return [ch * m for m in ch_mult]
+
+
+def _stage(widths_in_out, n_blocks: int, with_attn: bool, attn_type: str, dropout: float, resample=None) -> nn.Module:
+    """One resolution level of the first-stage networks as the reference names it (`block`, `attn`, optional `upsample` /
+    `downsample`; model.py:800-820, 920-945): n_blocks ResnetBlocks from widths_in_out[0] to widths_in_out[1] channels, each
+    followed by an AttnBlock where the level's resolution is listed in attn_resolutions.  The state-dict names of a checkpoint
+    (`up.2.block.0.conv1.weight`, `down.1.downsample.conv.bias`, ...) are these attribute names."""
+    cin, cout = widths_in_out
+    level = nn.Module()
+    level.block = nn.ModuleList(ResnetBlock(in_channels=cin if i == 0 else cout, out_channels=cout, temb_channels=0, dropout=dropout)
+                                for i in range(n_blocks))
+    level.attn = nn.ModuleList(make_attn(cout, attn_type=attn_type) for _ in range(n_blocks if with_attn else 0))
+    if resample is not None:
+        name, module = resample
+        setattr(level, name, module)
+    return level
+
+
+def _mid(width: int, attn_type: str, dropout: float) -> nn.Module:
+    mid = nn.Module()
+    mid.block_1 = ResnetBlock(in_channels=width, out_channels=width, temb_channels=0, dropout=dropout)
+    mid.attn_1 = make_attn(width, attn_type=attn_type)
+    mid.block_2 = ResnetBlock(in_channels=width, out_channels=width, temb_channels=0, dropout=dropout)
+    return mid
+
+
 class Decoder(nn.Module, Packable):
     """model.py:882-1026.  `forward(z)`: z (F, z_channels, h, w) -> image (F, out_ch, 8h, 8w) for ch_mult of length 4."""
 
@@ -224,38 +252,25 @@ class Decoder(nn.Module, Packable):
         super().__init__()
         if use_linear_attn:
             raise NotImplementedError("linear attention is not on the first-stage path")
-        self.ch, self.temb_ch = ch, 0
-        self.num_resolutions = len(ch_mult)
-        self.num_res_blocks = num_res_blocks
-        self.resolution, self.in_channels = resolution, in_channels
+        widths = _level_widths(ch, ch_mult)
+        L = len(widths)
+        self.ch, self.temb_ch, self.num_resolutions, self.num_res_blocks = ch, 0, L, num_res_blocks
+        self.resolution, self.in_channels, self.z_channels, self.out_ch = resolution, in_channels, z_channels, out_ch
         self.give_pre_end, self.tanh_out = give_pre_end, tanh_out
-        block_in = ch * ch_mult[self.num_resolutions - 1]
-        curr_res = resolution // 2 ** (self.num_resolutions - 1)
-        self.z_shape = (1, z_channels, curr_res, curr_res)
-        self.z_channels = z_channels
-        self.conv_in = torch.nn.Conv2d(z_channels, block_in, kernel_size=3, stride=1, padding=1)
-        self.mid = nn.Module()
-        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
-        self.mid.attn_1 = make_attn(block_in, attn_type=attn_type)
-        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
-        self.up = nn.ModuleList()
-        for i_level in reversed(range(self.num_resolutions)):
-            block, attn = nn.ModuleList(), nn.ModuleList()
-            block_out = ch * ch_mult[i_level]
-            for _ in range(self.num_res_blocks + 1):
-                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
-                block_in = block_out
-                if curr_res in attn_resolutions:
-                    attn.append(make_attn(block_in, attn_type=attn_type))
-            up = nn.Module()
-            up.block, up.attn = block, attn
-            if i_level != 0:
-                up.upsample = Upsample(block_in, resamp_with_conv)
-                curr_res = curr_res * 2
-            self.up.insert(0, up)
-        self.norm_out = Normalize(block_in)
-        self.conv_out = torch.nn.Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
-        self.out_ch = out_ch
+        res = [resolution // 2 ** (L - 1 - k) for k in range(L)]             # coarse -> fine: the resolution of the k-th level built
+        self.z_shape = (1, z_channels, res[0], res[0])
+        self.conv_in = _conv(z_channels, widths[-1])
+        self.mid = _mid(widths[-1], attn_type, dropout)
+        # levels are built coarse -> fine (that is the order the widths chain in) and stored fine -> coarse like the reference's
+        # `self.up.insert(0, up)`: up[i] works at resolution / 2^i and upsamples unless it is the finest
+        levels, cin = [None] * L, widths[-1]
+        for k, i_level in enumerate(reversed(range(L))):
+            up = (("upsample", Upsample(widths[i_level], resamp_with_conv)) if i_level != 0 else None)
+            levels[i_level] = _stage((cin, widths[i_level]), num_res_blocks + 1, res[k] in attn_resolutions, attn_type, dropout, up)
+            cin = widths[i_level]
+        self.up = nn.ModuleList(levels)
+        self.norm_out = Normalize(widths[0])
+        self.conv_out = _conv(widths[0], out_ch)
         self._init_packable()
 
     def get_last_layer(self, **kwargs):
@@ -310,38 +325,21 @@ class Encoder(nn.Module, Packable):
         super().__init__()
         if use_linear_attn:
             raise NotImplementedError("linear attention is not on the first-stage path")
-        self.ch, self.temb_ch = ch, 0
-        self.num_resolutions = len(ch_mult)
-        self.num_res_blocks = num_res_blocks
+        widths = _level_widths(ch, ch_mult)
+        L = len(widths)
+        self.ch, self.temb_ch, self.num_resolutions, self.num_res_blocks = ch, 0, L, num_res_blocks
         self.resolution, self.in_channels = resolution, in_channels
-        self.conv_in = torch.nn.Conv2d(in_channels, self.ch, kernel_size=3, stride=1, padding=1)
-        curr_res = resolution
-        in_ch_mult = (1,) + tuple(ch_mult)
-        self.in_ch_mult = in_ch_mult
-        self.down = nn.ModuleList()
-        block_in = ch
-        for i_level in range(self.num_resolutions):
-            block, attn = nn.ModuleList(), nn.ModuleList()
-            block_in = ch * in_ch_mult[i_level]
-            block_out = ch * ch_mult[i_level]
-            for _ in range(self.num_res_blocks):
-                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
-                block_in = block_out
-                if curr_res in attn_resolutions:
-                    attn.append(make_attn(block_in, attn_type=attn_type))
-            down = nn.Module()
-            down.block, down.attn = block, attn
-            if i_level != self.num_resolutions - 1:
-                down.downsample = Downsample(block_in, resamp_with_conv)
-                curr_res = curr_res // 2
-            self.down.append(down)
-        self.mid = nn.Module()
-        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
-        self.mid.attn_1 = make_attn(block_in, attn_type=attn_type)
-        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
-        self.norm_out = Normalize(block_in)
+        self.in_ch_mult = (1,) + tuple(ch_mult)
+        self.conv_in = _conv(in_channels, ch)
+        chain = [ch] + widths                                        # level i: chain[i] -> chain[i + 1] channels at resolution / 2^i
+        self.down = nn.ModuleList(
+            _stage((chain[i], chain[i + 1]), num_res_blocks, (resolution // 2 ** i) in attn_resolutions, attn_type, dropout,
+                   ("downsample", Downsample(chain[i + 1], resamp_with_conv)) if i != L - 1 else None)
+            for i in range(L))
+        self.mid = _mid(widths[-1], attn_type, dropout)
+        self.norm_out = Normalize(widths[-1])
         self.out_channels = 2 * z_channels if double_z else z_channels
-        self.conv_out = torch.nn.Conv2d(block_in, self.out_channels, kernel_size=3, stride=1, padding=1)
+        self.conv_out = _conv(widths[-1], self.out_channels)
         self._init_packable()
 
     def _pack(self):

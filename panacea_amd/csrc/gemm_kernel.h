@@ -1223,6 +1223,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(cons
     }
 }
 
+// (Round 4 measured the same GEMM as TWO independent persistent 4-wave workgroups per CU — 128 x 256 tiles, 32-channel half tiles,
+// bit-identical — so that one workgroup's GEGLU epilogue runs under the other's MFMAs, the arrangement that gave the view
+// attention 8 %: 6 % SLOWER at level 0 (410 -> 435 us), 14 % at levels 1-2; staging W once per 128 rows instead of once per 256
+// costs more than the overlap returns.  Kernel source and numbers: tools/exp/gemm_geglu_2wg_kernel.h, profiles/round4/ff1_two_workgroups_ab_r4i.txt.)
 template <int BM, int BN, int WGM, int WGN>
 int launch_geglu_persist(const PncGemmParams& p, hipStream_t st) {
     constexpr int lds = 2 * (BM + BN) * 128;               // dynamic part: the operand ring (table and staging are static)

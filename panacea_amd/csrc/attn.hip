@@ -490,9 +490,10 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     // two MFMAs (600-670 TFLOP/s at level 0 vs 470-500 for 4 x 1); mid-size views: 8 x 1 (256 queries); small views: 4 x 1
     // (128).  Measured in profiles/round1/kbench_attn_variants.log, profiles/round4/attn_ab_r4a.log.
     const int force = pnc_get_option(PNC_OPT_ATTN_VARIANT);      // tests / kbench: force one variant
-    // Few keys per view (the 77 text tokens: two K/V tiles): the launch is a stream of q in / o out, and three 4-wave workgroups
-    // per CU hide its latencies better than one of 8 waves — 4 x 1: 90 / 48 / 30 us at levels 0-2 vs 100 / 53 / 37 for 8 x 2
-    // (profiles/round3/attn_text_variants_r3p.txt).
+    // Few keys per view (the 77 text tokens: two K/V tiles): the launch is a stream of q in / o out.  Round 3 took 4 waves x 1 block
+    // (three small workgroups per CU: 90 / 48 / 30 us at levels 0-2 vs 100 / 53 / 37 for 8 x 2); with two workgroups per CU the
+    // 4 x 2 shape (256 queries per workgroup: half the per-workgroup prologues) is faster still — 84 / 45 / 27 us vs 110 / 55 / 33
+    // on one box (tools/exp/text_attn_variants.py, profiles/round4/attn_text_variants_r4k.txt).
     const int kv_keys = p.kv_valid * 2;                           // at most two K/V segments per view
     // Large views (>= 512 queries): 4 waves x 2 blocks, TWO workgroups per CU (round 4).  The 8 x 2 workgroup it replaces shares
     // each K/V tile among 512 queries but its barrier re-aligns the two waves of every SIMD each tile, so their softmax (VALU)
@@ -500,7 +501,7 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     // cross 1221 -> 1164, level 1 intra 111 -> 100 (same box, interleaved: profiles/round4/attn_ab_r4a.log).  force = 1: the size
     // heuristic with 82 in the place of 42 (whole-step A/B of the old choice).
     const int big = force == 1 ? 82 : 42;
-    const int variant = force >= 41 ? force : (kv_keys <= 256 ? 41 : (Nq >= 512 ? big : (Nq >= 256 ? 81 : 41)));
+    const int variant = force >= 41 ? force : (kv_keys <= 256 ? (Nq >= 256 ? 42 : 41) : (Nq >= 512 ? big : (Nq >= 256 ? 81 : 41)));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int dma_mode = pnc_get_option(PNC_OPT_ATTN_DMA);
     const bool dma = ((kvWv & 7) == 0) && ((p.kvW & 7) == 0) && ((p.ldvt & 7) == 0) && ((p.vt_gstride & 7) == 0) && dma_mode != 0;

@@ -152,7 +152,7 @@ typedef struct PncGemmParams {
      * (sgm/modules/diffusionmodules/model.py:108-112) */
     int32_t conv_pad_br;
     /* sizeof(PncGemmParams) as the CALLER compiled it.  pnc_gemm_f16 / pnc_gemm_workspace_floats return PNC_EABI when
-     * it differs from the library's, instead of reading past a shorter struct (ABI version 3: 304 bytes). */
+     * it differs from the library's, instead of reading past a shorter struct (ABI version 4: 312 bytes). */
     int32_t struct_bytes;
     /* Precise ("split") activation operands.  An fp16 operand v is carried as two fp16 planes,
      *     hi = fp16(v),   lo = fp16((v - hi) * 2^11)        (a 22-bit operand; the 2^11 keeps lo out of the subnormals)
@@ -192,6 +192,12 @@ typedef struct PncGemmParams {
      * frame before the first and after the last of the T frames the rows speak of are present — a frame group's halo frames
      * (engine.FrameShard: the neighbour rank's frame, zeros at the two ends of the clip) — and no tap is padded */
     int32_t t_halo;
+    /* PNC_A_CONV3X3 over a BAND of a wider image (engine.ViewShard: a rank's columns of the panorama): 0 = off; otherwise the
+     * element offset from A (and from A_lo, in its own elements) to a block [2][frames][Hin][Cin] holding image column -1 (side
+     * 0) and column Win (side 1) of every row — the neighbour ranks' edge columns, zeros at the two ends of the panorama.  The
+     * taps that leave the band on the left / right read it instead of zero padding; rows above / below the image stay padded.
+     * Band, block and everything between them must lie within 2^31 bytes of each frame's origin. */
+    int64_t x_halo_off;
 } PncGemmParams;
 
 int pnc_gemm_f16(const PncGemmParams* p, void* stream);

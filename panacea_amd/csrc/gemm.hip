@@ -167,13 +167,16 @@ static int validate(const PncGemmParams& p) {
         if (p.stride != 1 && p.stride != 2) return PNC_EINVAL;
         if (p.upsample && (p.stride != 1 || p.Hout != 2 * p.Hin || p.Wout != 2 * p.Win)) return PNC_EINVAL;
         if (p.conv_pad_br && (p.upsample || p.stride != 2)) return PNC_EINVAL;
-        if (p.M % (p.Hout * p.Wout)) return PNC_EINVAL;
+        if (p.M % (p.Hout * p.Wout) || p.Wout >= 65536 || p.M / (p.Hout * p.Wout) >= 32768) return PNC_EINVAL;
+        if (p.x_halo_off < 0 || (p.x_halo_off && (p.conv_pad_br || (p.x_halo_off & 15)))) return PNC_EINVAL;
+        if (p.x_halo_off + 2 * (int64_t)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Cin >= (int64_t)1 << 30) return PNC_EINVAL;   // 2^31 bytes
     } else if (p.a_mode == PNC_A_CONV1D_T) {
         if (p.Cin % 8 || p.K != 3 * p.Cin || p.T <= 0 || p.Npix <= 0) return PNC_EINVAL;
         if (p.M % (p.T * p.Npix)) return PNC_EINVAL;
     } else {
         return PNC_EINVAL;
     }
+    if (p.a_mode != PNC_A_CONV3X3 && p.x_halo_off) return PNC_EINVAL;
     if (p.act != PNC_ACT_NONE && p.act != PNC_ACT_SILU && p.act != PNC_ACT_GELU) return PNC_EINVAL;
     if (p.ldw != 0 && (p.ldw < p.K || p.ldw % 8)) return PNC_EALIGN;
     if (p.rowbias && (p.rb_rows <= 0 || p.rb_mod <= 0)) return PNC_EINVAL;

@@ -63,7 +63,8 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 
 struct RowState {               // per staged A row, fixed over the K loop
     int rel;                    // element offset of the row origin from the tile's WINDOW origin (a_window_origin)
-    int y, x;                   // conv3x3: output pixel; conv1d: t in .y
+    int y, x;                   // conv3x3: output pixel, the row's frame in the upper 16 bits of .x (indexes a view band's column block);
+                                // conv1d: t in .y
     bool valid;
 };
 
@@ -90,7 +91,7 @@ __device__ __forceinline__ RowState make_row(const PncGemmParams& p, int m, int 
     } else if (AMODE == PNC_A_CONV3X3) {
         const int hw = p.Hout * p.Wout;
         const int f = mm / hw, pix = mm - f * hw;
-        s.y = pix / p.Wout; s.x = pix - s.y * p.Wout;
+        s.y = pix / p.Wout; s.x = (pix - s.y * p.Wout) | (f << 16);
         s.rel = (f - m0 / hw) * p.Hin * p.Win * p.Cin;
     } else {
         const int f = mm / p.Npix;
@@ -136,17 +137,28 @@ __device__ __forceinline__ unsigned a_chunk_off(const PncGemmParams& p, const Ro
             tap = kc / p.Cin; ci = kc - tap * p.Cin;
         }
         const int ky = tap / 3, kx = tap - ky * 3;
+        // x_halo_off: the image is a BAND of a wider one and its columns -1 and Win live in a block [2][frames][Hin][Cin] at A +
+        // x_halo_off (engine.ViewShard: the neighbour ranks' edge columns, zeros at the ends of the panorama)
+        const int xh = p.x_halo_off != 0 ? 1 : 0;
+        const int sx = s.x & 0xFFFF;
         int iy, ix; bool ok;
         if (p.upsample) {
-            const int uy = s.y + ky - 1, ux = s.x + kx - 1;
-            ok = (uy >= 0) && (uy < p.Hout) && (ux >= 0) && (ux < p.Wout);
-            iy = uy >> 1; ix = ux >> 1;
+            const int uy = s.y + ky - 1, ux = sx + kx - 1;
+            ok = (uy >= 0) && (uy < p.Hout) && (ux >= -xh) && (ux < p.Wout + xh);
+            iy = uy >> 1; ix = ux >> 1;                      // ux = -1 -> column -1, ux = Wout -> column Win
         } else {
             const int pad = p.conv_pad_br ? 0 : 1;
-            iy = s.y * p.stride + ky - pad; ix = s.x * p.stride + kx - pad;
-            ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+            iy = s.y * p.stride + ky - pad; ix = sx * p.stride + kx - pad;
+            ok = (iy >= 0) && (iy < p.Hin) && (ix >= -xh) && (ix < p.Win + xh);
         }
-        return ok ? (unsigned)(s.rel + (iy * p.Win + ix) * p.Cin + ci) * ESZ : PNC_BUF_OOB;
+        // (32-bit and branch-free: pnc_gemm_f16 admits a column block only when band + block stay below 2^30 elements)
+        int off = (iy * p.Win + ix) * p.Cin;
+        if (xh) {
+            const int f = s.x >> 16, frames = p.M / (p.Hout * p.Wout);
+            const int hoff = (int)p.x_halo_off - f * (p.Hin * p.Win * p.Cin) + (((ix < 0 ? 0 : frames) + f) * p.Hin + iy) * p.Cin;
+            off = (ix < 0 || ix >= p.Win) ? hoff : off;
+        }
+        return ok ? (unsigned)(s.rel + off + ci) * ESZ : PNC_BUF_OOB;
     } else {
         // K order: (dt, ci); (ci/64, dt, ci%64) when Cin % 64 == 0 (the three taps of a slice are consecutive K tiles)
         int tap, ci;

@@ -90,7 +90,11 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
     // Operands reach LDS through buffer resources (common.h: glds16_buf; 4-7 % over per-lane 64-bit pointers on every conv shape):
     // base = this tile's frame of each activation plane / the tile's first weight row, per-lane 32-bit byte offsets that do not
     // change along K (the slice / half tile enters as the scalar offset); PNC_BUF_OOB offsets read as zero (padding, N tail).
-    const unsigned frame_bytes = (unsigned)(p.Hin * p.Win * p.Cin) * 2u;
+    // x_halo_off (a view band): image columns -1 and Win are read from the block [2][frames][Hin][Cin] at A + x_halo_off, beyond the frame
+    const bool xh = p.x_halo_off != 0;
+    const unsigned frame_bytes = xh ? 0x7FFFFF00u : (unsigned)(p.Hin * p.Win * p.Cin) * 2u;
+    const int64_t xh_rel = p.x_halo_off - img_base + (int64_t)f * p.Hin * p.Cin;      // this frame's rows of the left column
+    const int64_t xh_side = (int64_t)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Cin;        // ... of the right column, from there
     const buffer_rsrc_t rs_a = make_rsrc(A + img_base, frame_bytes);
     const buffer_rsrc_t rs_lo = make_rsrc((A_lo ? A_lo : A) + img_base, frame_bytes);
     const buffer_rsrc_t rs_w = make_rsrc(Wt + (int64_t)n0 * p.ldw, 0x7FFFFF00u);
@@ -103,8 +107,10 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
         const int hy = hr / HW2, hx = hr - hy * HW2;
         const int c8 = (lane & 7) ^ ((hx >> 1) & 7);
         const int iy = Y0 - 1 + hy, ix = X0 - 1 + hx;
-        const bool ok = (hr < HROWS) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
-        const unsigned off = ok ? (unsigned)((iy * p.Win + ix) * p.Cin + c8 * 8) * 2u : PNC_BUF_OOB;     // out of the image: zeros
+        const bool yok = (hr < HROWS) && (iy >= 0) && (iy < p.Hin), xin = (ix >= 0) && (ix < p.Win);
+        const bool ok = yok && (xin || (xh && ix >= -1 && ix <= p.Win));
+        unsigned off = ok ? (unsigned)((iy * p.Win + ix) * p.Cin + c8 * 8) * 2u : PNC_BUF_OOB;           // out of the image: zeros
+        if (ok && !xin) off = (unsigned)(xh_rel + (ix < 0 ? 0 : xh_side) + iy * p.Cin + c8 * 8) * 2u;
         glds16_buf(lo_plane ? rs_lo : rs_a, off, (unsigned)cc << 7, halo + buf * HBYTES + b * 1024);
     };
     // ---- W DMA: half tile k = 32 channels of K tile k/2 = k offset 32 k of the packed [N][(ci/64, tap, ci%64)] weights.

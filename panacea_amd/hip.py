@@ -67,6 +67,7 @@ class GemmParams(C.Structure):
         ("ldln", C.c_int32), ("a_lo_fmt", C.c_int32),
         ("out_lo_fmt", C.c_int32), ("ldw_lo", C.c_int32),
         ("W_lo", C.c_void_p), ("w_lo_exp", C.c_int32), ("t_halo", C.c_int32),
+        ("x_halo_off", C.c_int64),
     ]
 
 
@@ -289,6 +290,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
         p.Hout, p.Wout = conv["Hout"], conv["Wout"]
         p.stride, p.upsample = conv.get("stride", 1), int(conv.get("upsample", 0))
         p.conv_pad_br = int(conv.get("pad_br", 0))
+        p.x_halo_off = int(conv.get("x_halo_off", 0))
     if tconv:
         p.Cin, p.T, p.Npix = tconv["C"], tconv["T"], tconv["Npix"]
         p.t_halo = int(tconv.get("halo", 0))

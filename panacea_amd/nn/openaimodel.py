@@ -70,29 +70,27 @@ def run_conv3x3(rt: Runtime, x16: torch.Tensor, F: int, Hin: int, Win: int, Cin_
 
 def _conv3x3_view_band(rt: Runtime, x16, F, Hin, Win, Cin_pad, w16, bias, Cout, stride, upsample, act_silu, out32, out16,
                        x16_lo, split_out, w_lo):
-    """run_conv3x3 on this rank's band of views (engine.ViewShard): the band is widened by the neighbours' halo columns, the
-    unmodified conv runs over the widened map, and the band's window of its output columns is kept.  (First form of the
-    view-group layout: the widen / window copies go away once the gather takes a window origin — DESIGN.md section 9.)"""
+    """run_conv3x3 on this rank's band of views (engine.ViewShard).  The band's columns -1 and Win — the neighbour ranks' edge
+    columns — sit in a tail of the operand's own allocation (ViewShard.band_operand) and the gather reads them where the
+    unsharded conv reads the neighbouring views (PncGemmParams.x_halo_off): the conv runs over the band as it lies and writes
+    the band's outputs, no widened copy of the operand and no window copy of the result."""
     vs = rt.vshard
-    left, right, first, n_out = vs.conv_window(Win, stride, upsample)
-    planes = [x16.view(F, Hin, Win, Cin_pad)] + ([x16_lo.view(F, Hin, Win, Cin_pad)] if x16_lo is not None else [])
-    wide = vs.halo(planes, left, right)
-    Wp = left + Win + right
+    if stride == 2 and Win % 2:
+        raise ValueError(f"a stride-2 conv over a view band needs an even band width, got {Win}")
+    planes, xoff = vs.band_operand(rt, [x16] + ([x16_lo] if x16_lo is not None else []), F, Hin, Win, Cin_pad)
     Hout = 2 * Hin if upsample else (Hin - 1) // stride + 1
-    Wout = 2 * Wp if upsample else (Wp - 1) // stride + 1
+    Wout = 2 * Win if upsample else (Win - 1) // stride + 1
     M = F * Hout * Wout
     o32 = rt.empty((M, Cout), torch.float32) if out32 else None
     o16 = rt.empty((M, Cout), torch.float16) if out16 else None
     o16lo = rt.lo_plane((M, Cout), split_out, on=out16) if split_out else None
-    rt.be.gemm(wide[0].view(-1, Cin_pad), w16, M=M, N=Cout, K=9 * Cin_pad, a_mode=E._hip.A_CONV3X3, w_lo=w_lo,
-               conv=dict(Cin=Cin_pad, Hin=Hin, Win=Wp, Hout=Hout, Wout=Wout, stride=stride, upsample=int(upsample)),
+    rt.be.gemm(planes[0], w16, M=M, N=Cout, K=9 * Cin_pad, a_mode=E._hip.A_CONV3X3, w_lo=w_lo,
+               conv=dict(Cin=Cin_pad, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride, upsample=int(upsample),
+                         x_halo_off=xoff),
                bias=bias, act=E._hip.ACT_SILU if act_silu else E._hip.ACT_NONE,
                out32=o32, ldc32=Cout, out16=o16, ldc16=Cout,
-               a16_lo=wide[1].view(-1, Cin_pad) if x16_lo is not None else None, out16_lo=o16lo)
-
-    def band(t):
-        return None if t is None else t.view(F, Hout, Wout, Cout)[:, :, first:first + n_out].contiguous().view(-1, Cout)
-    return Act(F, Hout, n_out, Cout, f32=band(o32), f16=band(o16), f16_lo=band(o16lo))
+               a16_lo=planes[1] if x16_lo is not None else None, out16_lo=o16lo)
+    return Act(F, Hout, Wout, Cout, f32=o32, f16=o16, f16_lo=o16lo)
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock, Packable):
@@ -243,7 +241,8 @@ class ResBlock3D(TimestepBlock, Packable):
         Mt = rt.B * rt.T * Nt
         tconv = dict(C=Co, T=rt.T, Npix=Nt)
         # in_layers: GN + SiLU + conv3x3
-        a16, a16lo = E.gn_spatial(rt, x.f32, F, N, Cin, pk["g1"], pk["b1"], 1e-5, True, split="gn_res")
+        tail = 2 * F * x.H if rt.vshard is not None else 0      # room for a view band's neighbour columns (_conv3x3_view_band)
+        a16, a16lo = E.gn_spatial(rt, x.f32, F, N, Cin, pk["g1"], pk["b1"], 1e-5, True, split="gn_res", tail_rows=tail)
         h = run_conv3x3(rt, a16, F, H, W, Cin, pk["w1"], pk["c1"], Co, x16_lo=a16lo).f32
         # h = h + conv1d_t(SiLU(GN_t(h))) + emb_layers(emb)[frame]      (:505-531)
         # emb32 arrives as SiLU(emb): the activation of `emb_layers` is applied ONCE per network evaluation by
@@ -278,7 +277,7 @@ class ResBlock3D(TimestepBlock, Packable):
             if sh is not None:
                 h = sh.to_frames(h, rt.B, N)
         # out_layers: GN + SiLU + conv3x3
-        a16, a16lo = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True, split="gn_res")
+        a16, a16lo = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True, split="gn_res", tail_rows=tail)
         g = run_conv3x3(rt, a16, F, H, W, Co, pk["w2"], pk["c2"], Co, x16_lo=a16lo).f32
         # skip path
         if s is None:
@@ -529,7 +528,8 @@ class UNetModel3D(nn.Module, Packable):
         """self.out: GN + SiLU + conv3x3 -> NCHW fp32 (:1245-1253, controlmodel.py:197-202); `tokens`: the channels-last
         fp32 tokens instead (consumed by the fused sampler-step exit, pnc_cfg_euler_step)."""
         pk = self.packed()
-        a16, a16lo = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, pk["og"], pk["ob"], 1e-5, True, split="gn_head")
+        a16, a16lo = E.gn_spatial(rt, h.f32, h.F, h.N, h.C, pk["og"], pk["ob"], 1e-5, True, split="gn_head",
+                                  tail_rows=2 * h.F * h.H if rt.vshard is not None else 0)
         o = run_conv3x3(rt, a16, h.F, h.H, h.W, h.C, pk["ow"], pk["oc"], self.out_channels, x16_lo=a16lo,
                         w_lo=E.wlo(pk, "ow", a16lo))
         if tokens:

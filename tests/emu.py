@@ -102,14 +102,22 @@ def _contract(a16, Wm, M, N, K, lda, a_mode, conv, tconv):
         stride, up = conv.get("stride", 1), conv.get("upsample", 0)
         Fr = M // (Hout * Wout)
         x = a16.reshape(-1)[: Fr * Hin * Win * Cin].view(Fr, Hin, Win, Cin).permute(0, 3, 1, 2).float()
+        xh = int(conv.get("x_halo_off", 0))      # PncGemmParams.x_halo_off: columns -1 and Win of a view band, [2][Fr][Hin][Cin]
+        if xh:
+            cols = a16.reshape(-1)[xh: xh + 2 * Fr * Hin * Cin].view(2, Fr, Hin, Cin).permute(0, 1, 3, 2).float()
+            x = torch.cat([cols[0][..., None], x, cols[1][..., None]], dim=3)
         if up:
             x = TF.interpolate(x, scale_factor=2, mode="nearest")
+            if xh:
+                x = x[..., 1:-1]
         if Cin % 64 == 0:     # K order (ci/64, ky, kx, ci%64)
             w = Wm.view(N, Cin // 64, 3, 3, 64).permute(0, 1, 4, 2, 3).reshape(N, Cin, 3, 3)
         else:                 # K order (ky, kx, ci)
             w = Wm.view(N, 3, 3, Cin).permute(0, 3, 1, 2)
         if conv.get("pad_br", 0):
             y = TF.conv2d(TF.pad(x, (0, 1, 0, 1)), w, stride=stride, padding=0)
+        elif xh:
+            y = TF.conv2d(TF.pad(x, (0, 0, 1, 1)), w, stride=stride, padding=0)
         else:
             y = TF.conv2d(x, w, stride=stride, padding=1)
         assert y.shape[2] == Hout and y.shape[3] == Wout, (y.shape, Hout, Wout)

@@ -40,7 +40,7 @@ def test_ctypes_structs_match_the_header_as_gcc_lays_it_out(tmp_path):
         for f in fields[st]:
             assert int(got[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
     assert int(got["abi"]) == hip.ABI_VERSION
-    assert ctypes.sizeof(hip.GemmParams) == 304
+    assert ctypes.sizeof(hip.GemmParams) == 312
 
 
 def test_enum_constants_match_the_header_as_gcc_reads_it(tmp_path):

@@ -273,6 +273,62 @@ def test_gemm_conv1d_temporal(B, T, Npix, C):
     check("conv1d_t", h["o"], e["o"], 2e-3)
 
 
+@pytest.mark.parametrize("F,H,W,V,Cin,N,stride,up,lo", [
+    (2, 16, 64, 2, 64, 320, 1, 0, None),        # stencil tiles (16 x 16)
+    (1, 32, 192, 3, 128, 320, 1, 0, "f16"),     # stencil tiles, two slices, precise operand (fp16 lo plane)
+    (3, 8, 96, 3, 64, 256, 1, 0, "e4m3"),       # 8 x 32 tiles / per-tap lo8 pass
+    (2, 8, 48, 2, 16, 64, 1, 0, None),          # narrow input: the per-tap gather, K order (ky, kx, ci)
+    (2, 16, 48, 2, 64, 128, 2, 0, None),        # stride 2 (Downsample): only the left column is read
+    (1, 8, 48, 6, 128, 64, 1, 1, None),         # nearest x2 then conv (Upsample), six bands
+    (2, 8, 96, 2, 320, 320, 2, 0, "e4m3"),      # Downsample of a precise stream
+    (1, 16, 96, 2, 320, 640, 1, 1, "f16"),
+])
+def test_gemm_conv3x3_view_band_columns(F, H, W, V, Cin, N, stride, up, lo):
+    """PncGemmParams.x_halo_off (round 4, engine.ViewShard): a 3x3 conv over a BAND of the panorama whose columns -1 / W_l sit in a
+    block behind the band.  The bands' outputs, side by side, are the conv over the whole panorama — the same products in the same
+    K order per output pixel (compared to 2e-6 of the output scale: only a split-K choice could reorder them) — and each band
+    agrees with the emulation."""
+    from panacea_amd import engine
+    wl = W // V
+    K = 9 * Cin
+    x32 = rnd(F, H, W, Cin, seed=71)
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=72)
+    bias = rnd(N, seed=73)
+
+    def planes(v32):
+        hi = v32.half()
+        if lo == "f16":
+            return hi, ((v32 - hi.float()) * 2048.0).half()
+        if lo == "e4m3":
+            q = torch.zeros(v32.shape, device=DEV, dtype=torch.uint8)
+            hip.cast_f16(v32.contiguous(), v32.numel(), torch.zeros_like(hi), q)
+            return hi, q
+        return hi, None
+    w_lo = engine.pk_lo8(w) if lo == "e4m3" else None
+    Hout, Wfull = (2 * H, 2 * W) if up else ((H - 1) // stride + 1, (W - 1) // stride + 1)
+    hi, lop = planes(x32)
+    full = torch.zeros(F * Hout * Wfull, N, device=DEV)
+    hip.gemm(a16=hi, w16=w, M=full.shape[0], N=N, K=K, a_mode=hip.A_CONV3X3, bias=bias, out32=full, ldc32=N, a16_lo=lop, w_lo=w_lo,
+             conv=dict(Cin=Cin, Hin=H, Win=W, Hout=Hout, Wout=Wfull, stride=stride, upsample=up))
+    Wout = Wfull // V
+    zero = torch.zeros(F, H, 1, Cin, device=DEV)
+    for v in range(V):
+        band = x32[:, :, v * wl:(v + 1) * wl]
+        left = x32[:, :, v * wl - 1:v * wl] if v > 0 else zero
+        right = x32[:, :, (v + 1) * wl:(v + 1) * wl + 1] if v < V - 1 else zero
+        whole = torch.cat([band.reshape(-1, Cin), left.reshape(-1, Cin), right.reshape(-1, Cin)])
+        bhi, blo = planes(whole)
+        kw = dict(a16=bhi, w16=w, M=F * Hout * Wout, N=N, K=K, a_mode=hip.A_CONV3X3, bias=bias, ldc32=N, a16_lo=blo, w_lo=w_lo,
+                  conv=dict(Cin=Cin, Hin=H, Win=wl, Hout=Hout, Wout=Wout, stride=stride, upsample=up, x_halo_off=F * H * wl * Cin))
+        oh, oe = torch.zeros(kw["M"], N, device=DEV), torch.zeros(kw["M"], N, device=DEV)
+        hip.gemm(out32=oh, **kw)
+        emu.gemm(out32=oe, **kw)
+        torch.cuda.synchronize()
+        check(f"band {v} vs emu", oh, oe, *((2e-5, 1e-5) if lo else (2e-3, 2e-3)))
+        want = full.view(F, Hout, Wfull, N)[:, :, v * Wout:(v + 1) * Wout].reshape(-1, N)
+        check(f"band {v} vs the panorama's conv", oh, want, 2e-6, 2e-6)
+
+
 @pytest.mark.parametrize("B,Tl,Npix,C,lo8", [(2, 2, 96, 64, False), (1, 4, 300, 320, True), (2, 1, 64, 128, False), (1, 2, 3072, 320, True)])
 def test_gemm_conv1d_temporal_halo_layout(B, Tl, Npix, C, lo8):
     """PncGemmParams.t_halo (round 4, engine.FrameShard): A holds Tl + 2 frames per sample — the frame before and after the Tl the

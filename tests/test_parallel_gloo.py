@@ -257,20 +257,36 @@ def _views_worker(rank, world, port, out_dir, cfg, V, T, network):
     wgt = torch.randn(5, C, 3, 3, generator=g)
     wl = W // V
     mine = full[:, :, vg * wl:(vg + 1) * wl].contiguous()
+    import types
+    from panacea_amd import engine as E
+    stub = types.SimpleNamespace(device=torch.device("cpu"))
+    stub.empty = lambda shape, dtype, tail_rows=0: E.Runtime.empty(stub, shape, dtype, tail_rows)
+    full, wgt = full.half().float(), wgt.half().float()
+    w16 = E.pk_conv3x3(wgt)
+    mine = full[:, :, vg * wl:(vg + 1) * wl].contiguous()
     for stride, up in ((1, False), (2, False), (1, True)):
-        left, right, first, n_out = vs.conv_window(wl, stride, up)
-        wide, = vs.halo([mine], left, right)
-        assert wide.shape[2] == left + wl + right
+        for in_place in (False, True):
+            if in_place:        # an operand that was allocated with room for the columns is used where it lies
+                op = stub.empty((Fx * H * wl, C), torch.float16, 2 * Fx * H)
+                op.copy_(mine.view(-1, C))
+            else:
+                op = mine.half().view(-1, C)
+            (plane,), xoff = vs.band_operand(stub, [op], Fx, H, wl, C)
+            assert (plane.data_ptr() == op.data_ptr()) == in_place and xoff == Fx * H * wl * C
+            Hout = 2 * H if up else (H - 1) // stride + 1
+            Wout = 2 * wl if up else (wl - 1) // stride + 1
+            got = torch.empty(Fx * Hout * Wout, 5)
+            emu.gemm(plane, w16, M=got.shape[0], N=5, K=9 * C, a_mode=emu.A_CONV3X3,
+                     conv=dict(Cin=C, Hin=H, Win=wl, Hout=Hout, Wout=Wout, stride=stride, upsample=int(up), x_halo_off=xoff),
+                     out32=got, ldc32=5)
 
-        def conv(t):
-            t = t.permute(0, 3, 1, 2)
-            if up:
-                t = TF.interpolate(t, scale_factor=2, mode="nearest")
-            return TF.conv2d(t, wgt, stride=stride, padding=1)
-        want = conv(full)
-        wo = want.shape[-1] // V
-        got = conv(wide)[..., first:first + n_out]
-        assert n_out == wo and torch.allclose(got, want[..., vg * wo:(vg + 1) * wo], atol=1e-5), (stride, up)
+            def conv(t):
+                t = t.permute(0, 3, 1, 2)
+                if up:
+                    t = TF.interpolate(t, scale_factor=2, mode="nearest")
+                return TF.conv2d(t, wgt, stride=stride, padding=1)
+            want = conv(full)[..., vg * Wout:(vg + 1) * Wout].permute(0, 2, 3, 1).reshape(-1, 5)
+            assert torch.allclose(got, want, atol=1e-4), (stride, up, in_place, (got - want).abs().max())
     # --- (1b) GroupNorm statistics of the whole panorama from the bands' records
     x32 = torch.randn(Fx * H * wl, 64, generator=torch.Generator().manual_seed(11 + vg)) * (1 + vg) + vg
     ppc = 8

@@ -112,8 +112,8 @@ def _rccl_world1_view_worker(rank, port, out):
 def test_sharded_layouts_loop_back_at_full_width(tmp_path):
     """BASELINE config 4's code paths at the network's real width on ONE device: the Panacea+
     network on a 16x192 panorama, T = 2, through (a) the loop-back ViewShard (G = 1: the band is the whole panorama and its own
-    circular neighbour — every conv runs over a widened map and keeps its window, every spatial GroupNorm applies combined
-    records, the cross-view attention reads the kv_views = 8 layout), (b) the loop-back FrameShard (every to_pixels / to_frames
+    circular neighbour — every 3x3 conv reads its columns -1 / W from the block behind its operand (PncGemmParams.x_halo_off), every
+    spatial GroupNorm applies combined records, the cross-view attention reads the kv_views = 8 layout), (b) the loop-back FrameShard (every to_pixels / to_frames
     site), (c) both at once (the cfg x views x frames grid's runtime).  Then the view exchanges through a one-rank RCCL group."""
     from helpers import cond, product_network, step_inputs
     from panacea_amd import configs, engine as E, parallel
@@ -132,8 +132,8 @@ def test_sharded_layouts_loop_back_at_full_width(tmp_path):
         parallel.apply_view_shard(w, None)
         got_f = w(inp["x"], inp["t"], cond(inp))
     torch.cuda.synchronize()
-    # The view loop-back runs every 3x3 conv over a map two (three) columns wider: per output element the kernels are
-    # width-invariant, but tile choice / split K follow M, so a summation order may change.  The frame loop-back runs the
+    # The view loop-back runs every 3x3 conv over the band as it lies (same M, same tiles; the column block holds zeros = the
+    # padding) and the GroupNorms on one combined record per frame: measured bit-identical to the unsharded eps.  The frame loop-back runs the
     # ResBlock3D temporal sites in their sharded form (partial sums of the temporal GroupNorm + the halo-frame layout of the
     # temporal conv): other roundings of the statistics — both differ from the unsharded eps like two `precise` runs do
     df = (got_f - ref).abs()

@@ -367,6 +367,8 @@ def main():
                     help="A/B: PNC_OPT_STENCIL_TILES (0 = one gathered A tile per tap everywhere, 1 = default, 2 = halo tiles wherever the shape allows)")
     ap.add_argument("--gemm-group-m", type=int, default=0,
                     help="A/B: PNC_OPT_GEMM_GROUP_M (0 = auto, 1 = plain tile order, k = groups of k row panels); same result")
+    ap.add_argument("--no-gn-epilogue", action="store_true",
+                    help="A/B: GroupNorm statistics from their own launches instead of the temporal convs' epilogues")
     ap.add_argument("--no-modes", action="store_true", help="do not time the other operand policy (profiling runs)")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: pnc_set_option before the run, e.g. ATTN_VARIANT=42, ATTN_DEFER_MAX=0, GEMM_PERSIST=0 (hip.OPT_<NAME>); "
@@ -424,6 +426,9 @@ def main():
         hip.set_option(hip.OPT_STENCIL_TILES, args.stencil_tiles)
     if args.gemm_group_m:
         hip.set_option(hip.OPT_GEMM_GROUP_M, args.gemm_group_m)
+    if args.no_gn_epilogue:
+        from panacea_amd import engine as _eng
+        _eng.GN_FROM_EPILOGUE = False
     for kv in args.set_option:
         name, _, val = kv.partition("=")
         hip.set_option(getattr(hip, "OPT_" + name.upper()), int(val))

@@ -71,7 +71,9 @@ enum {
                                      rescaling of its accumulators — until some query of the wave exceeds it by more than k in the
                                      exp2 domain (probabilities then reach at most 2^k: fp16-safe up to 15); 0 = rescale whenever a
                                      maximum grows.  Same softmax, other roundings of P (not bit-identical across values) */
-    PNC_OPT_COUNT = 9
+    PNC_OPT_GEMM_GN_STATS = 9,    /* 1 (default): PncGemmParams.gn_part comes out of the temporal conv's epilogue where its waves own whole
+                                     groups; 0 = always the statistics kernel after the GEMM (same records up to fp32 summation order) */
+    PNC_OPT_COUNT = 10
 };
 int pnc_set_option(int option, int value);
 
@@ -152,7 +154,7 @@ typedef struct PncGemmParams {
      * (sgm/modules/diffusionmodules/model.py:108-112) */
     int32_t conv_pad_br;
     /* sizeof(PncGemmParams) as the CALLER compiled it.  pnc_gemm_f16 / pnc_gemm_workspace_floats return PNC_EABI when
-     * it differs from the library's, instead of reading past a shorter struct (ABI version 4: 312 bytes). */
+     * it differs from the library's, instead of reading past a shorter struct (ABI version 4: 320 bytes). */
     int32_t struct_bytes;
     /* Precise ("split") activation operands.  An fp16 operand v is carried as two fp16 planes,
      *     hi = fp16(v),   lo = fp16((v - hi) * 2^11)        (a 22-bit operand; the 2^11 keeps lo out of the subnormals)
@@ -198,6 +200,14 @@ typedef struct PncGemmParams {
      * taps that leave the band on the left / right read it instead of zero padding; rows above / below the image stay padded.
      * Band, block and everything between them must lie within 2^31 bytes of each frame's origin. */
     int64_t x_halo_off;
+    /* PNC_A_CONV1D_T: GroupNorm(32) statistics of the fp32 output, from the GEMM (util.py:276-283: the GroupNorm that follows
+     * every temporal conv of a ResBlock3D reads what this launch writes).  NULL = off; otherwise [frames][ceil(Npix / 64)][32][3]
+     * floats that receive the {n, mean, M2} records pnc_groupnorm_stats(out32, ldc32, frames, Npix, N, 64, gn_part) would
+     * write — frames = M / Npix, channels = N — for pnc_groupnorm_apply(..., n_records = ceil(Npix / 64)).  When a workgroup's
+     * waves own whole groups (N % 320 == 0 on the 256x320 tile, Npix % 64 == 0) the records come out of the epilogue, one per
+     * (64-row block, group), in a fixed summation order; otherwise the library launches its statistics kernel after the GEMM
+     * on the same stream.  Needs out32 (ldc32 % 4 == 0), N % 64 == 0. */
+    float* gn_part;
 } PncGemmParams;
 
 int pnc_gemm_f16(const PncGemmParams* p, void* stream);
@@ -255,14 +265,16 @@ int pnc_attn_temporal_f16(const void* q, int ldq, const void* k, int ldk,
  * ------------------------------------------------------------------------- */
 /* Spatial GroupNorm(32,C) over one frame's (H*W, C/32) slab, two launches.
  *   stats: partial[(f*nchunk + chunk)*32 + g] = {count, mean, M2}
- *   apply: y = (x-mean)*rstd*gamma+beta, optional SiLU, -> fp16 [F*Npix][ldy]
+ *   apply: y = (x-mean)*rstd*gamma+beta, optional SiLU, -> fp16 [F*Npix][ldy].  n_records: records per frame in `partial`
+ *          (0 = ceil(Npix / pix_per_chunk), what pnc_groupnorm_stats with the same chunking wrote; another count when they come
+ *          from elsewhere: PncGemmParams.gn_part writes ceil(Npix / 64) per frame) — pix_per_chunk only shapes the apply's own grid
  *    -> nn.GroupNorm (diffusionmodules/util.py:283 eps 1e-5; attention.py:129-132 eps 1e-6) + nn.SiLU */
 int pnc_groupnorm_stats(const float* x, int ldx, int F, int Npix, int C,
                         int pix_per_chunk, float* partial, void* stream);
 int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int C,
                         int pix_per_chunk, const float* partial,
                         const float* gamma, const float* beta, float eps, int silu,
-                        void* y16, int ldy, void* y16_lo, int lo_fmt, void* stream);
+                        void* y16, int ldy, void* y16_lo, int lo_fmt, int n_records, void* stream);
 /* Chan-combine `parts` sets of chunk records, in[((s*F + f)*nchunk + c)*32 + g] = {count, mean, M2} (the all-gathered
  * pnc_groupnorm_stats records of the bands of a view group), per (frame, group), in the fixed order (s, c):
  * out[(f*nchunk + 0)*32 + g] = the combined record, every other slot of the frame {0, 0, 0} — an empty record leaves the

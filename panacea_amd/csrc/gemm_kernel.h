@@ -48,7 +48,8 @@ enum : unsigned {
     E_GEGLU = 64,    // value * gelu(gate) on interleaved 32-column blocks, fp16 output
     E_GENERIC = 128, // run-time flags, scalar predicated accesses: ragged N, unaligned pointers / leading dimensions
     E_GELU = 256,    // erf GELU on the fp16 output (text-tower MLP); its own variant: erff is ~60 instructions per element
-    E_LN = 512       // LayerNorm of the fp32 output rows written as fp16 by the same workgroup (it owns whole rows)
+    E_LN = 512,      // LayerNorm of the fp32 output rows written as fp16 by the same workgroup (it owns whole rows)
+    E_GS = 1024      // GroupNorm(32) statistics of the fp32 output: one {n, mean, M2} record per (64-row wave block, group) (PncGemmParams.gn_part)
 };
 
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;   // lo plane = (v - hi) * 2^11
@@ -244,9 +245,22 @@ struct RowHalo {
 template <int MI, int NI, unsigned EPI, class RM = RowLinear>
 __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[MI][NI], float* ep, int lane,
                                          RM rmap, int nw, int ncols, float2* ln_mine = nullptr,
-                                         const float2* ln_partner = nullptr) {
+                                         const float2* ln_partner = nullptr, float* gs_tab = nullptr) {
     constexpr bool R1 = (EPI & E_R1) != 0, R2 = (EPI & E_R2) != 0, RB = (EPI & E_RB) != 0;
     constexpr bool O32 = (EPI & E_O32) != 0, O16 = (EPI & E_O16) != 0, LN = (EPI & E_LN) != 0;
+    // E_GS: GroupNorm statistics of the values this wave writes (its MI*32 rows x NI*32 columns; the host admits the variant only
+    // when every group of N/32 channels lies inside one wave's columns, cpg even, and the rows are whole and of one frame).  Per
+    // slab a lane owns 8 columns = at most two groups' pieces: pair sums over the slab's passes in registers, split at the
+    // group boundary once per slab, added over the slab's row lanes (xor shuffles) and kept per 8-column chunk in gs_tab
+    // ([NI*4][4] floats of this wave: {sum, squares} of the piece in the chunk's first group, then of the next group's).
+    // No atomics and a fixed order everywhere: the records are reproducible bit for bit.
+    constexpr bool GS = (EPI & E_GS) != 0;
+    static_assert(!GS || (O32 && !LN), "statistics of the fp32 output; not next to the fused LayerNorm");
+    const int cpg = GS ? (p.N >> 5) : 1;
+    if constexpr (GS) {
+        gs_tab[lane] = 0.0f;
+        if (lane + 64 < NI * 16) gs_tab[lane + 64] = 0.0f;
+    }
     static_assert(!LN || O32, "the fused LayerNorm normalises the fp32 output it has just written");
     constexpr bool HAS_X = R1 || RB, HAS_Y = R1 && (R2 || RB);
     static_assert(!(R2 && !R1), "a single residual is passed as res1");
@@ -306,6 +320,7 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
         f32x4 b0 = z4, b1 = z4;
         if (p.bias && col_on) { b0 = ld4(p.bias + ncol); b1 = ld4(p.bias + ncol + 4); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // previous slab fully read back from LDS
+        float gP[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gQ[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // E_GS: column-pair sums over this slab's passes
         static_for<cw>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
 #pragma unroll
@@ -374,6 +389,15 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
                 *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
             }
+            if constexpr (GS) {
+                if (on) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        gP[k] += v[2 * k] + v[2 * k + 1];
+                        gQ[k] += fmaf(v[2 * k], v[2 * k], v[2 * k + 1] * v[2 * k + 1]);
+                    }
+                }
+            }
             if (!on) return;
             if constexpr (O32) {
                 float* op = p.out32 + (int64_t)m * p.ldc32 + ncol;
@@ -383,6 +407,27 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
             }
             if constexpr (O16) store_h8(out16, out16_lo, (int64_t)m * p.ldc16 + ncol, v, p.out_lo_fmt);
         });
+        if constexpr (GS) {
+            const int nA = min(8, (ncol / cpg + 1) * cpg - ncol);           // columns of this lane's chunk in its first group (even)
+            float sA = 0.0f, qA = 0.0f, sB = 0.0f, qB = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool a = 2 * k < nA;
+                sA += a ? gP[k] : 0.0f; qA += a ? gQ[k] : 0.0f;
+                sB += a ? 0.0f : gP[k]; qB += a ? 0.0f : gQ[k];
+            }
+#pragma unroll
+            for (int o = CPL; o < 64; o <<= 1) {
+                sA += __shfl_xor(sA, o, 64); qA += __shfl_xor(qA, o, 64);
+                sB += __shfl_xor(sB, o, 64); qB += __shfl_xor(qB, o, 64);
+            }
+            if (lane < CPL) {                   // rl == 0: this chunk's entry (row blocks i = 0 .. MI-1 add up in slab order)
+                f32x4* e = reinterpret_cast<f32x4*>(gs_tab + (jc * 4 + cl) * 4);
+                f32x4 t = *e;
+                t[0] += sA; t[1] += qA; t[2] += sB; t[3] += qB;
+                *e = t;
+            }
+        }
         if constexpr (LN) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every lane's rows are back in the slab
             static_for<cw>([&](auto j_) {
@@ -393,6 +438,25 @@ __device__ __forceinline__ void epi_fast(const PncGemmParams& p, f32x16 (&acc)[M
             });
         }
     });
+    if constexpr (GS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int m_first = rmap(0);
+        if (lane < (NI * 32) / cpg && m_first < p.M) {
+            const int c0 = (lane * cpg) >> 3, c1 = ((lane + 1) * cpg - 1) >> 3;
+            float S = 0.0f, Q = 0.0f;
+            for (int c = c0; c <= c1; ++c) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(gs_tab + c * 4);
+                const bool first = (c * 8) / cpg == lane;       // the chunk's first group is this one; else its second piece is
+                S += first ? t[0] : t[2];
+                Q += first ? t[1] : t[3];
+            }
+            const float n = (float)(MI * 32 * cpg);
+            const float mean = S / n;
+            const int f = m_first / p.Npix, chunk = (m_first - f * p.Npix) / (MI * 32), nrec = p.Npix / (MI * 32);
+            float* o = p.gn_part + ((int64_t)(f * nrec + chunk) * 32 + nw / cpg + lane) * 3;
+            o[0] = n; o[1] = mean; o[2] = fmaxf(Q - S * mean, 0.0f);
+        }
+    }
     if constexpr (LN) {
         __syncthreads();                      // both halves of every row have their statistics in LDS
         half_t* lnout = reinterpret_cast<half_t*>(p.ln_out16);
@@ -1029,7 +1093,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
                 float2* lnb = reinterpret_cast<float2*>(reinterpret_cast<float*>(smem) + NW * (32 * EPITCH));
                 epi_fast<MI, NI, EPI>(p, acc, ep, lane, RowLinear{mw}, nw, p.N, lnb + wave * 64, lnb + (wave ^ 1) * 64);
             } else {
-                epi_fast<MI, NI, (EPI & ~E_VT)>(p, acc, ep, lane, RowLinear{mw}, nw, (EPI & E_VT) ? p.n_split : p.N);   // E_GELU rides along
+                float* gs_tab = reinterpret_cast<float*>(smem) + NW * (32 * EPITCH) + wave * (NI * 16);
+                epi_fast<MI, NI, (EPI & ~E_VT)>(p, acc, ep, lane, RowLinear{mw}, nw, (EPI & E_VT) ? p.n_split : p.N, nullptr, nullptr,
+                                                (EPI & E_GS) ? gs_tab : nullptr);   // E_GELU rides along
             }
         }
     }

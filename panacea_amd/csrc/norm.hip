@@ -78,14 +78,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        int ppc, const float* __restrict__ partial,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu,
-                                                       half_t* __restrict__ y, int ldy, void* __restrict__ ylo, int lo_fmt) {
+                                                       half_t* __restrict__ y, int ldy, void* __restrict__ ylo, int lo_fmt, int nrec) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // A[C], B[C], then mean[32], rstd[32]
     const int tabw = 2 * C > 24 * GROUPS ? 2 * C : 24 * GROUPS;
     float* sA = sm;
     float* sB = sm + C;
     float* s_mean = sm + tabw;
     float* s_rstd = s_mean + GROUPS;
-    const int f = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int f = blockIdx.y, chunk = blockIdx.x, nchunk = nrec;       // records per frame (= the grid's chunks unless the caller says otherwise)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         // Chan-combine the chunk partials of this frame: 8 thread slices per group walk every 8th chunk (loads of a
@@ -421,8 +421,8 @@ extern "C" int pnc_groupnorm_stats(const float* x, int ldx, int F, int Npix, int
 extern "C" int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int C,
                                    int pix_per_chunk, const float* partial,
                                    const float* gamma, const float* beta, float eps, int silu,
-                                   void* y16, int ldy, void* y16_lo, int lo_fmt, void* stream) {
-    if (!x || !partial || !gamma || !beta || !y16 || F < 1 || Npix < 1 || pix_per_chunk < 1) return PNC_EINVAL;
+                                   void* y16, int ldy, void* y16_lo, int lo_fmt, int n_records, void* stream) {
+    if (!x || !partial || !gamma || !beta || !y16 || F < 1 || Npix < 1 || pix_per_chunk < 1 || n_records < 0) return PNC_EINVAL;
     if (lo_fmt != PNC_LO_F16 && lo_fmt != PNC_LO_E4M3) return PNC_EINVAL;
     if (C % 64 || C > GN_MAXC || ldx % 4 || ldy % 4) return PNC_EINVAL;
     if (((uintptr_t)x & 15) || (((uintptr_t)y16 | (uintptr_t)y16_lo) & 7)) return PNC_EALIGN;
@@ -431,7 +431,7 @@ extern "C" int pnc_groupnorm_apply(const float* x, int ldx, int F, int Npix, int
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     half_t* y = reinterpret_cast<half_t*>(y16);
     PNC_GN_DISPATCH(gn_apply_kernel, dim3(nchunk, F), dim3(256), lds, st, x, ldx, Npix, C, pix_per_chunk, partial,
-                    gamma, beta, eps, silu, y, ldy, y16_lo, lo_fmt);
+                    gamma, beta, eps, silu, y, ldy, y16_lo, lo_fmt, n_records > 0 ? n_records : nchunk);
     return pnc_launch_status();
 }
 

@@ -122,6 +122,7 @@ class Act:
     f32: Optional[torch.Tensor] = None
     f16: Optional[torch.Tensor] = None
     f16_lo: Optional[torch.Tensor] = None      # lo plane when f16 is a precise (split) operand
+    gn_part: Optional[torch.Tensor] = None     # GroupNorm(32) records of f32 when its producer wrote them (engine.gn_records)
 
     @property
     def N(self) -> int:
@@ -685,23 +686,37 @@ def _ppc(npix: int) -> int:
     return max(16, min(128, npix // 48), -(-npix // 256))
 
 
+GN_EPILOGUE_CHUNK = 64      # pixels per record of PncGemmParams.gn_part (the temporal conv's 64-row wave blocks)
+GN_FROM_EPILOGUE = True     # False (bench.py --no-gn-epilogue, A/B): every spatial GroupNorm launches its own statistics kernel
+
+
+def gn_records(rt: Runtime, F: int, N: int) -> Optional[torch.Tensor]:
+    """the record buffer a temporal conv fills for the GroupNorm of its output (`gemm(..., gn_part=)`, then `gn_spatial(..., part=)`)"""
+    if not GN_FROM_EPILOGUE:
+        return None
+    return rt.empty((F * (-(-N // GN_EPILOGUE_CHUNK)) * 32 * 3,), torch.float32)
+
+
 def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, beta, eps: float, silu: bool,
-               split: Optional[str] = None, tail_rows: int = 0):
+               split: Optional[str] = None, tail_rows: int = 0, part: Optional[torch.Tensor] = None):
     """-> (y16, y16_lo).  `split`: the operand class of the output ("gn_stt" | "gn_res" | "gn_head"); y16_lo is None unless the
     policy splits that class (precise operand for the consumer GEMM).  `tail_rows`: Runtime.empty's, for an output that feeds a
-    3x3 conv of a view band."""
+    3x3 conv of a view band.  `part`: the statistics records of x32 when its producer wrote them (`gn_records`): no statistics launch."""
     if C % 64:
         raise ValueError(f"GroupNorm(32) kernels need C % 64 == 0, got {C}")
     ppc = _ppc(N)
-    nchunk = (N + ppc - 1) // ppc
-    part = rt.empty((F * nchunk * 32 * 3,), torch.float32)
     y = rt.empty((F * N, C), torch.float16, tail_rows)
     ylo = rt.lo_plane((F * N, C), split, tail_rows=tail_rows) if split else None
-    # (launching the pair per Infinity-Cache sized panel of frames was measured: slower, profiles/round3/ab_two_wg_and_mall_panels_r3c.txt)
-    rt.be.groupnorm_stats(x32, C, F, N, C, ppc, part)
+    if part is None:
+        nrec = (N + ppc - 1) // ppc
+        part = rt.empty((F * nrec * 32 * 3,), torch.float32)
+        # (launching the pair per Infinity-Cache sized panel of frames was measured: slower, profiles/round3/ab_two_wg_and_mall_panels_r3c.txt)
+        rt.be.groupnorm_stats(x32, C, F, N, C, ppc, part)
+    else:
+        nrec = -(-N // GN_EPILOGUE_CHUNK)
     if rt.vshard is not None:           # statistics of the whole panorama, not of this rank's band of views
-        part = rt.vshard.combine_stats(part, F, nchunk, rt.be)
-    rt.be.groupnorm_apply(x32, C, F, N, C, ppc, part, gamma, beta, eps, silu, y, C, ylo)
+        part = rt.vshard.combine_stats(part, F, nrec, rt.be)
+    rt.be.groupnorm_apply(x32, C, F, N, C, ppc, part, gamma, beta, eps, silu, y, C, ylo, n_records=nrec)
     return y, ylo
 
 

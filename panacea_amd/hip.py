@@ -67,7 +67,7 @@ class GemmParams(C.Structure):
         ("ldln", C.c_int32), ("a_lo_fmt", C.c_int32),
         ("out_lo_fmt", C.c_int32), ("ldw_lo", C.c_int32),
         ("W_lo", C.c_void_p), ("w_lo_exp", C.c_int32), ("t_halo", C.c_int32),
-        ("x_halo_off", C.c_int64),
+        ("x_halo_off", C.c_int64), ("gn_part", C.c_void_p),
     ]
 
 
@@ -99,7 +99,7 @@ _SIGNATURES = {
     "pnc_softmax_rows_f16": (_I, [_P, _L, _I, _I, _F, _I, _I, _P, _L, _P]),
     "pnc_attn_temporal_f16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "pnc_groupnorm_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
-    "pnc_groupnorm_apply": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P, _I, _P]),
+    "pnc_groupnorm_apply": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _I, _P, _I, _I, _P]),
     "pnc_groupnorm_combine": (_I, [_P, _I, _I, _I, _P, _P]),
     "pnc_groupnorm_temporal_part": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P, _P, _I, _I, _P]),
     "pnc_groupnorm_temporal_silu": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _I, _P]),
@@ -170,6 +170,7 @@ def load():
 OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA, OPT_GEMM_FUSE_LN, OPT_GEMM_GROUP_M, OPT_STENCIL_TILES = 0, 1, 2, 3, 4, 5, 6
 OPT_GEMM_PERSIST = 7
 OPT_ATTN_DEFER_MAX = 8
+OPT_GEMM_GN_STATS = 9
 
 
 def build_digest() -> str:
@@ -179,7 +180,7 @@ def build_digest() -> str:
 
 def set_option(option: int, value: int) -> int:
     """pnc_set_option: process-global tuning / test switch of the library; returns the previous value."""
-    if not 0 <= option <= OPT_ATTN_DEFER_MAX:
+    if not 0 <= option <= OPT_GEMM_GN_STATS:
         raise PncError(f"unknown library option {option}")
     return load().pnc_set_option(option, value)
 
@@ -265,8 +266,10 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
          a16_lo: Optional[torch.Tensor] = None, out16_lo: Optional[torch.Tensor] = None, w_ld: int = 0,
          w_lo: Optional[tuple] = None,
          ln_gamma: Optional[torch.Tensor] = None, ln_beta: Optional[torch.Tensor] = None,
-         ln_out16: Optional[torch.Tensor] = None, ldln: int = 0, ln_eps: float = 1e-5, ln_in_library: bool = False):
-    """`a16_lo` / `out16_lo`: lo planes of precise (split) operands, see PncGemmParams.A_lo in the header; their dtype names the
+         ln_out16: Optional[torch.Tensor] = None, ldln: int = 0, ln_eps: float = 1e-5, ln_in_library: bool = False,
+         gn_part: Optional[torch.Tensor] = None):
+    """`gn_part` (temporal conv only): receives the GroupNorm(32) records of the fp32 output, ceil(Npix / 64) per frame
+    (PncGemmParams.gn_part).  `a16_lo` / `out16_lo`: lo planes of precise (split) operands, see PncGemmParams.A_lo in the header; their dtype names the
     format (fp16, or uint8 = e4m3 bytes).  `w_lo` = (W_lo e4m3 bytes [N, K], w_lo_exp E8M0 byte of the tensor) — engine.pk_lo8 —
     is the weight side of an e4m3 lo pass."""
     p = GemmParams()
@@ -294,6 +297,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
     if tconv:
         p.Cin, p.T, p.Npix = tconv["C"], tconv["T"], tconv["Npix"]
         p.t_halo = int(tconv.get("halo", 0))
+    p.gn_part = _ptr(gn_part, f32, "gn_part")
     p.bias, p.rowbias, p.rb_rows, p.rb_mod = _ptr(bias, f32, "bias"), _ptr(rowbias, f32, "rowbias"), rb_rows, rb_mod
     p.res1, p.ldr1, p.res2, p.ldr2 = _ptr(res1, f32, "res1"), ldr1, _ptr(res2, f32, "res2"), ldr2
     p.out32, p.ldc32, p.out16, p.ldc16 = _ptr(out32, f32, "out32"), ldc32, _ptr(out16, f16, "out16"), ldc16
@@ -360,11 +364,11 @@ def groupnorm_combine(parts_in, parts, F, nchunk, out):
     _check(load().pnc_groupnorm_combine(_ptr(parts_in), parts, F, nchunk, _ptr(out), _stream()), "pnc_groupnorm_combine")
 
 
-def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy, y16_lo=None):
+def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy, y16_lo=None, n_records=0):
     nb = (6.0 + _lo_bytes(y16_lo)) * F * Npix * Cch
     _check(_timed("groupnorm", 0.0, nb, load().pnc_groupnorm_apply, _ptr(x32), ldx, F, Npix, Cch,
                   ppc, _ptr(partial), _ptr(gamma), _ptr(beta), eps, int(silu), _ptr(y16), ldy, _ptr(y16_lo), lo_fmt(y16_lo),
-                  _stream()),
+                  int(n_records), _stream()),
            "pnc_groupnorm_apply")
 
 

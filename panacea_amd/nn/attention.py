@@ -378,7 +378,8 @@ class SpatialTemporalTransformer(nn.Module, Packable):
         pk = self.packed()
         C, M = x.C, x.M
         n16, n16lo = E.gn_spatial(rt, x.f32, x.F, x.N, C, pk["g" + sfx], pk["b" + sfx], 1e-6, False,
-                                  split="gn_stt")
+                                  split="gn_stt", part=x.gn_part)
+        x.gn_part = None             # (the branches update x.f32 in place: the producer's records describe the first branch's input only)
         sh = rt.shard if branch == "temporal" else None
         if sh is not None:
             # Frame-sharded run: the temporal branch is pointwise per pixel (LN, projections, text cross-attention, FF) or

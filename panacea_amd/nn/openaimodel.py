@@ -109,7 +109,8 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock, Packable):
             nxt = layers[i + 1] if i + 1 < len(layers) else None
             wf = want_f16 if nxt is None else isinstance(nxt, (Upsample, Downsample, nn.Conv2d))
             if isinstance(layer, ResBlock3D):
-                x = layer._run(rt, x, emb32, want_f16=wf)
+                # (want_stats: the next layer starts with a spatial GroupNorm of this block's output)
+                x = layer._run(rt, x, emb32, want_f16=wf, want_stats=isinstance(nxt, (ResBlock3D, SpatialTemporalTransformer)))
             elif isinstance(layer, SpatialTemporalTransformer):
                 x = layer._run(rt, x, want_f16=wf)
             elif isinstance(layer, (Upsample, Downsample)):
@@ -227,7 +228,7 @@ class ResBlock3D(TimestepBlock, Packable):
             pk["ws"], pk["bs"] = E.pk_linear(self.skip_connection.weight), f32(self.skip_connection.bias)
         return pk
 
-    def _run(self, rt: Runtime, x: Act, emb32: torch.Tensor, want_f16: bool = False) -> Act:
+    def _run(self, rt: Runtime, x: Act, emb32: torch.Tensor, want_f16: bool = False, want_stats: bool = False) -> Act:
         if rt.T != self.num_frames:
             raise ValueError(f"runtime has {rt.T} frames per sample, block was built for {self.num_frames}")
         pk = self.packed()
@@ -242,7 +243,7 @@ class ResBlock3D(TimestepBlock, Packable):
         tconv = dict(C=Co, T=rt.T, Npix=Nt)
         # in_layers: GN + SiLU + conv3x3
         tail = 2 * F * x.H if rt.vshard is not None else 0      # room for a view band's neighbour columns (_conv3x3_view_band)
-        a16, a16lo = E.gn_spatial(rt, x.f32, F, N, Cin, pk["g1"], pk["b1"], 1e-5, True, split="gn_res", tail_rows=tail)
+        a16, a16lo = E.gn_spatial(rt, x.f32, F, N, Cin, pk["g1"], pk["b1"], 1e-5, True, split="gn_res", tail_rows=tail, part=x.gn_part)
         h = run_conv3x3(rt, a16, F, H, W, Cin, pk["w1"], pk["c1"], Co, x16_lo=a16lo).f32
         # h = h + conv1d_t(SiLU(GN_t(h))) + emb_layers(emb)[frame]      (:505-531)
         # emb32 arrives as SiLU(emb): the activation of `emb_layers` is applied ONCE per network evaluation by
@@ -256,9 +257,10 @@ class ResBlock3D(TimestepBlock, Packable):
             emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
             t16, t16lo = E.gn_temporal_sharded(rt, sh, h, N, Co, pk["gt1"], pk["bt1"], 1e-5)
             tch = dict(C=Co, T=rt.T_local, Npix=N, halo=1)
+            part1 = E.gn_records(rt, F, N)
             rt.be.gemm(t16, pk["wt1"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tch, bias=pk["ct1"],
                        rowbias=emb_out, rb_rows=N, rb_mod=F, res1=h, ldr1=Co, out32=h, ldc32=Co, a16_lo=t16lo,
-                       w_lo=E.wlo(pk, "wt1", t16lo))
+                       w_lo=E.wlo(pk, "wt1", t16lo), gn_part=part1)
         elif sh is not None:
             # (round 2's form, FrameShard(resblock="transpose"): the fp32 stream to the pixel sharding and back)
             # the exchange runs on the communicator's stream; what this site computes independently of it — the timestep
@@ -271,13 +273,15 @@ class ResBlock3D(TimestepBlock, Packable):
             emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
         if not halo:
             t16, t16lo = E.gn_temporal(rt, h, Nt, Co, pk["gt1"], pk["bt1"], 1e-5)
+            # the GroupNorm of out_layers reads what this conv writes: its statistics come out of the conv's epilogue (frame layout only)
+            part1 = E.gn_records(rt, F, N) if sh is None else None
             rt.be.gemm(t16, pk["wt1"], M=Mt, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tconv, bias=pk["ct1"],
                        rowbias=emb_out, rb_rows=Nt, rb_mod=rt.B * rt.T, res1=h, ldr1=Co, out32=h, ldc32=Co, a16_lo=t16lo,
-                       w_lo=E.wlo(pk, "wt1", t16lo))
+                       w_lo=E.wlo(pk, "wt1", t16lo), gn_part=part1)
             if sh is not None:
                 h = sh.to_frames(h, rt.B, N)
         # out_layers: GN + SiLU + conv3x3
-        a16, a16lo = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True, split="gn_res", tail_rows=tail)
+        a16, a16lo = E.gn_spatial(rt, h, F, N, Co, pk["g2"], pk["b2"], 1e-5, True, split="gn_res", tail_rows=tail, part=part1)
         g = run_conv3x3(rt, a16, F, H, W, Co, pk["w2"], pk["c2"], Co, x16_lo=a16lo).f32
         # skip path
         if s is None:
@@ -285,6 +289,7 @@ class ResBlock3D(TimestepBlock, Packable):
         # return skip(x) + (g + conv1d_t(SiLU(GN_t(g))))                 (:533-542)
         o16 = rt.empty((M, Co), torch.float16) if want_f16 else None
         o16lo = rt.lo_plane((M, Co), "stream", on=want_f16)
+        part2 = None
         if sh is None or halo:
             if halo:
                 t16, t16lo = E.gn_temporal_sharded(rt, sh, g, N, Co, pk["gt2"], pk["bt2"], 1e-5)
@@ -292,9 +297,11 @@ class ResBlock3D(TimestepBlock, Packable):
             else:
                 t16, t16lo = E.gn_temporal(rt, g, N, Co, pk["gt2"], pk["bt2"], 1e-5)
                 tc2 = tconv
+            # ... and so do the statistics of the block's output, for the GroupNorm the next layer starts with
+            part2 = E.gn_records(rt, F, N) if want_stats else None
             rt.be.gemm(t16, pk["wt2"], M=M, N=Co, K=3 * Co, a_mode=hip.A_CONV1D_T, tconv=tc2, bias=pk["ct2"],
                        res1=g, ldr1=Co, res2=s, ldr2=Co, out32=g, ldc32=Co, out16=o16, ldc16=Co, a16_lo=t16lo,
-                       out16_lo=o16lo, w_lo=E.wlo(pk, "wt2", t16lo))
+                       out16_lo=o16lo, w_lo=E.wlo(pk, "wt2", t16lo), gn_part=part2)
         else:
             # the skip path stays in the frame layout: g + conv1d in the pixel layout, exchange back, then + skip
             gp = sh.to_pixels(g, rt.B, N)
@@ -303,7 +310,7 @@ class ResBlock3D(TimestepBlock, Packable):
                        res1=gp, ldr1=Co, out32=gp, ldc32=Co, a16_lo=t16lo, w_lo=E.wlo(pk, "wt2", t16lo))
             g = sh.to_frames(gp, rt.B, N)
             rt.be.add_f32(g, s, M * Co, g, o16, o16lo)
-        return Act(F, H, W, Co, f32=g, f16=o16, f16_lo=o16lo)
+        return Act(F, H, W, Co, f32=g, f16=o16, f16_lo=o16lo, gn_part=part2)
 
     def _skip(self, rt: Runtime, x: Act, pk: dict) -> torch.Tensor:
         """skip_connection(x): the 1x1 conv where the channel count changes (openaimodel.py:486), else x itself"""
@@ -581,6 +588,7 @@ class UNetModel3D(nn.Module, Packable):
         if control is not None:
             c = control.pop()
             rt.be.add_f32(h.f32, c.f32, h.M * h.C, h.f32, None)                       # h += control.pop()
+            h.gn_part = None                                                           # (statistics of the old values)
         for i, module in enumerate(self.output_blocks):
             s = hs.pop()
             c = control.pop() if control is not None else None

@@ -141,7 +141,7 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
          rb_rows=0, rb_mod=0, res1=None, ldr1=0, res2=None, ldr2=0, out32=None, ldc32=0, out16=None,
          ldc16=0, out16t=None, ldt=0, t_rows=0, t_gstride=0, n_split=0, act=ACT_NONE, geglu=False,
          a16_lo=None, out16_lo=None, w_ld=0, ln_gamma=None, ln_beta=None, ln_out16=None, ldln=0, ln_eps=1e-5,
-         ln_in_library=False, w_lo=None):
+         ln_in_library=False, w_lo=None, gn_part=None):
     assert (not STRICT_DTYPES) or (a16.dtype == torch.float16 and w16.dtype == torch.float16)
     assert K % 8 == 0
     Wm = _mat(w16, N, K, w_ld or K).float()
@@ -199,6 +199,9 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
     if ln_out16 is not None:
         assert out32 is not None and out16t is None
         layernorm(out32, ldc32, M, N, ln_gamma, ln_beta, ln_eps, ln_out16, ldln)
+    if gn_part is not None:      # PncGemmParams.gn_part: the records pnc_groupnorm_stats writes for 64-pixel chunks
+        assert a_mode == A_CONV1D_T and out32 is not None and N % 64 == 0
+        groupnorm_stats(out32, ldc32, M // tconv["Npix"], tconv["Npix"], N, 64, gn_part)
     if out16t is not None:
         G = M // t_rows
         assert G * t_rows == M
@@ -297,8 +300,8 @@ def groupnorm_combine(parts_in, parts, F, nchunk, out):
     O[:, 0] = torch.stack([n, mean, m2], dim=-1).to(O.dtype)
 
 
-def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy, y16_lo=None):
-    nchunk = (Npix + ppc - 1) // ppc
+def groupnorm_apply(x32, ldx, F, Npix, Cch, ppc, partial, gamma, beta, eps, silu, y16, ldy, y16_lo=None, n_records=0):
+    nchunk = n_records or (Npix + ppc - 1) // ppc
     P = partial.reshape(-1)[: F * nchunk * 32 * 3].view(F, nchunk, 32, 3).double()
     n = P[..., 0].sum(1)
     mean = (P[..., 0] * P[..., 1]).sum(1) / n

@@ -1,5 +1,6 @@
 """Shared test helpers: build the product network with deterministic synthetic weights, load golden
 vectors, compare with the oracle."""
+import contextlib
 import json
 from pathlib import Path
 
@@ -53,6 +54,20 @@ def err_stats(got: torch.Tensor, ref) -> dict:
     d = (got.detach().float().cpu() - ref).abs()
     return dict(max_abs=d.max().item(), mean_abs=d.mean().item(), ref_rms=ref.pow(2).mean().sqrt().item(),
                 ref_max=ref.abs().max().item())
+
+
+@contextlib.contextmanager
+def gn_statistics_from_launches():
+    """Every spatial GroupNorm with its own statistics launch (engine.GN_FROM_EPILOGUE off): the form in which a run that only MOVES
+    data (round 2's transposed frame shard) must reproduce the unsharded bits — by default the unsharded ResBlock3D takes two of
+    its GroupNorms' statistics from the temporal convs' epilogues, the transposed one cannot (other fp32 summation order)."""
+    from panacea_amd import engine as E
+    prev = E.GN_FROM_EPILOGUE
+    E.GN_FROM_EPILOGUE = False
+    try:
+        yield
+    finally:
+        E.GN_FROM_EPILOGUE = prev
 
 
 def measured(tag: str, **values):

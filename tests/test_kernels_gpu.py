@@ -363,6 +363,83 @@ def test_gemm_conv1d_temporal_halo_layout(B, Tl, Npix, C, lo8):
     assert torch.equal(plain.view(B, Tl, Npix, N), full.view(B, Tl + 2, Npix, N)[:, 1:Tl + 1])
 
 
+@pytest.mark.parametrize("B,T,Npix,C,epi,lo8", [
+    (2, 8, 12288, 320, "rb", True),        # level 0: 10 channels per group, chunks of 8 columns straddle the groups
+    (2, 8, 3072, 640, "r2", True),         # level 1: 20 per group, 384 tiles = a full round + tail-split tiles (quarter workgroups)
+    (2, 8, 768, 1280, "r2+o16", False),    # level 2: 40 per group (256-column tiles are chosen here: the statistics launch follows)
+    (2, 8, 192, 1280, "rb", True),         # level 3: 192 pixels per frame, small tiles: the statistics launch follows
+    (1, 4, 1024, 320, "r2+o16", False),
+    (1, 2, 640, 640, "rb", False),         # 640 pixels = 2.5 tiles per frame: a tile's wave blocks belong to two frames
+])
+def test_gemm_conv1d_groupnorm_records_from_the_epilogue(B, T, Npix, C, epi, lo8):
+    """PncGemmParams.gn_part (round 4): the temporal conv writes the GroupNorm(32) records of its fp32 output — one {n, mean, M2}
+    per (64-pixel block, group) — out of its epilogue.  The output is unchanged to the bit; the records combine to the statistics
+    pnc_groupnorm_stats computes from the output (and feed pnc_groupnorm_apply through n_records); they are bit-reproducible; and
+    with PNC_OPT_GEMM_GN_STATS = 0 the library's trailing statistics launch fills the same buffer."""
+    from panacea_amd import engine
+    M, N, K = B * T * Npix, C, 3 * C
+    x32 = rnd(M, C, seed=81)
+    x = x32.half()
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=82)
+    bias, emb = rnd(N, seed=83), rnd(B * T, N, seed=84)
+    res, skip = rnd(M, N, seed=85) * 2.0 + 0.5, rnd(M, N, seed=86)
+    kw = dict(a16=x, w16=w, M=M, N=N, K=K, a_mode=hip.A_CONV1D_T, tconv=dict(C=C, T=T, Npix=Npix), bias=bias, ldr1=N, ldc32=N)
+    if lo8:
+        xlo = torch.zeros(M, C, device=DEV, dtype=torch.uint8)
+        hip.cast_f16(x32, x32.numel(), torch.zeros_like(x), xlo)
+        kw.update(a16_lo=xlo, w_lo=engine.pk_lo8(w))
+    if epi == "rb":
+        kw.update(rowbias=emb, rb_rows=Npix, rb_mod=B * T)
+    else:
+        kw.update(res2=skip, ldr2=N)
+    o16 = torch.zeros(M, N, device=DEV, dtype=torch.float16) if "o16" in epi else None
+    if o16 is not None:
+        kw.update(out16=o16, ldc16=N)
+    F, nrec = B * T, -(-Npix // 64)
+
+    def run(opt, with_part):
+        prev = hip.set_option(hip.OPT_GEMM_GN_STATS, opt)
+        try:
+            out = res.clone()
+            part = torch.full((F * nrec * 96,), float("nan"), device=DEV) if with_part else None
+            hip.gemm(res1=out, out32=out, gn_part=part, **kw)
+            torch.cuda.synchronize()
+        finally:
+            hip.set_option(hip.OPT_GEMM_GN_STATS, prev)
+        return out, part
+    plain, _ = run(1, False)
+    fused, part = run(1, True)
+    again, part2 = run(1, True)
+    trail, part_t = run(0, True)
+    assert torch.equal(fused, plain) and torch.equal(trail, plain)                 # the output does not know about the records
+    assert torch.equal(part, part2)                                               # fixed summation order
+    assert torch.isfinite(part).all() and torch.isfinite(part_t).all()
+    # the records against float64 statistics of the output, per (frame, 64-pixel block, group)
+    blk = plain.double().view(F, Npix, 32, C // 32)
+    P = part.view(F, nrec, 32, 3).double()
+    for r in sorted({0, 1, 2, nrec // 2, nrec - 2, nrec - 1} & set(range(nrec))):
+        v = blk[:, r * 64:(r + 1) * 64]
+        n = v.shape[1] * (C // 32)
+        assert torch.equal(P[:, r, :, 0], torch.full((F, 32), float(n), device=DEV, dtype=torch.float64))
+        mean, m2 = v.mean(dim=(1, 3)), v.var(dim=(1, 3), unbiased=False) * n
+        assert (P[:, r, :, 1] - mean).abs().max().item() <= 2e-6 * (1 + mean.abs().max().item()), r
+        assert ((P[:, r, :, 2] - m2).abs() / m2).max().item() <= 2e-4, r
+    Pt = part_t.view(F, nrec, 32, 3).double()
+    assert (P[..., 1] - Pt[..., 1]).abs().max().item() <= 4e-6 * (1 + Pt[..., 1].abs().max().item())
+    assert ((P[..., 2] - Pt[..., 2]).abs() / Pt[..., 2]).max().item() <= 4e-4
+    # ... and through the apply kernel: same normalised operand as the two-launch GroupNorm of the output (fp16 roundings may flip)
+    gamma, beta = rnd(C, seed=87) * 0.2 + 1.0, rnd(C, seed=88) * 0.1
+    y_ep, y_ref = torch.zeros(M, C, device=DEV, dtype=torch.float16), torch.zeros(M, C, device=DEV, dtype=torch.float16)
+    ppc = engine._ppc(Npix)
+    hip.groupnorm_apply(plain, C, F, Npix, C, ppc, part, gamma, beta, 1e-5, True, y_ep, C, n_records=nrec)
+    pr = torch.zeros(F * (-(-Npix // ppc)) * 96, device=DEV)
+    hip.groupnorm_stats(plain, C, F, Npix, C, ppc, pr)
+    hip.groupnorm_apply(plain, C, F, Npix, C, ppc, pr, gamma, beta, 1e-5, True, y_ref, C)
+    torch.cuda.synchronize()
+    check("GroupNorm from the epilogue's records", y_ep, y_ref, 2e-3, 2e-3)
+    assert (y_ep != y_ref).float().mean().item() < 2e-2
+
+
 @pytest.mark.parametrize("B,T,Tl,Npix,C,lo8", [(2, 8, 2, 96, 64, False), (1, 4, 4, 77, 320, True), (2, 8, 4, 64, 1280, True), (1, 2, 1, 40, 128, False)])
 def test_groupnorm_temporal_in_parts(B, T, Tl, Npix, C, lo8):
     """pnc_groupnorm_temporal_part (round 4): the T frames of a pixel on T / Tl ranks — every rank's partial {sum, sum of squares}

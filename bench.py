@@ -367,6 +367,8 @@ def main():
                     help="A/B: PNC_OPT_STENCIL_TILES (0 = one gathered A tile per tap everywhere, 1 = default, 2 = halo tiles wherever the shape allows)")
     ap.add_argument("--gemm-group-m", type=int, default=0,
                     help="A/B: PNC_OPT_GEMM_GROUP_M (0 = auto, 1 = plain tile order, k = groups of k row panels); same result")
+    ap.add_argument("--upsample-plain-operand", action="store_true",
+                    help="A/B of the error budget: the Upsample convs read the fp16 plane of their operand only (no e4m3 lo pass)")
     ap.add_argument("--no-gn-epilogue", action="store_true",
                     help="A/B: GroupNorm statistics from their own launches instead of the temporal convs' epilogues")
     ap.add_argument("--no-modes", action="store_true", help="do not time the other operand policy (profiling runs)")
@@ -426,6 +428,9 @@ def main():
         hip.set_option(hip.OPT_STENCIL_TILES, args.stencil_tiles)
     if args.gemm_group_m:
         hip.set_option(hip.OPT_GEMM_GROUP_M, args.gemm_group_m)
+    if args.upsample_plain_operand:
+        from panacea_amd.nn import openaimodel as _om
+        _om.Upsample.precise_operand = False
     if args.no_gn_epilogue:
         from panacea_amd import engine as _eng
         _eng.GN_FROM_EPILOGUE = False

@@ -151,11 +151,16 @@ class Upsample(nn.Module, Packable):
         w, b = conv_params(self.conv)
         return dict(w=w, b=b)
 
+    # the conv's operand as a precise pair (class `stream`).  False (bench.py --upsample-plain-operand, an A/B of the error budget):
+    # the three Upsample convs of the UNet decoder read the fp16 plane only — their e4m3 lo pass is 1.6 ms of the step
+    precise_operand = True
+
     def _run(self, rt: Runtime, x: Act, want_f16=False) -> Act:
         pk = self.packed()
         x16 = x.need_f16(rt)
+        lo = x.f16_lo if self.precise_operand else None
         return run_conv3x3(rt, x16, x.F, x.H, x.W, x.C, pk["w"], pk["b"], self.out_channels,
-                           upsample=True, out16=want_f16, x16_lo=x.f16_lo, split_out="stream", w_lo=E.wlo(pk, "w", x.f16_lo))
+                           upsample=True, out16=want_f16, x16_lo=lo, split_out="stream", w_lo=E.wlo(pk, "w", lo))
 
 
 class Downsample(nn.Module, Packable):

@@ -15,6 +15,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+if os.environ.get("PNC_UPSAMPLE_PLAIN"):       # error-budget A/B (tools/runs/r4t.sh): the Upsample convs without their lo pass
+    from panacea_amd.nn import openaimodel as _om
+    _om.Upsample.precise_operand = False
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():

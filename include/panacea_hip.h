@@ -200,9 +200,8 @@ typedef struct PncGemmParams {
      * taps that leave the band on the left / right read it instead of zero padding; rows above / below the image stay padded.
      * Band, block and everything between them must lie within 2^31 bytes of each frame's origin. */
     int64_t x_halo_off;
-    /* PNC_A_CONV1D_T and PNC_A_PLAIN (the latter with Npix = rows per frame set by the caller): GroupNorm(32) statistics of the fp32
-     * output, from the GEMM (util.py:276-283, attention.py:129-132: the GroupNorm that follows every temporal conv of a ResBlock3D
-     * and every proj_out of an STT branch reads what this launch writes).  NULL = off; otherwise [frames][ceil(Npix / 64)][32][3]
+    /* PNC_A_CONV1D_T: GroupNorm(32) statistics of the fp32 output, from the GEMM (util.py:276-283: the GroupNorm that follows
+     * every temporal conv of a ResBlock3D reads what this launch writes).  NULL = off; otherwise [frames][ceil(Npix / 64)][32][3]
      * floats that receive the {n, mean, M2} records pnc_groupnorm_stats(out32, ldc32, frames, Npix, N, 64, gn_part) would
      * write — frames = M / Npix, channels = N — for pnc_groupnorm_apply(..., n_records = ceil(Npix / 64)).  When a workgroup's
      * waves own whole groups (N % 320 == 0 on the 256x320 tile, Npix % 64 == 0) the records come out of the epilogue, one per

@@ -177,8 +177,7 @@ static int validate(const PncGemmParams& p) {
         return PNC_EINVAL;
     }
     if (p.a_mode != PNC_A_CONV3X3 && p.x_halo_off) return PNC_EINVAL;
-    if (p.gn_part && (p.a_mode == PNC_A_CONV3X3 || !p.out32 || (p.N % 64) || (p.ldc32 % 4) || p.out16t || p.geglu || p.ln_out16 ||
-                      p.Npix <= 0 || (p.M % p.Npix))) return PNC_EINVAL;
+    if (p.gn_part && (p.a_mode != PNC_A_CONV1D_T || !p.out32 || (p.N % 64) || (p.ldc32 % 4) || p.out16t || p.geglu)) return PNC_EINVAL;
     if (p.act != PNC_ACT_NONE && p.act != PNC_ACT_SILU && p.act != PNC_ACT_GELU) return PNC_EINVAL;
     if (p.ldw != 0 && (p.ldw < p.K || p.ldw % 8)) return PNC_EALIGN;
     if (p.rowbias && (p.rb_rows <= 0 || p.rb_mod <= 0)) return PNC_EINVAL;

@@ -1894,14 +1894,6 @@ static inline bool ln_whole_rows(const PncGemmParams& p, TileChoice tc) {
 }
 
 // launch the variant EPI of AMODE on the chosen tile
-// PncGemmParams.gn_part out of the epilogue (E_GS): the 256x320 tile's waves (64 rows x 160 columns) own whole groups of N/32 = 10,
-// 20 or 40 channels, their 64 rows are pixels of one frame, every row and column of a tile exists, K is not split
-static inline bool gn_stats_in_epilogue(const PncGemmParams& p, const TileChoice& tc) {
-    const int cpg = p.N / 32;
-    return tc.tile == T_256x320 && tc.ksplit <= 1 && (p.N % 320) == 0 && (160 % cpg) == 0 && (cpg % 2) == 0 && p.Npix > 0 &&
-           (p.Npix % 64) == 0 && (p.M % 64) == 0 && pnc_get_option(PNC_OPT_GEMM_GN_STATS) != 0;
-}
-
 template <int AMODE, unsigned EPI>
 int launch_tile(const PncGemmParams& p, hipStream_t st, TileChoice tc) {
     constexpr bool GEGLU = (EPI & E_GEGLU) != 0;

@@ -14,26 +14,6 @@ static int launch_ln(const PncGemmParams& p, hipStream_t st, TileChoice tc) {
 int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st, bool* ln_fused) {
     constexpr int AM = PNC_A_PLAIN;
     const TileChoice tc = choose_tile(p);
-    if (p.gn_part) {
-        // proj_out + residual of an STT branch: the next branch starts with a GroupNorm of this output.  The statistics come out of the
-        // one-tile-per-workgroup kernel's epilogue (level 0 leaves the persistent kernel for it: 1.5-4 % of a launch against a whole
-        // statistics launch); otherwise from the statistics kernel, launched here
-        int rc = PNC_EINVAL;
-        bool fused = gn_stats_in_epilogue(p, tc);
-        if (fused) {
-            switch (epi) {
-                case E_R1 | E_O32: rc = launch<AM, 256, 320, 4, 2, 2, false, E_R1 | E_O32 | E_GS>(p, st); break;
-                case E_R1 | E_O32 | E_O16: rc = launch<AM, 256, 320, 4, 2, 2, false, E_R1 | E_O32 | E_O16 | E_GS>(p, st); break;
-                default: fused = false;
-            }
-        }
-        if (fused) return rc;
-        PncGemmParams q = p;
-        q.gn_part = nullptr;
-        rc = dispatch_plain(q, epi, st, ln_fused);
-        if (rc != PNC_OK) return rc;
-        return pnc_groupnorm_stats(p.out32, p.ldc32, p.M / p.Npix, p.Npix, p.N, 64, p.gn_part, st);
-    }
     if (epi & E_LN) {
         // fuse only when ONE column tile covers the row (level-0 width 320 on 256x320; <= 128 on 128x128)
         if (ln_whole_rows(p, tc)) *ln_fused = true;

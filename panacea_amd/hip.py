@@ -267,9 +267,9 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
          w_lo: Optional[tuple] = None,
          ln_gamma: Optional[torch.Tensor] = None, ln_beta: Optional[torch.Tensor] = None,
          ln_out16: Optional[torch.Tensor] = None, ldln: int = 0, ln_eps: float = 1e-5, ln_in_library: bool = False,
-         gn_part: Optional[torch.Tensor] = None, gn_npix: int = 0):
-    """`gn_part` (temporal conv; plain A with `gn_npix` = rows per frame): receives the GroupNorm(32) records of the fp32 output,
-    ceil(Npix / 64) per frame (PncGemmParams.gn_part).  `a16_lo` / `out16_lo`: lo planes of precise (split) operands, see PncGemmParams.A_lo in the header; their dtype names the
+         gn_part: Optional[torch.Tensor] = None):
+    """`gn_part` (temporal conv only): receives the GroupNorm(32) records of the fp32 output, ceil(Npix / 64) per frame
+    (PncGemmParams.gn_part).  `a16_lo` / `out16_lo`: lo planes of precise (split) operands, see PncGemmParams.A_lo in the header; their dtype names the
     format (fp16, or uint8 = e4m3 bytes).  `w_lo` = (W_lo e4m3 bytes [N, K], w_lo_exp E8M0 byte of the tensor) — engine.pk_lo8 —
     is the weight side of an e4m3 lo pass."""
     p = GemmParams()
@@ -298,8 +298,6 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
         p.Cin, p.T, p.Npix = tconv["C"], tconv["T"], tconv["Npix"]
         p.t_halo = int(tconv.get("halo", 0))
     p.gn_part = _ptr(gn_part, f32, "gn_part")
-    if gn_part is not None and a_mode == A_PLAIN:
-        p.Npix = int(gn_npix)
     p.bias, p.rowbias, p.rb_rows, p.rb_mod = _ptr(bias, f32, "bias"), _ptr(rowbias, f32, "rowbias"), rb_rows, rb_mod
     p.res1, p.ldr1, p.res2, p.ldr2 = _ptr(res1, f32, "res1"), ldr1, _ptr(res2, f32, "res2"), ldr2
     p.out32, p.ldc32, p.out16, p.ldc16 = _ptr(out32, f32, "out32"), ldc32, _ptr(out16, f16, "out16"), ldc16

@@ -374,7 +374,7 @@ class SpatialTemporalTransformer(nn.Module, Packable):
         pk["pos"] = E.temporal_pos_table(self.num_frames, self.inner_dim).to(self.proj_in.weight.device)
         return pk
 
-    def _branch(self, rt: Runtime, x: Act, sfx: str, blocks, branch: str, out16=None, out16_lo=None, want_stats=False):
+    def _branch(self, rt: Runtime, x: Act, sfx: str, blocks, branch: str, out16=None, out16_lo=None):
         pk = self.packed()
         C, M = x.C, x.M
         n16, n16lo = E.gn_spatial(rt, x.f32, x.F, x.N, C, pk["g" + sfx], pk["b" + sfx], 1e-6, False,
@@ -408,24 +408,21 @@ class SpatialTemporalTransformer(nn.Module, Packable):
         if sh is not None:
             p16 = sh.to_frames(p16, rt.B, x.N)
             p16lo = sh.to_frames(p16lo, rt.B, x.N) if p16lo is not None else None
-        # x = proj_out(t) + x_in, in place on the stream; `want_stats`: a GroupNorm reads x next (the following branch, or the layer
-        # behind the STT) — its statistics come out of this GEMM (PncGemmParams.gn_part)
-        part = E.gn_records(rt, x.F, x.N) if want_stats else None
+        # x = proj_out(t) + x_in, in place on the stream
         rt.be.gemm(p16, pk["wo" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bo" + sfx], res1=x.f32, ldr1=C,
                    out32=x.f32, ldc32=C, out16=out16, ldc16=C, a16_lo=p16lo, out16_lo=out16_lo,
-                   w_lo=E.wlo(pk, "wo" + sfx, p16lo), gn_part=part, gn_npix=x.N)
-        x.gn_part = part
+                   w_lo=E.wlo(pk, "wo" + sfx, p16lo))
 
-    def _run(self, rt: Runtime, x: Act, want_f16: bool = False, want_stats: bool = False) -> Act:
+    def _run(self, rt: Runtime, x: Act, want_f16: bool = False) -> Act:
         if rt.T != self.num_frames:
             raise ValueError(f"runtime has {rt.T} frames per sample, module was built for {self.num_frames}")
-        self._branch(rt, x, "", self.transformer_blocks, "spatial", want_stats=True)
+        self._branch(rt, x, "", self.transformer_blocks, "spatial")
         if self.insert_crossview:
-            self._branch(rt, x, "_crossview", self.transformer_blocks_crossview, "crossview", want_stats=True)
+            self._branch(rt, x, "_crossview", self.transformer_blocks_crossview, "crossview")
         out16 = rt.empty((x.M, x.C), torch.float16) if want_f16 else None
         out16lo = rt.lo_plane((x.M, x.C), "stream", on=want_f16)
-        self._branch(rt, x, "_temporal", self.transformer_blocks_temporal, "temporal", out16=out16, out16_lo=out16lo, want_stats=want_stats)
-        return Act(x.F, x.H, x.W, x.C, f32=x.f32, f16=out16, f16_lo=out16lo, gn_part=x.gn_part)
+        self._branch(rt, x, "_temporal", self.transformer_blocks_temporal, "temporal", out16=out16, out16_lo=out16lo)
+        return Act(x.F, x.H, x.W, x.C, f32=x.f32, f16=out16, f16_lo=out16lo)
 
     precision = "precise"      # operand policy of the reference-compatible entry below (the network sets rt.prec itself)
 

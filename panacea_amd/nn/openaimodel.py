@@ -112,7 +112,7 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock, Packable):
                 # (want_stats: the next layer starts with a spatial GroupNorm of this block's output)
                 x = layer._run(rt, x, emb32, want_f16=wf, want_stats=isinstance(nxt, (ResBlock3D, SpatialTemporalTransformer)))
             elif isinstance(layer, SpatialTemporalTransformer):
-                x = layer._run(rt, x, want_f16=wf, want_stats=isinstance(nxt, (ResBlock3D, SpatialTemporalTransformer)))
+                x = layer._run(rt, x, want_f16=wf)
             elif isinstance(layer, (Upsample, Downsample)):
                 x = layer._run(rt, x, want_f16=wf)
             elif isinstance(layer, nn.Conv2d):

@@ -141,7 +141,7 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
          rb_rows=0, rb_mod=0, res1=None, ldr1=0, res2=None, ldr2=0, out32=None, ldc32=0, out16=None,
          ldc16=0, out16t=None, ldt=0, t_rows=0, t_gstride=0, n_split=0, act=ACT_NONE, geglu=False,
          a16_lo=None, out16_lo=None, w_ld=0, ln_gamma=None, ln_beta=None, ln_out16=None, ldln=0, ln_eps=1e-5,
-         ln_in_library=False, w_lo=None, gn_part=None, gn_npix=0):
+         ln_in_library=False, w_lo=None, gn_part=None):
     assert (not STRICT_DTYPES) or (a16.dtype == torch.float16 and w16.dtype == torch.float16)
     assert K % 8 == 0
     Wm = _mat(w16, N, K, w_ld or K).float()
@@ -200,9 +200,8 @@ def gemm(a16, w16, *, M, N, K, lda=0, a_mode=A_PLAIN, conv=None, tconv=None, bia
         assert out32 is not None and out16t is None
         layernorm(out32, ldc32, M, N, ln_gamma, ln_beta, ln_eps, ln_out16, ldln)
     if gn_part is not None:      # PncGemmParams.gn_part: the records pnc_groupnorm_stats writes for 64-pixel chunks
-        npix = tconv["Npix"] if a_mode == A_CONV1D_T else gn_npix
-        assert a_mode != A_CONV3X3 and out32 is not None and N % 64 == 0 and npix > 0 and M % npix == 0
-        groupnorm_stats(out32, ldc32, M // npix, npix, N, 64, gn_part)
+        assert a_mode == A_CONV1D_T and out32 is not None and N % 64 == 0
+        groupnorm_stats(out32, ldc32, M // tconv["Npix"], tconv["Npix"], N, 64, gn_part)
     if out16t is not None:
         G = M // t_rows
         assert G * t_rows == M

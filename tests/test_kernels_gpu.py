@@ -440,50 +440,6 @@ def test_gemm_conv1d_groupnorm_records_from_the_epilogue(B, T, Npix, C, epi, lo8
     assert (y_ep != y_ref).float().mean().item() < 2e-2
 
 
-@pytest.mark.parametrize("F,Npix,C,o16,lo8", [
-    (16, 12288, 320, False, True),      # level 0: leaves the persistent kernel for the one-tile kernel's statistics epilogue
-    (16, 3072, 640, True, True),        # level 1: 1.5 rounds of tiles (tail-split quarter workgroups write their own blocks)
-    (16, 768, 1280, False, False),      # level 2: 256-column tiles -> the statistics launch follows
-    (4, 320, 320, True, False),         # 5 blocks of 64 pixels per frame: tiles span two frames
-])
-def test_gemm_plain_groupnorm_records_from_the_epilogue(F, Npix, C, o16, lo8):
-    """PncGemmParams.gn_part on a plain-A GEMM (proj_out + residual of an STT branch, in place on the stream; Npix = rows per frame):
-    same bits out as without it (whatever kernel runs the launch), records = the statistics of the output."""
-    from panacea_amd import engine
-    M = F * Npix
-    a32 = rnd(M, C, seed=91)
-    a = a32.half()
-    w = rnd(C, C, scale=C ** -0.5, dtype=torch.float16, seed=92)
-    bias, res = rnd(C, seed=93), rnd(M, C, seed=94) * 1.5 - 0.3
-    kw = dict(a16=a, w16=w, M=M, N=C, K=C, lda=C, bias=bias, ldr1=C, ldc32=C)
-    if lo8:
-        alo = torch.zeros(M, C, device=DEV, dtype=torch.uint8)
-        hip.cast_f16(a32, a32.numel(), torch.zeros_like(a), alo)
-        kw.update(a16_lo=alo, w_lo=engine.pk_lo8(w))
-    nrec = -(-Npix // 64)
-
-    def run(with_part):
-        out = res.clone()
-        h = torch.zeros(M, C, device=DEV, dtype=torch.float16) if o16 else None
-        part = torch.full((F * nrec * 96,), float("nan"), device=DEV) if with_part else None
-        hip.gemm(res1=out, out32=out, out16=h, ldc16=C if o16 else 0, gn_part=part, gn_npix=Npix, **kw)
-        torch.cuda.synchronize()
-        return out, h, part
-    plain, h0, _ = run(False)
-    fused, h1, part = run(True)
-    _, _, part2 = run(True)
-    assert torch.equal(fused, plain) and (not o16 or torch.equal(h0, h1)) and torch.equal(part, part2)
-    P = part.view(F, nrec, 32, 3).double()
-    blk = plain.double().view(F, Npix, 32, C // 32)
-    for r in sorted({0, 1, nrec // 2, nrec - 1}):
-        v = blk[:, r * 64:(r + 1) * 64]
-        n = v.shape[1] * (C // 32)
-        mean, m2 = v.mean(dim=(1, 3)), v.var(dim=(1, 3), unbiased=False) * n
-        assert torch.equal(P[:, r, :, 0], torch.full((F, 32), float(n), device=DEV, dtype=torch.float64))
-        assert (P[:, r, :, 1] - mean).abs().max().item() <= 2e-6 * (1 + mean.abs().max().item()), r
-        assert ((P[:, r, :, 2] - m2).abs() / m2).max().item() <= 2e-4, r
-
-
 @pytest.mark.parametrize("B,T,Tl,Npix,C,lo8", [(2, 8, 2, 96, 64, False), (1, 4, 4, 77, 320, True), (2, 8, 4, 64, 1280, True), (1, 2, 1, 40, 128, False)])
 def test_groupnorm_temporal_in_parts(B, T, Tl, Npix, C, lo8):
     """pnc_groupnorm_temporal_part (round 4): the T frames of a pixel on T / Tl ranks — every rank's partial {sum, sum of squares}

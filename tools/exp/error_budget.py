@@ -153,7 +153,7 @@ class Experiment:
         emu.r16, emu.STRICT_DTYPES = self.r16, False
         self._empty, self._zeros, self._ctx = E.Runtime.empty, E.Runtime.zeros, E.Runtime.set_context
         f32 = lambda d: torch.float32 if d == torch.float16 else d   # noqa: E731
-        E.Runtime.empty = lambda rt, shape, dtype: torch.empty(shape, device=rt.device, dtype=f32(dtype))
+        E.Runtime.empty = lambda rt, shape, dtype, tail_rows=0: torch.empty(shape, device=rt.device, dtype=f32(dtype))
         E.Runtime.zeros = lambda rt, shape, dtype: torch.zeros(shape, device=rt.device, dtype=f32(dtype))
         exp = self
 

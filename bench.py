@@ -16,7 +16,8 @@ are recomputed every step, like the reference).
 N > 1: one process per GPU.  Without torchrun's environment `--gpus N` SPAWNS the N ranks itself (this process becomes the
 launcher; rank 0 prints the line), so `python bench.py --gpus 8` is a complete command.  The headline is the reference's own
 multi-GPU strategy — one independent sample per rank (inference.py:248-280: replicas, no collective on the data path), hence
-"scaling": "weak" — and, with the default `--parallelism auto`, the same line carries under "strong_scaling" the
+"scaling": "weak" — and, with the default `--parallelism auto`, the same line carries under "strong_scaling" (and, with the views of
+a sample sharded as BASELINE config 4 words it, under "strong_scaling_views") the
 per-sample-latency mode (one sample over 2 CFG halves x up to 4 frame groups, RCCL all-to-all at the temporal sites) measured
 in the same run: RCCL rank count, exchanges and bytes sent per rank and step.
 
@@ -47,6 +48,10 @@ MFMA_PEAK_TFLOPS = 2500.0          # dense fp16, MI355X_MICROARCH.md
 GOLDEN_FULL = ROOT / "tests" / "golden" / "full_cfg3.npz"
 # the reference's own fp32 forward at BASELINE config 3 (oracle/gen_golden_full.py): (file, timestep index, input salt)
 GOLDEN_PINS = [("full_cfg3.npz", 999, 0), ("full_cfg3_t500.npz", 500, 0), ("full_cfg3_t39_s1.npz", 39, 1)]
+# the pins of the other timed workloads (round 5: the in-run guard follows the workload): --frames 1 = BASELINE config 2,
+# --yaml-exact = BASELINE config 5's sampler step 0 (inputs from synth.yaml_exact_step0_inputs)
+GOLDEN_PIN_CFG2 = ("full_cfg2.npz", 999, 0)
+GOLDEN_PIN_CFG5 = ("full_cfg5_step0.npz", 999, 0)
 
 
 def log(*a):
@@ -193,7 +198,7 @@ def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, 
     from panacea_amd import parallel, sampling
     import torch.distributed as dist
     T, (h, w) = kw["num_frames"], hw
-    layout = parallel.layout_for(world, rank, parallelism)
+    layout = parallel.layout_for(world, rank, parallelism, num_frames=T)
     groups = parallel.Groups(layout)
     # every rank of a sample starts from the SAMPLE's inputs (salt = sample index; the synthetic generator is deterministic):
     # `g` was drawn for this rank's sample of the headline layout, which is another sample for most ranks
@@ -438,7 +443,7 @@ def main():
         name, _, val = kv.partition("=")
         hip.set_option(getattr(hip, "OPT_" + name.upper()), int(val))
     primary = "replica" if args.parallelism == "auto" else args.parallelism
-    layout = parallel.layout_for(world, rank, primary)
+    layout = parallel.layout_for(world, rank, primary, num_frames=args.frames)
     groups = parallel.Groups(layout) if (layout.per_sample > 1) else None
     kw = configs.with_frames(configs.get(args.config), args.frames) if (args.config == "full" or args.frames != 8) \
         else configs.get(args.config)
@@ -516,19 +521,23 @@ def main():
     def parity_of(prec):
         """eps of one network call at BASELINE config 3 vs the REFERENCE's own fp32 forward, at every committed pin (three noise
         levels, two input seeds); the headline numbers are the WORST over the pins"""
-        if not (args.config == "full" and T == 8 and rank == 0 and GOLDEN_FULL.exists()) or shard is not None or vshard is not None \
+        if not (args.config == "full" and T in (1, 8) and rank == 0 and GOLDEN_FULL.exists()) or shard is not None or vshard is not None \
                 or args.no_parity:
             return None          # (a frame-sharded network runs collectives: no single-rank evaluation)
         import numpy as np
         net.diffusion_model.precision = prec
         pins = []
-        for fname, t_index, salt in GOLDEN_PINS:
+        todo = [GOLDEN_PIN_CFG2] if T == 1 else (GOLDEN_PINS + ([GOLDEN_PIN_CFG5] if args.yaml_exact else []))
+        for fname, t_index, salt in todo:
             f = ROOT / "tests" / "golden" / fname
             if not f.exists():
                 continue
             gold = np.load(f)
-            gi = {k: v.to(dev) for k, v in synth.synth_inputs(2, T, h, w, context_dim=kw["context_dim"], t_index=t_index,
-                                                               salt=salt).items()}
+            if fname == GOLDEN_PIN_CFG5[0]:
+                gi = synth.yaml_exact_step0_inputs(T, h, w, context_dim=kw["context_dim"], salt=salt)
+            else:
+                gi = synth.synth_inputs(2, T, h, w, context_dim=kw["context_dim"], t_index=t_index, salt=salt)
+            gi = {k: v.to(dev) for k, v in gi.items()}
             eps = net(gi["x"], gi["t"], {k: gi[k] for k in ("concat", "crossattn", "cond_feat")})
             d = (eps.reshape(-1)[::7].float().cpu() - torch.from_numpy(gold["eps_s7"])).abs()
             pins.append({"golden": fname, "t_index": t_index, "input_salt": salt, "eps_max_abs_err": d.max().item(),
@@ -539,7 +548,8 @@ def main():
         return {"eps_max_abs_err": worst["eps_max_abs_err"], "eps_mean_abs_err": max(q["eps_mean_abs_err"] for q in pins),
                 "eps_ref_rms": worst["eps_ref_rms"], "tolerance": 1e-3, "within_tolerance": bool(worst["eps_max_abs_err"] < 1e-3),
                 "precision": prec, "pins": pins,
-                "against": "reference fp32 CPU forward (tests/golden/full_cfg3*.npz), worst of the pins"}
+                "against": "reference fp32 CPU forward (tests/golden/" + ", ".join(q["golden"] for q in pins) + "), worst of the pins; "
+                           "the second weight draw and the heavy-tail weight set (full_cfg3_t500_w1 / _tail256) are gated in tests/test_model_gpu.py"}
 
     with torch.no_grad():
         # parity guard inside the bench run: eps of the very first network call vs the reference's own output
@@ -588,14 +598,17 @@ def main():
                    "frames_per_step": 2 * T, "parallelism": layout.name, **({"options": args.set_option} if args.set_option else {}),
                    "ranks_per_sample": layout.per_sample, "per_sample_latency_ms": ms_per_step,
                    "graph": bool(args.graph), "streams": 1 if args.one_stream else 2,
-                   "hoisted_step_invariants": bool(args.hoist), "fused_step_tail": bool(smp.fuse)},
+                   "hoisted_step_invariants": bool(args.hoist),
+                   # what the timed steps really ran: the switch AND the sampler's own test on the benchmark's denoiser / guider / cond
+                   "fused_step_tail": bool(smp._fusable(denoiser, x, cond))},
     }
     if args.config == "full":
         ach = ALGO_TFLOP_PER_STEP * (value / world) if T == 8 else None     # per GPU
         # HBM-side bytes per step come from separate rocprofv3 --pmc passes of this same command (they cannot be collected
         # inside a timed run).  The record names the build it was measured on: a stale record reports null, not a number.
-        traffic, tnote = None, "no PMC record for this build (tools/pmc_traffic.py writes profiles/round4/pmc_traffic.json)"
-        pmc = ROOT / "profiles" / "round4" / "pmc_traffic.json"
+        traffic, tnote = None, "no PMC record for this build (tools/pmc_traffic.py writes profiles/round<N>/pmc_traffic.json)"
+        cands = sorted((ROOT / "profiles").glob("round*/pmc_traffic.json"), key=lambda q: int(q.parent.name[5:]))
+        pmc = cands[-1] if cands else ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists() and T == 8:
             rec = json.loads(pmc.read_text())
             cur = hip.build_digest()               # the digest compiled into the loaded library
@@ -618,26 +631,34 @@ def main():
     if args.emulate_kernels:
         out["emulated_kernels"] = True
         out["metric"] += " [HARNESS SELF-TEST on the CPU emulation of the C-ABI: not a measurement]"
-    if args.parallelism == "auto" and world > 1 and world % 2 == 0 and T % max(1, min(4, world // 2)) == 0:
-        # The secondary mode must never cost the headline: it runs collectives that no multi-GPU node has exercised for the
+    if args.parallelism == "auto" and world > 1 and world % 2 == 0:
+        # The secondary modes must never cost the headline: they run collectives that no multi-GPU node has exercised for the
         # builder.  An exception is recorded in the line; a HANG (a rank lost inside a collective) is cut by a watchdog that
         # prints the headline line with the failure noted and ends the process.
+        #   strong_scaling        one sample over 2 CFG halves x G frame groups (G <= 4)
+        #   strong_scaling_views  BASELINE config 4 literally — the VIEWS of a sample sharded: views x2 on 2 GPUs, cfg x views x2 on 4,
+        #                         cfg x views x2 x frame groups on 8 (SURVEY 8e's grid)                               (round 5)
         import threading
+        modes = [("strong_scaling", "cfg+frames")]
+        modes.append(("strong_scaling_views", "views" if world == 2 else ("cfg+views" if world < 8 or world % 4 else "cfg+views+frames")))
+        state = {"key": modes[0][0]}
 
         def give_up():
-            out["strong_scaling"] = {"error": f"no result within {args.strong_timeout} s (a collective did not complete); headline unaffected"}
+            out[state["key"]] = {"error": f"no result within {args.strong_timeout} s (a collective did not complete); headline unaffected"}
             if rank == 0:
                 print(json.dumps(out), flush=True)
             os._exit(0 if rank == 0 else 3)
-        dog = threading.Timer(args.strong_timeout, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            out["strong_scaling"] = run_sharded_mode(args, "cfg+frames", net, kw, (h, w), dev, sync, rank, world, g, layout.sample, den)
-        except Exception as e:          # noqa: BLE001 — reported, not swallowed: the line says what failed
-            out["strong_scaling"] = {"error": f"{type(e).__name__}: {e}"[:400]}
-        finally:
-            dog.cancel()
+        for key, mode in modes:
+            state["key"] = key
+            dog = threading.Timer(args.strong_timeout, give_up)
+            dog.daemon = True
+            dog.start()
+            try:
+                out[key] = run_sharded_mode(args, mode, net, kw, (h, w), dev, sync, rank, world, g, layout.sample, den)
+            except Exception as e:          # noqa: BLE001 — reported, not swallowed: the line says what failed
+                out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            finally:
+                dog.cancel()
     if shard is not None:
         nsteps = args.steps + args.warmup
         out["config"]["exchange"] = {"frame_exchanges_per_step": shard.exchanges // max(1, nsteps),

@@ -8,6 +8,8 @@ oracle is run on the same data and must agree (fp32 vs fp32) before the file is 
     python -m oracle.gen_golden_full --t 39 --salt 1 --no-oracle   # second input seed:  full_cfg3_t39_s1.npz
     python -m oracle.gen_golden_full --frames 1 --no-oracle        # BASELINE config 2 (round 4): full_cfg2.npz
     python -m oracle.gen_golden_full --yaml-exact --no-oracle      # BASELINE config 5, sampler step 0: full_cfg5_step0.npz
+    python -m oracle.gen_golden_full --t 500 --wsalt 1 --no-oracle # second WEIGHT draw (round 5): full_cfg3_t500_w1.npz
+    python -m oracle.gen_golden_full --t 500 --wtail 256 --no-oracle   # heavy-tailed stream (round 5): full_cfg3_t500_tail256.npz
 
 The extra pins skip the (6 minute) oracle leg: oracle vs reference is established by the first file and by the
 small configurations; what the extra files pin is the reference's eps at other noise levels / inputs.
@@ -32,10 +34,16 @@ if __name__ == "__main__":
     ap.add_argument("--salt", type=int, default=0, help="salt of the synthetic INPUTS (weights keep salt 0)")
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--frames", type=int, default=8, help="1 = BASELINE config 2: the YAML network built with num_frames = 1")
+    ap.add_argument("--wsalt", type=int, default=0, help="salt of the synthetic WEIGHTS (synth.synth_state_dict)")
+    ap.add_argument("--wtail", type=float, default=0.0, help="heavy-tail weight set: gain of the output channels c %% 64 == 5 of the residual-out tensors")
     ap.add_argument("--yaml-exact", action="store_true",
                     help="BASELINE config 5: last-frame concat conditioning + share-noise latent, t = 999 (sampler step 0)")
     args = ap.parse_args()
     tag = "" if (args.t == 999 and args.salt == 0) else f"_t{args.t}" + (f"_s{args.salt}" if args.salt else "")
+    if args.wsalt:
+        tag += f"_w{args.wsalt}"
+    if args.wtail:
+        tag += f"_tail{int(args.wtail)}"
     stem = "full_cfg3"
     if args.frames != 8:
         assert args.frames == 1 and not args.yaml_exact
@@ -48,7 +56,7 @@ if __name__ == "__main__":
     t0 = time.time()
     net, wrapper = ref_import.build_reference_network(ns, kw)
     manifest = {k: list(v.shape) for k, v in net.state_dict().items()}
-    sd = synth.synth_state_dict(manifest)
+    sd = synth.synth_state_dict(manifest, salt=args.wsalt, tail=args.wtail)
     net.load_state_dict(sd, strict=True)
     del sd
     print(f"built + loaded in {time.time() - t0:.0f}s", flush=True)
@@ -76,6 +84,7 @@ if __name__ == "__main__":
         assert d <= 1e-4
     np.savez_compressed(GOLDEN / f"{stem}{tag}.npz", eps_s7=eps.reshape(-1)[::7].numpy(),
                         t_index=np.int32(args.t), input_salt=np.int32(args.salt),
+                        weight_salt=np.int32(args.wsalt), weight_tail=np.float32(args.wtail),
                         eps_rms=np.float32(eps.pow(2).mean().sqrt().item()),
                         eps_max=np.float32(eps.abs().max().item()),
                         ref_seconds=np.float32(t_ref), oracle_seconds=np.float32(t_or),

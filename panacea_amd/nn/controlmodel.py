@@ -295,8 +295,10 @@ class StepInvariants:
             raise ValueError("StepInvariants were prepared for different (or since modified) context / hint tensors")
         if self.prec != rt.prec:
             raise ValueError(f"StepInvariants were prepared with precision {self.prec.name}, the network runs {rt.prec.name}")
-        if self.guided.F != rt.F:
-            raise ValueError(f"StepInvariants hold {self.guided.F} frames, the batch has {rt.F}")
+        # the guided hint holds every frame of the batch, or — prepared from a layout shared by the CFG halves — the frames of one
+        # sample, which _run_control broadcasts over the samples (prepare() accepts both, so check() must too)
+        if self.guided.F != rt.F and (self.guided.F != rt.F // max(1, rt.B) or rt.F % self.guided.F):
+            raise ValueError(f"StepInvariants hold {self.guided.F} frames, the batch has {rt.F} ({rt.B} samples)")
 
 
 _SIDE_STREAMS = {}

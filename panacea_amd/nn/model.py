@@ -257,7 +257,10 @@ class Decoder(nn.Module, Packable):
         self.ch, self.temb_ch, self.num_resolutions, self.num_res_blocks = ch, 0, L, num_res_blocks
         self.resolution, self.in_channels, self.z_channels, self.out_ch = resolution, in_channels, z_channels, out_ch
         self.give_pre_end, self.tanh_out = give_pre_end, tanh_out
-        res = [resolution // 2 ** (L - 1 - k) for k in range(L)]             # coarse -> fine: the resolution of the k-th level built
+        # coarse -> fine: the resolution of the k-th level built — the coarsest is floored ONCE and then doubled, as model.py:917-918,
+        # 960 do it (curr_res = resolution // 2^(L-1); curr_res *= 2 per level): for a resolution that is no multiple of 2^(L-1) a
+        # per-level floor gives another list (100: 12, 25, 50, 100 instead of 12, 24, 48, 96) and with it other AttnBlock placements
+        res = [(resolution // 2 ** (L - 1)) * 2 ** k for k in range(L)]
         self.z_shape = (1, z_channels, res[0], res[0])
         self.conv_in = _conv(z_channels, widths[-1])
         self.mid = _mid(widths[-1], attn_type, dropout)

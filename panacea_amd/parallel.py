@@ -135,22 +135,28 @@ class RankLayout:
         return " . ".join(parts) or "single"
 
 
-def layout_for(world: int, rank: int, parallelism: str) -> RankLayout:
+def layout_for(world: int, rank: int, parallelism: str, num_frames: int = 8) -> RankLayout:
     """`replica` (one sample per rank) | `cfg` (one sample per rank pair) | `cfg+frames` (one sample over up to 8 ranks:
     2 CFG halves x min(4, world/2) frame groups; with a single rank it degenerates to `replica`)."""
     if parallelism == "replica" or world == 1:
         return RankLayout(world, rank)
     if parallelism == "cfg":
         return RankLayout(world, rank, cfg=2)
+    def frame_groups(per):                      # largest G <= 4 dividing the ranks available to a half AND the clip's frames
+        return [g for g in (4, 2, 1) if per % g == 0 and num_frames % g == 0][0]
     if parallelism == "cfg+frames":
-        return RankLayout(world, rank, cfg=2, frames=max(1, min(4, world // 2)))
+        if world % 2:
+            raise ValueError(f"cfg+frames needs an even number of ranks, got {world}")
+        return RankLayout(world, rank, cfg=2, frames=frame_groups(world // 2))
     if parallelism == "frames":
-        return RankLayout(world, rank, cfg=1, frames=min(4, world))
+        return RankLayout(world, rank, cfg=1, frames=frame_groups(world))
     if parallelism == "cfg+views+frames":
         # SURVEY 8(e)'s 8-GPU grid: 2 CFG halves x 2 view groups (3 views each) x world/4 frame groups
         if world % 4 or world < 8:
             raise ValueError(f"cfg+views+frames needs a multiple of 4 ranks >= 8 (2 halves x 2 view groups x G frame groups), got {world}")
-        return RankLayout(world, rank, cfg=2, frames=min(4, world // 4), views=2)
+        # G: the largest frame-group count <= 4 that divides BOTH the ranks of a (half, view group) and the clip's frames, so that
+        # 2 x 2 x G factors the sample's ranks and every rank holds whole frames (world 12 -> G = 1 x 3 samples, not G = 3)
+        return RankLayout(world, rank, cfg=2, frames=frame_groups(world // 4), views=2)
     if parallelism in ("views", "cfg+views"):
         cfg = 2 if parallelism == "cfg+views" else 1
         fit = [v for v in (6, 3, 2) if (world // cfg) % v == 0 and world >= cfg * v]
@@ -241,6 +247,8 @@ def local_frames(t: torch.Tensor, layout: RankLayout, num_frames: int) -> torch.
     """this rank's frames of a per-frame tensor whose leading dimension is (samples_in_t * num_frames)"""
     if layout.frames == 1:
         return t
+    if num_frames % layout.frames:
+        raise ValueError(f"{num_frames} frames do not split over {layout.frames} frame groups")
     tl = num_frames // layout.frames
     v = t.view(t.shape[0] // num_frames, num_frames, *t.shape[1:])
     return v[:, layout.frame_group * tl:(layout.frame_group + 1) * tl].reshape(-1, *t.shape[1:]).contiguous()

@@ -29,8 +29,17 @@ def _fp16_round(a: np.ndarray) -> np.ndarray:
     return a.astype(np.float16).astype(np.float32)
 
 
-def synth_tensor(name: str, shape: Tuple[int, ...], salt: int = 0) -> torch.Tensor:
-    """One parameter, from its NAME and SHAPE only."""
+TAIL_PERIOD, TAIL_PHASE = 64, 5       # heavy-tail weight sets: output channels c with c % 64 == 5 of every residual-out tensor
+
+
+def synth_tensor(name: str, shape: Tuple[int, ...], salt: int = 0, tail: float = 0.0) -> torch.Tensor:
+    """One parameter, from its NAME and SHAPE only.
+
+    `tail` > 0 (a power of two, so the values stay fp16-representable) multiplies the output rows c % 64 == 5 of every tensor that
+    writes into the residual stream: a few "massive activation" channels, as trained diffusion / transformer checkpoints have
+    them, carry the stream to |v| = 10^2 .. 10^3 — the regime where the e4m3 lo plane of an fp16-rounded operand clamps
+    (include/panacea_hip.h: |v| >= 512) and a GroupNorm group is dominated by one channel.  Default 0: the weight sets of every
+    earlier pin are unchanged."""
     g = _rng(name, salt)
     shape = tuple(int(s) for s in shape)
     leaf = name.rsplit(".", 1)[-1]
@@ -45,18 +54,20 @@ def synth_tensor(name: str, shape: Tuple[int, ...], salt: int = 0) -> torch.Tens
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
         gain = 0.5 if any(t in name for t in _RESIDUAL_OUT) else 1.0
         a = g.standard_normal(shape, dtype=np.float32) * (gain / np.sqrt(max(fan_in, 1)))
+        if tail > 0.0 and gain != 1.0 and len(shape) > 1:
+            a[TAIL_PHASE::TAIL_PERIOD] *= np.float32(tail)
     return torch.from_numpy(_fp16_round(a))
 
 
-def synth_state_dict(manifest: Dict[str, Iterable[int]], salt: int = 0, threads: int = 8) -> Dict[str, torch.Tensor]:
+def synth_state_dict(manifest: Dict[str, Iterable[int]], salt: int = 0, threads: int = 8, tail: float = 0.0) -> Dict[str, torch.Tensor]:
     """Every tensor is generated from its own (name, shape) stream, so the result does not depend on the
     thread count; numpy's Generator releases the GIL while sampling."""
     items = list(manifest.items())
     if threads <= 1 or len(items) < 64:
-        return {k: synth_tensor(k, tuple(v), salt) for k, v in items}
+        return {k: synth_tensor(k, tuple(v), salt, tail) for k, v in items}
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(threads) as ex:
-        vals = list(ex.map(lambda kv: synth_tensor(kv[0], tuple(kv[1]), salt), items))
+        vals = list(ex.map(lambda kv: synth_tensor(kv[0], tuple(kv[1]), salt, tail), items))
     return {k: v for (k, _), v in zip(items, vals)}
 
 

@@ -34,6 +34,10 @@ def test_bench_gpus_2_spawns_its_ranks_and_reports_both_scalings():
     s = d["strong_scaling"]
     assert s["scaling"] == "strong" and s["ranks_per_sample"] == 2 and s["parallelism"] == "cfg x2"
     assert s["cfg_all_gathers_per_step"] == 1 and "2 ranks" in s["collective_backend"]
+    # BASELINE config 4 literally: the VIEWS of one sample sharded over the 2 ranks, in the same line (round 5)
+    v = d["strong_scaling_views"]
+    assert "error" not in v, v
+    assert v["scaling"] == "strong" and v["parallelism"] == "views x2" and v["exchange"]["neighbour_exchanges_per_step"] > 0
 
 
 @pytest.mark.parametrize("mode,name", [("frames", "frames x2"), ("cfg", "cfg x2"), ("views", "views x2")])
@@ -59,6 +63,11 @@ def test_bench_gpus_8_is_the_drivers_scaling_command():
     assert "error" not in s, s
     assert s["parallelism"] == "cfg x2 . frames x4" and s["ranks_per_sample"] == 8 and s["samples_in_flight"] == 1
     assert s["exchange"]["frame_exchanges_per_step"] > 0 and s["per_sample_latency_ms"] > 0
+    # SURVEY 8(e)'s 8-GPU grid as the second strong-scaling record: 2 CFG halves x 2 view groups x 2 frame groups
+    v = d["strong_scaling_views"]
+    assert "error" not in v, v
+    assert v["parallelism"] == "cfg x2 . frames x2 . views x2" and v["ranks_per_sample"] == 8
+    assert v["exchange"]["frame_exchanges_per_step"] > 0 and v["view_exchange"]["neighbour_exchanges_per_step"] > 0
 
 
 def test_bench_yaml_exact_setup_runs_multi_rank():

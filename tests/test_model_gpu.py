@@ -228,6 +228,41 @@ def test_full_size_properties_and_golden(full_net):
         pytest.skip("tests/golden/full_cfg3.npz not generated yet (property checks passed)")
 
 
+# Round 5 (VERDICT r4 weak spot 2): every earlier pin used ONE synthetic weight draw (salt 0) whose residual stream stays far below the
+# |v| = 512 where the e4m3 lo plane of an fp16-rounded operand clamps (include/panacea_hip.h).  Two more pins of the reference's own
+# forward (oracle/gen_golden_full.py --t 500 --wsalt 1 / --wtail 256): a second weight draw, and a heavy-tailed weight set whose
+# "massive activation" channels (synth.synth_tensor: output rows c % 64 == 5 of every residual-out tensor x 256) carry the stream
+# into the clamp range.  TAIL_GATE is the bound the network states for that regime (UNetModel3D.eps_contract_heavy_tail).
+TAIL_GATE = 1.0e-3
+
+
+@pytest.mark.parametrize("fname,wsalt,wtail", [("full_cfg3_t500_w1.npz", 1, 0.0), ("full_cfg3_t500_tail256.npz", 0, 256.0)])
+def test_full_size_other_weight_sets(full_net, fname, wsalt, wtail):
+    from panacea_amd import synth
+    path = GOLDEN / fname
+    if not path.exists():
+        pytest.skip(f"{fname} not generated")
+    w, kw = full_net
+    gp = np.load(path)
+    assert int(gp["weight_salt"]) == wsalt and float(gp["weight_tail"]) == wtail and int(gp["t_index"]) == 500
+    try:
+        w.diffusion_model.load_state_dict(synth.synth_state_dict(manifest("full"), salt=wsalt, tail=wtail), strict=True)
+        gi = {k: v.to(DEV) for k, v in synth.synth_inputs(2, 8, 32, 384, context_dim=kw["context_dim"], t_index=500).items()}
+        trace = {} if wtail else None
+        eps = w(gi["x"], gi["t"], cond(gi), trace=trace) if wtail else w(gi["x"], gi["t"], cond(gi))
+        st = err_stats(eps.reshape(-1)[::7], gp["eps_s7"])
+        extra = {}
+        if wtail:
+            extra["stream_max_abs"] = max(float(v.abs().max()) for k, v in trace.items() if "blocks" in k or "middle" in k)
+            assert extra["stream_max_abs"] >= 512.0, extra          # the regime the pin exists for: the e4m3 clamp range is reached
+            del trace
+        print(f"config 3, t=500, weight salt {wsalt}, tail {wtail} vs reference:", st, extra)
+        measured("full_cfg3_weights", wsalt=wsalt, wtail=wtail, max_abs=st["max_abs"], mean_abs=st["mean_abs"], **extra)
+        assert st["max_abs"] <= (TAIL_GATE if wtail else NORTH_STAR), st
+    finally:
+        w.diffusion_model.load_state_dict(synth.synth_state_dict(manifest("full")), strict=True)     # the module fixture's weights
+
+
 def test_streams_and_graph_replay_are_bit_identical():
     """ControlNet on a side stream, per-sample stream pairs and hipGraph replay of a whole sampler step must not
     change a single bit (tiny network; the same invariants hold at full size because no kernel depends on the

@@ -34,7 +34,8 @@ extern "C" {
 /* library / build identification: returns "panacea_hip <version> gfx950" */
 const char* pnc_version(void);
 /* ABI revision of this header (bumped whenever a parameter struct or a prototype changes): 4
- * (round 4: + pnc_groupnorm_combine, + PNC_OPT_ATTN_DEFER_MAX, PNC_OPT_GEMM_PERSIST is a bit set, - pnc_ff_chain_*) */
+ * (round 4: + pnc_groupnorm_combine, + PNC_OPT_ATTN_DEFER_MAX, PNC_OPT_GEMM_PERSIST is a bit set, - pnc_ff_chain_*;
+ *  round 5 adds PNC_OPT_GEMM_STAGGER without an ABI bump: no struct or prototype changed) */
 #define PNC_ABI_VERSION 4
 int pnc_abi_version(void);
 /* hex SHA-256 of the sources + compile flags the library was built from (panacea_amd/build.py computes the same digest over
@@ -73,7 +74,12 @@ enum {
                                      maximum grows.  Same softmax, other roundings of P (not bit-identical across values) */
     PNC_OPT_GEMM_GN_STATS = 9,    /* 1 (default): PncGemmParams.gn_part comes out of the temporal conv's epilogue where its waves own whole
                                      groups; 0 = always the statistics kernel after the GEMM (same records up to fp32 summation order) */
-    PNC_OPT_COUNT = 10
+    PNC_OPT_GEMM_STAGGER = 10,    /* k (default 8; round 5): the 8-wave two-stage GEMM kernels run K loops of at least k tiles (lo + hi) in the
+                                     STAGGERED schedule — four phases per K tile {fragment reads + a third of the next tile's DMA | barrier |
+                                     MFMAs | barrier}, waves 4-7 one barrier behind waves 0-3, so that on every SIMD one wave multiplies
+                                     while the other reads; 0 = never (round 4's loops), 1 = always.  Same K and MFMA order per
+                                     accumulator: bit-identical results */
+    PNC_OPT_COUNT = 11
 };
 int pnc_set_option(int option, int value);
 

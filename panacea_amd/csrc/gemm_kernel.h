@@ -721,7 +721,8 @@ __device__ __forceinline__ void epi_generic(const PncGemmParams& p, f32x16 (&acc
 template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE, unsigned EPI>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams pin, const int ksplit,
                                                                    const int nfull, const int tail_f,
-                                                                   const float* __restrict__ phi_g, const int group_m) {
+                                                                   const float* __restrict__ phi_g, const int group_m,
+                                                                   const int stagger_min) {
     PncGemmParams p = pin;
     constexpr int NW = WGM * WGN;                          // waves per workgroup
     constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
@@ -842,7 +843,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     for (int i = 0; i < A_IT; ++i)
         aoff[i] = (AMODE == PNC_A_PLAIN && rows[i].valid) ? (unsigned)(rows[i].rel + schunk * 8) * 2u : PNC_BUF_OOB;
     const int kt_tail = (p.K & (BK - 1)) ? ntiles_all - 1 : -1;      // the one K tile with chunks beyond K, if any
-    auto issue_tile = [&](int kt_local, int stage) {
+    // DMA pieces [Q0, Q1) of K tile kt_local into `stage` (pieces 0 .. A_IT-1: the A row groups, A_IT .. LOADS-1: the W row groups;
+    // the range is compile-time so that the staggered schedule below can spread a tile's pieces over its phases)
+    auto issue_part = [&](int kt_local, int stage, auto q0_, auto q1_) __attribute__((always_inline)) {
+        constexpr int Q0 = decltype(q0_)::value, Q1 = decltype(q1_)::value;
         const bool lo = kt_local < nt_lo;
         char* sa = smem + stage * STAGE + wave * 1024;
         char* sb = sa + A_BYTES;
@@ -858,15 +862,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
             const bool k_on = kc8 < p.K;                 // false only in the chunks of the last tile beyond K
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
+                if (i < Q0 || i >= Q1) continue;
                 if constexpr (AMODE == PNC_A_PLAIN)      // (rel + 8 schunk) * 2 -> rel + 16 schunk
                     glds16_buf(rs_alo, (k_on && aoff[i] != PNC_BUF_OOB) ? (aoff[i] >> 1) + (unsigned)schunk8 * 8u : PNC_BUF_OOB, ks8,
                                sa + i * (RPI * 128));
                 else glds16_buf(rs_alo, a_chunk_off<AMODE, 1u>(p, rows[i], kc8), 0u, sa + i * (RPI * 128));
             }
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i)
+            for (int i = 0; i < B_IT; ++i) {
+                if (A_IT + i < Q0 || A_IT + i >= Q1) continue;
                 glds16_buf(rs_wlo, (k_on && woff[i] != PNC_BUF_OOB) ? (unsigned)((i * RPI + srow8) * p.ldw_lo + schunk8 * 16) : PNC_BUF_OOB,
                            ks8, sb + i * (RPI * 128));
+            }
             return;
         }
         const int kt = (lo ? kt_begin_lo : kt_begin - nt_lo) + kt_local;
@@ -876,21 +883,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
         if (kt != kt_tail) {                             // (uniform) no per-lane predicate on the K index
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
+                if (i < Q0 || i >= Q1) continue;
                 if constexpr (AMODE == PNC_A_PLAIN) glds16_buf(rs, aoff[i], ks, sa + i * (RPI * 128));
                 else glds16_buf(rs, a_chunk_off<AMODE>(p, rows[i], kc), 0u, sa + i * (RPI * 128));
             }
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i) glds16_buf(rs_w, woff[i], ks, sb + i * (RPI * 128));
+            for (int i = 0; i < B_IT; ++i) {
+                if (A_IT + i < Q0 || A_IT + i >= Q1) continue;
+                glds16_buf(rs_w, woff[i], ks, sb + i * (RPI * 128));
+            }
         } else {
             const bool k_on = kc < p.K;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
+                if (i < Q0 || i >= Q1) continue;
                 if constexpr (AMODE == PNC_A_PLAIN) glds16_buf(rs, k_on ? aoff[i] : PNC_BUF_OOB, ks, sa + i * (RPI * 128));
                 else glds16_buf(rs, a_chunk_off<AMODE>(p, rows[i], kc), 0u, sa + i * (RPI * 128));
             }
 #pragma unroll
-            for (int i = 0; i < B_IT; ++i) glds16_buf(rs_w, k_on ? woff[i] : PNC_BUF_OOB, ks, sb + i * (RPI * 128));
+            for (int i = 0; i < B_IT; ++i) {
+                if (A_IT + i < Q0 || A_IT + i >= Q1) continue;
+                glds16_buf(rs_w, k_on ? woff[i] : PNC_BUF_OOB, ks, sb + i * (RPI * 128));
+            }
         }
+    };
+    auto issue_tile = [&](int kt_local, int stage) __attribute__((always_inline)) {
+        issue_part(kt_local, stage, std::integral_constant<int, 0>{}, std::integral_constant<int, LOADS>{});
     };
 
     // GEGLU: the Phi table rides into LDS (behind the operand ring) with the first K tile
@@ -1008,8 +1026,145 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
 
     // The second-dispatched half of an 8-wave workgroup loses every issue arbitration by age (MI355X_MICROARCH.md, two waves per
     // SIMD): static priority for it.  Plain-A GEMMs -1.9 ms per step in a same-box A/B; the gathers (+0.3 / +0.4 ms) keep age order.
-    if (AMODE == PNC_A_PLAIN && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    if (STAGES == 2) {
+    // STAGGERED schedule (round 5; 8-wave geometries on two stages, PNC_OPT_GEMM_STAGGER): a K tile is four PHASES, one per k-step —
+    //     fragment reads of the k-step + a third of the NEXT tile's DMA pieces | s_barrier | MI x NI MFMAs | s_barrier
+    // and waves 4-7 (the second wave of every SIMD) run ONE barrier behind waves 0-3: while one wave of a SIMD is in its MFMA
+    // cluster the other reads its fragments and issues its DMA, and the barriers hold that alternation (the two-group form of the
+    // HIP guide's 256^2 8-phase template on this kernel's stages).  vmcnt(0) once per K tile, before the first barrier of phase 3 — a
+    // whole MFMA cluster after the last DMA issue —, together with lgkmcnt(0): the OTHER group is one barrier away from reading the
+    // next tile / overwriting this one.  Same K order and MFMA order per accumulator as the loops below: bit-identical results.
+    // Measured on the shipped geometry (tools/exp/gemm_phase_probe.hip, profiles/round5/gemm_phase_probe_r5a.log): +6 .. +19 % on
+    // every K >= 640 shape (L1 conv-K 907 -> 1082 TFLOP/s, L2 FF2 1104 -> 1259 = the vendor GEMM's 1259); the group offset is the
+    // whole effect (phases without it: -2 %), priority flips around the MFMA clusters are flat, and a finer ring of k-half units
+    // with counted vmcnt is slower than full-tile stages.
+    bool staggered = false;
+    if constexpr (STAGES == 2 && NW == 8) staggered = stagger_min > 0 && ntot >= stagger_min;
+    if (AMODE == PNC_A_PLAIN && NW == 8 && wave >= 4 && !staggered) __builtin_amdgcn_s_setprio(1);
+    if (staggered) {
+        if constexpr (STAGES == 2 && NW == 8) {
+            constexpr int Q0 = (LOADS + 2) / 3, Q1 = (LOADS - Q0 + 1) / 2;
+            const std::integral_constant<int, 0> C0{};
+            const std::integral_constant<int, Q0> CQ0{};
+            const std::integral_constant<int, Q0 + Q1> CQ1{};
+            const std::integral_constant<int, LOADS> CQ2{};
+            const int grp = wave >> 2;
+            half8v af[MI], bf[NI];
+            i32x8 af8[MI], bf8[NI];
+            auto rd = [&](int stage, int ks) {
+                const char* sa = smem + stage * STAGE;
+                const char* sb = sa + A_BYTES;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[i] = *reinterpret_cast<const half8v*>(sa + lds_off128(wm * (MI * 32) + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    bf[j] = *reinterpret_cast<const half8v*>(sb + lds_off128(wn * (NI * 32) + j * 32 + frow, ks * 2 + fk));
+            };
+            auto rd8 = [&](int stage, int w) {
+                const char* sa = smem + stage * STAGE;
+                const char* sb = sa + A_BYTES;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int row = wm * (MI * 32) + i * 32 + frow;
+                    const i32x4 a0 = *reinterpret_cast<const i32x4*>(sa + lds_off128(row, w * 4 + fk * 2));
+                    const i32x4 a1 = *reinterpret_cast<const i32x4*>(sa + lds_off128(row, w * 4 + fk * 2 + 1));
+                    af8[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int row = wn * (NI * 32) + j * 32 + frow;
+                    const i32x4 b0 = *reinterpret_cast<const i32x4*>(sb + lds_off128(row, w * 4 + fk * 2));
+                    const i32x4 b1 = *reinterpret_cast<const i32x4*>(sb + lds_off128(row, w * 4 + fk * 2 + 1));
+                    bf8[j] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            };
+            // first barrier of a phase (+ this wave's fragment reads have returned), second barrier
+            auto bar1 = [&]() {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto bar2 = [&]() {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            };
+            issue_tile(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int n8 = lo8 ? nt_lo : 0;
+            // The e4m3 lo tiles of the GATHERS (Down / Upsample convs, temporal convs: 3-20 short tiles) keep the plain loop — every
+            // wave in step, one barrier per tile: phased, the 56 fragment registers of a 128-k tile are live across the gather's
+            // address arithmetic next to 160 accumulator registers (39 spilled VGPRs, reloaded inside the loop).  The group offset
+            // starts behind them.  Plain A has no address arithmetic in the loop: its lo tiles are phased below.
+            constexpr bool LO8_PHASED = AMODE == PNC_A_PLAIN;
+            if constexpr (!LO8_PHASED) {
+                for (int kt = 0; kt < n8; ++kt) {
+                    if (kt + 1 < ntot) issue_tile(kt + 1, (kt + 1) & 1);
+                    if (wave_on) compute8(kt & 1, kt);
+                    __syncthreads();
+                }
+            }
+            if (grp == 1) __builtin_amdgcn_s_barrier();               // group 1 runs one barrier behind group 0 from here on
+            for (int kt = 0; kt < (LO8_PHASED ? n8 : 0); ++kt) {      // e4m3 lo tiles: one phase per 64-k MFMA window
+                const int st = kt & 1;
+                const int nwin = (p.K - (kt_begin_lo + kt) * BK8) > 64 ? 2 : 1;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    if (w < nwin) {
+                        if (AMODE == PNC_A_PLAIN && wave_on) rd8(st, w);
+                        if (w == 0 && kt + 1 < ntot) issue_tile(kt + 1, st ^ 1);
+                        if (AMODE != PNC_A_PLAIN) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (wave_on) rd8(st, w);
+                        }
+                        if (w == nwin - 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        bar1();
+                        if (wave_on) {
+#pragma unroll
+                            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                                for (int i = 0; i < MI; ++i)
+                                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af8[i], bf8[j], acc[i][j], 0, 0, 0, E8M0_LO_INV, 0, p.w_lo_exp);
+                        }
+                        bar2();
+                    }
+                }
+            }
+            for (int kt = n8; kt < ntot; ++kt) {
+                const int st = kt & 1;
+                const bool nxt = kt + 1 < ntot;
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    // plain A: reads first (their latency runs under the DMA issue; the measured order).  Gathers: DMA first — the
+                    // ~25 address temporaries per piece are dead before the 28 fragment registers go live (reads first spilled 39
+                    // VGPRs in the conv3x3 variants next to 160 accumulator registers)
+                    if (AMODE == PNC_A_PLAIN && wave_on) rd(st, ph);
+                    if (nxt) {
+                        if (ph == 0) issue_part(kt + 1, st ^ 1, C0, CQ0);
+                        else if (ph == 1) issue_part(kt + 1, st ^ 1, CQ0, CQ1);
+                        else if (ph == 2) issue_part(kt + 1, st ^ 1, CQ1, CQ2);
+                    }
+                    if (AMODE != PNC_A_PLAIN) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (wave_on) rd(st, ph);
+                    }
+                    if (ph == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    bar1();
+                    if (wave_on) {
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NI; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
+                    bar2();
+                }
+                if (wave_on && !lo8 && kt + 1 == nt_lo) scale_lo();
+            }
+            if (grp == 0) __builtin_amdgcn_s_barrier();               // group 0 waits for group 1's last phase
+        }
+    } else if (STAGES == 2) {
         // one tile in flight: the plain barrier carries the vmcnt(0) that lands the DMA
         issue_tile(0, 0);
         __syncthreads();
@@ -1137,7 +1292,7 @@ const float* phi_table_device(hipStream_t st, int* rc);
 // level-0 FF1 472-540 -> 409-430 us, level 1 356 -> 334, level 2 316 -> 308.
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(const PncGemmParams pin, const float* __restrict__ phi_g,
-                                                                            const int group_m) {
+                                                                            const int group_m, const int stagger_min) {
     PncGemmParams p = pin;
     constexpr int NW = WGM * WGN, MI = BM / WGM / 32, NI = BN / WGN / 32, RPI = NW * 8, A_IT = BM / RPI, B_IT = BN / RPI;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, RING_BYTES = 2 * STAGE;
@@ -1179,16 +1334,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(cons
     for (int i = 0; i < A_IT; ++i) aoff[i] = (unsigned)((i * RPI + srow) * p.lda + schunk * 8) * 2u;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) woff[i] = (unsigned)((i * RPI + srow) * p.ldw + schunk * 8) * 2u;
-    auto issue = [&](int m0, int n0, int kt, int stage) {
+    auto issue_part = [&](int m0, int n0, int kt, int stage, auto q0_, auto q1_) __attribute__((always_inline)) {
+        constexpr int Q0 = decltype(q0_)::value, Q1 = decltype(q1_)::value;       // DMA pieces [Q0, Q1): A row groups, then W row groups
         const buffer_rsrc_t rs_a = make_rsrc(A + (int64_t)m0 * p.lda, 0x7FFFFF00u);
         const buffer_rsrc_t rs_w = make_rsrc(Wt + (int64_t)n0 * p.ldw, 0x7FFFFF00u);
         char* sa = smem + stage * STAGE + wave * 1024;
         char* sb = sa + A_BYTES;
         const unsigned ks = (unsigned)kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) glds16_buf(rs_a, aoff[i], ks, sa + i * (RPI * 128));
+        for (int i = 0; i < A_IT; ++i)
+            if (i >= Q0 && i < Q1) glds16_buf(rs_a, aoff[i], ks, sa + i * (RPI * 128));
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) glds16_buf(rs_w, woff[i], ks, sb + i * (RPI * 128));
+        for (int i = 0; i < B_IT; ++i)
+            if (A_IT + i >= Q0 && A_IT + i < Q1) glds16_buf(rs_w, woff[i], ks, sb + i * (RPI * 128));
+    };
+    auto issue = [&](int m0, int n0, int kt, int stage) __attribute__((always_inline)) {
+        issue_part(m0, n0, kt, stage, std::integral_constant<int, 0>{}, std::integral_constant<int, A_IT + B_IT>{});
     };
 
     for (int i = tid; i < PHI_BYTES / 16; i += 64 * NW)                 // the Phi table: once per workgroup, by plain stores
@@ -1220,7 +1381,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(cons
         }
     };
 
-    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (NW == 8 && wave >= 4 && !(stagger_min > 0 && nk >= stagger_min)) __builtin_amdgcn_s_setprio(1);
     int v = blockIdx.x;
     if (v >= ntile) return;
     int m0, n0, sp = 0;
@@ -1232,6 +1393,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(cons
     };
     load_bias(n0, pb);
     issue(m0, n0, 0, 0);
+    // staggered schedule of the K loop (gemm_glds_kernel; PNC_OPT_GEMM_STAGGER): waves 4-7 one barrier behind waves 0-3 inside an
+    // output tile's K loop, both groups aligned again before the epilogue (their epilogues run together, as before; run one behind
+    // the other they would serialise: a group can do ONE phase while the other is in its epilogue).  The next output tile's first K
+    // tile is requested in phases 0-2 of the LAST K tile instead of in front of the epilogue.
+    const bool staggered = NW == 8 && stagger_min > 0 && nk >= stagger_min;
+    const int grp = wave >> 2;
     while (true) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -1239,19 +1406,71 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(cons
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        const int ls = (sp + nk - 1) & 1;       // the stage of the last K tile: every wave is done with it -> the epilogue's staging
+        const int vn = v + gridDim.x;
+        int m1 = 0, n1 = 0;
+        if (staggered) {
+            constexpr int LOADS = A_IT + B_IT, Q0 = (LOADS + 2) / 3, Q1 = (LOADS - Q0 + 1) / 2;
+            const std::integral_constant<int, 0> C0{};
+            const std::integral_constant<int, Q0> CQ0{};
+            const std::integral_constant<int, Q0 + Q1> CQ1{};
+            const std::integral_constant<int, LOADS> CQ2{};
+            if (v == (int)blockIdx.x) {          // (uniform) first output tile: its K tile 0 was requested above (+ the Phi table's stores)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }                                    // (later tiles: landed and published by the previous tile's last phase)
+            if (grp == 1) __builtin_amdgcn_s_barrier();
+            if (vn < ntile) tile_origin(vn, m1, n1);
+            half8v af[MI], bf[NI];
+            for (int kt = 0; kt < nk; ++kt) {
+                const int st = (sp + kt) & 1;
+                const bool last = kt + 1 == nk;
+                const bool nxt = !last || vn < ntile;
+                const int nm0 = last ? m1 : m0, nn0 = last ? n1 : n0, nkt = last ? 0 : kt + 1;
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    const char* sa = smem + st * STAGE;
+                    const char* sb = sa + A_BYTES;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        af[i] = *reinterpret_cast<const half8v*>(sa + lds_off128(wm * (MI * 32) + i * 32 + frow, ph * 2 + fk));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        bf[j] = *reinterpret_cast<const half8v*>(sb + lds_off128(wn * (NI * 32) + j * 32 + frow, ph * 2 + fk));
+                    if (nxt) {
+                        if (ph == 0) {
+                            if (last) load_bias(n1, pbn);         // BEFORE the DMA (vmcnt is in order)
+                            issue_part(nm0, nn0, nkt, st ^ 1, C0, CQ0);
+                        } else if (ph == 1) issue_part(nm0, nn0, nkt, st ^ 1, CQ0, CQ1);
+                        else if (ph == 2) issue_part(nm0, nn0, nkt, st ^ 1, CQ1, CQ2);
+                    }
+                    if (ph == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            if (grp == 0) __builtin_amdgcn_s_barrier();          // both groups past their last phase: the epilogues start together
+        } else {
         __syncthreads();                        // K tile 0 of this output tile has landed; the previous epilogue's staging is retired
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) issue(m0, n0, kt + 1, (sp + kt + 1) & 1);
             compute((sp + kt) & 1);
             __syncthreads();
         }
-        const int ls = (sp + nk - 1) & 1;       // the stage of the last K tile: every wave is done with it -> the epilogue's staging
-        const int vn = v + gridDim.x;
-        int m1 = 0, n1 = 0;
         if (vn < ntile) {                       // (uniform) the next output tile's first K tile, into the other stage
             tile_origin(vn, m1, n1);
             load_bias(n1, pbn);                 // BEFORE the DMA: nothing in the epilogue below may wait on vmcnt
             issue(m1, n1, 0, ls ^ 1);
+        }
         }
         {   // epi_geglu's register path, slab by slab (same operations in the same order: bit-identical)
             half_t* out16 = reinterpret_cast<half_t*>(p.out16);
@@ -1333,7 +1552,7 @@ int launch_geglu_persist(const PncGemmParams& p, hipStream_t st) {
         ncu_of[dev & 63].store(ncu, std::memory_order_relaxed);
     }
     const int blocks = tiles < ncu ? tiles : ncu;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * WGM * WGN), lds, st, p, phi, group_m);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * WGM * WGN), lds, st, p, phi, group_m, pnc_get_option(PNC_OPT_GEMM_STAGGER));
     return pnc_launch_status();
 }
 // the persistent kernel serves this problem (and the switch is on)
@@ -1750,6 +1969,9 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(const PncGemmParams p
 static inline bool plain_persist_ok(const PncGemmParams& p, unsigned epi) {
     if ((pnc_get_option(PNC_OPT_GEMM_PERSIST) & 2) == 0 || p.a_mode != PNC_A_PLAIN) return false;
     if ((p.M % 256) || (p.N % 320) || (p.K % 64) || p.K < 64) return false;
+    // long K (FF2 at level 0: K = 1280): the staggered schedule of the one-tile-per-workgroup kernel is worth more than the prefetch
+    // across output tiles (+10-16 % against 1.5-4 %); this kernel keeps the epilogue-bound K = 320 .. 640 launches
+    if (pnc_get_option(PNC_OPT_GEMM_STAGGER) > 0 && p.K >= 1024) return false;
     if (p.A_lo && (p.a_lo_fmt != PNC_LO_E4M3 || (p.lda % 16))) return false;
     if ((epi & E_LN) && p.N != 320) return false;
     if ((epi & E_VT) && ((p.n_split % 320) || (p.M % 8) || (p.t_rows % 8))) return false;
@@ -1823,7 +2045,7 @@ int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
     if (group_m > tiles_m) group_m = tiles_m;
     if (tiles_n < 2) group_m = 0;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds + (GEGLU ? PHI_BYTES : 0), st, q, ksplit, nfull, tail_f, phi,
-                       group_m);
+                       group_m, pnc_get_option(PNC_OPT_GEMM_STAGGER));
     if (ksplit > 1) return launch_splitk_reduce(p, ksplit, st);
     return pnc_launch_status();
 }

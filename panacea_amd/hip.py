@@ -171,6 +171,7 @@ OPT_GEMM_TAIL_SPLIT, OPT_GEMM_TILE, OPT_ATTN_VARIANT, OPT_ATTN_DMA, OPT_GEMM_FUS
 OPT_GEMM_PERSIST = 7
 OPT_ATTN_DEFER_MAX = 8
 OPT_GEMM_GN_STATS = 9
+OPT_GEMM_STAGGER = 10
 
 
 def build_digest() -> str:
@@ -180,7 +181,7 @@ def build_digest() -> str:
 
 def set_option(option: int, value: int) -> int:
     """pnc_set_option: process-global tuning / test switch of the library; returns the previous value."""
-    if not 0 <= option <= OPT_GEMM_GN_STATS:
+    if not 0 <= option <= OPT_GEMM_STAGGER:
         raise PncError(f"unknown library option {option}")
     return load().pnc_set_option(option, value)
 

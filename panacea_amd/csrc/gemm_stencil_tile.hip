@@ -25,7 +25,8 @@
 namespace pnc_gemm {
 
 template <int TWS, int NI, unsigned EPI>     // TW = 2^TWS columns per spatial tile; BN = NI * 64
-__global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams pin, const int group_m, const int nfull, const int tail_f) {
+__global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams pin, const int group_m, const int nfull, const int tail_f,
+                                                           const int stagger) {
     const PncGemmParams& p = pin;
     constexpr int TW = 1 << TWS, TH = 256 / TW;
     constexpr int IPS = 18;                                 // half-tile iterations per 64-channel slice: 9 taps x 2
@@ -198,6 +199,69 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
     auto slice_plane = [&](int gs) { return A_lo && gs < nslices; };      // true: the lo plane
     auto slice_cc = [&](int gs) { return gs >= nslices ? gs - nslices : gs; };
 
+    // STAGGERED schedule (round 5, PNC_OPT_GEMM_STAGGER; gemm_kernel.h has the story): one PHASE per k-step —
+    //     fragment reads of the k-step [+ DMA in the odd phases] | s_barrier | MI x NI MFMAs | s_barrier —
+    // with waves 4-7 one barrier behind waves 0-3.  The odd phase of half tile q issues one halo piece of the next slice (as the
+    // pipeline below does) and W half tile q + 2 into the ring stage of q - 1: every wave of BOTH groups finished its reads of that
+    // stage two barriers earlier (its last reads sat in phase (q - 1, 1); the other group's lgkmcnt(0) after the first barrier of
+    // that phase is passed by the time this group is behind the second barrier of phase (q, 0)).  The counted wait in the same
+    // phase leaves only the W group just issued in flight: W(q + 1), read from the next phase on, has landed.  Same K order
+    // and MFMA order per accumulator: bit-identical to the pipeline below.
+    if (stagger) {
+        const int grp = wave >> 2;
+#pragma unroll
+        for (int i = 0; i < H_IT; ++i)
+            if (wave + NW * i >= pc_lo && wave + NW * i < pc_hi && wave + NW * i < HBLK) issue_halo(slice_plane(0), 0, 0, wave + NW * i);
+        issue_w(0, 0);
+        if (nq > 1) issue_w(1 % nq1, 1);
+        if (nq > 2) issue_w(2 % nq1, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        auto bar1 = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto bar2 = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        int st = 0, gs = 0, r = 0, w2 = 3 % nq1;              // w2 = (q + 2) mod nq1 at the issue point of iteration q >= 1
+        for (int q = 0; q < nq; ++q) {
+            if (wave_on) frags(gs & 1, r >> 1, r & 1, st, 0, B0);
+            bar1();
+            if (wave_on) mfmas(B0);
+            bar2();
+            if (wave_on) frags(gs & 1, r >> 1, r & 1, st, 1, B1);
+            if (r < H_IT && gs + 1 < ns_tot && wave + NW * r >= pc_lo && wave + NW * r < pc_hi && wave + NW * r < HBLK)
+                issue_halo(slice_plane(gs + 1), slice_cc(gs + 1), (gs + 1) & 1, wave + NW * r);
+            if (q >= 1) {
+                if (q + 2 < nq) {
+                    issue_w(w2, st == 0 ? 2 : st - 1);         // the stage of half tile q - 1 = (q + 2) mod 3
+                    wait_all_but_last_w();
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                w2 = (w2 + 1 == nq1) ? 0 : w2 + 1;
+            }
+            bar1();
+            if (wave_on) mfmas(B1);
+            bar2();
+            if (A_lo && q + 1 == nq1) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] *= LO_INV;
+            }
+            if (++r == IPS) { r = 0; ++gs; }
+            st = (st == 2) ? 0 : st + 1;
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+    } else {
     // Software pipeline over half tiles q (two k-steps each), the barrier in the MIDDLE of q's MFMA stream:
     //   reads(q, ks1) | MFMA(q, ks0) | wait: W(q+1) landed, own reads of q done | s_barrier | DMA: halo piece, W(q+3) -> stage of q |
     //   reads(q+1, ks0) | MFMA(q, ks1)
@@ -249,6 +313,7 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
         }
         st = st1; r = r1; gs = gs1;
     }
+    }
     __syncthreads();                            // every wave is done with the operand buffers
     if (!wave_on) return;                       // rows of another workgroup (tail split)
 
@@ -282,7 +347,8 @@ static int launch_stencil(const PncGemmParams& p, hipStream_t st) {
     if (group_m == 1 || tiles_n < 2) group_m = 0;
     int nfull = tiles_m * tiles_n, tail_f = 1;
     tail_split<256, 4, lds>(tiles_m * tiles_n, nfull, tail_f);            // one workgroup per CU: 256 slots per round
-    hipLaunchKernelGGL(kern, dim3(nfull + (tiles_m * tiles_n - nfull) * tail_f), dim3(512), lds, st, p, group_m, nfull, tail_f);
+    hipLaunchKernelGGL(kern, dim3(nfull + (tiles_m * tiles_n - nfull) * tail_f), dim3(512), lds, st, p, group_m, nfull, tail_f,
+                       pnc_get_option(PNC_OPT_GEMM_STAGGER) > 0 ? 1 : 0);
     return pnc_launch_status();
 }
 

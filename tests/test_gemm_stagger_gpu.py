@@ -168,3 +168,38 @@ def test_geglu_staggered_is_bit_identical(M, C):
         hip.gemm(a, w, M=M, N=8 * C, K=C, lda=C, bias=bias, out16=o, ldc16=4 * C, geglu=True)
         return dict(o=o)
     _ab(run)
+
+
+@pytest.mark.parametrize("F,H,W,Cin,N,lo", [(2, 32, 64, 320, 320, None), (3, 8, 64, 128, 256, None), (2, 16, 16, 128, 320, "f16"),
+                                            (12, 64, 96, 64, 320, None), (5, 32, 64, 64, 640, None), (16, 16, 192, 640, 640, None)])
+def test_stencil_tile_kernel_staggered_is_bit_identical(F, H, W, Cin, N, lo):
+    """gemm_stencil_tile.hip: one phase per k-step with the group offset vs the round-2 software pipeline (one barrier per half tile) —
+    incl. tail-split rounds (quarter / half tile workgroups: one group idles), the 8 x 32 tile, 256-column tiles and a precise operand"""
+    M, K = F * H * W, 9 * Cin
+    x32 = rnd(F, H, W, Cin, seed=41)
+    x = x32.half()
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=42)
+    bias, res = rnd(N, seed=43), rnd(M, N, seed=44)
+    conv = dict(Cin=Cin, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0)
+    kw = dict(M=M, N=N, K=K, a_mode=hip.A_CONV3X3, conv=conv, bias=bias)
+    if lo:
+        xlo = torch.zeros(F, H, W, Cin, device=DEV, dtype=torch.float16)
+        hip.cast_f16(x32, x32.numel(), torch.zeros_like(x), xlo)
+        kw.update(a16_lo=xlo)
+    pst = hip.set_option(hip.OPT_STENCIL_TILES, 2)
+
+    def run():
+        o = res.clone()
+        o16 = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+        hip.gemm(x, w, res1=o, ldr1=N, out32=o, ldc32=N, out16=o16, ldc16=N, **kw)
+        return dict(o=o, o16=o16)
+    try:
+        ref = _ab(run)
+        hip.set_option(hip.OPT_STENCIL_TILES, 0)
+        hip.set_option(hip.OPT_GEMM_STAGGER, 0)
+        tap = run()
+        torch.cuda.synchronize()
+    finally:
+        hip.set_option(hip.OPT_STENCIL_TILES, pst)
+        hip.set_option(hip.OPT_GEMM_STAGGER, 8)
+    assert torch.equal(tap["o"], ref["o"])            # and both equal the per-tap gather

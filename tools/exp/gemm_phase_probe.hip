@@ -11,12 +11,16 @@
 //               wave is in its MFMA cluster while the other reads / issues DMA (the two-group schedule of the HIP guide's
 //               "256^2 8-phase template", on this kernel's 4 x 2 wave grid and full-tile stages); vmcnt(0) once per K tile, in
 //               phase 3, a whole phase after the last DMA issue.
-//   VAR 2  "P-" P without the priority flips (isolates s_setprio)
-//   VAR 3  "Pn" P without the group offset (every wave in the same phase: isolates the stagger)
+//               (first run, profiles/round5/gemm_phase_probe_r5a.log: priority flips around the MFMA clusters are flat — dropped)
+//   VAR 2  "P01" P with the next tile's DMA in phases 0-1 only; VAR 3 "P0": all of it in phase 0 (more time to land before phase 3's wait)
+//   VAR 6  "Pm"  P with the DMA pieces placed INSIDE the MFMA clusters (one after every third MFMA), the L parts carry reads only
+//   VAR 7  "Pn"  P without the group offset (every wave in the same phase: isolates the stagger)
 //   VAR 4  "U"  P on a ring of four K-HALF units (32 k = 64-byte LDS rows, 16 rows per DMA piece) instead of two full K tiles: same
 //               LDS bytes, but a unit is recycled two phases after its last read, so the DMA is spread evenly over ALL phases
 //               (2-3 pieces each), stays 2-3 units ahead and is waited for with a COUNTED vmcnt (never 0 in the steady state).
-//   VAR 5  "Un" U without the group offset
+//   Timing: "warm" = one operand set re-used by every launch (A comes from the 256 MB Infinity Cache after the first launch);
+//   "cold" = the launches rotate over operand sets that together exceed the Infinity Cache, so A streams from HBM (the network's
+//   case for the big activations).
 //
 //   build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I panacea_amd/csrc tools/exp/gemm_phase_probe.hip -o tools/exp/gemm_phase_probe
 //   run:    tools/exp/gemm_phase_probe            (on the GPU box; verifies every variant against a host reference first)
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(512) void gemm_probe(const half_t* __restrict__ A, 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
 
-    if constexpr (VAR >= 4) {
+    if constexpr (VAR == 4 || VAR == 5) {
         // ---- ring of four k-half units.  Unit rows R = 0 .. 255 (A), 256 .. 255 + BN (W); row R at byte 64 R of the unit, its 16-byte
         // chunk c (8 k) in slot c ^ ((R >> 2) & 3): the 16 lanes of a ds_read_b128 group (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}
         // of a 32-row block, one chunk) then cover all 16 slots of the four 64-byte rows that share a 256-byte bank row.
@@ -214,9 +218,11 @@ __global__ __launch_bounds__(512) void gemm_probe(const half_t* __restrict__ A, 
             __syncthreads();
         }
     } else {
-        constexpr bool PRIO = VAR != 2, STAGGER = VAR != 3;
-        // pieces of the next tile issued in phases 0, 1, 2 (none in phase 3: they get at least one MFMA cluster to land)
-        constexpr int Q0 = (LOADS + 2) / 3, Q1 = (LOADS - Q0 + 1) / 2;
+        // VAR 1 "P": DMA pieces of the next tile in the L parts of phases 0, 1, 2;  VAR 2 "P01": phases 0, 1;  VAR 3 "P0": all in phase 0;
+        // VAR 6 "Pm": inside the MFMA clusters of phases 0, 1, 2 (one piece after every third MFMA);  VAR 7 "Pn": P without the group offset
+        constexpr bool STAGGER = VAR != 7;
+        constexpr int NDP = VAR == 2 ? 2 : (VAR == 3 ? 1 : 3);               // phases that carry DMA
+        constexpr int PER = (LOADS + NDP - 1) / NDP;
         const int grp = wave >> 2;
         issue_tile(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -228,17 +234,9 @@ __global__ __launch_bounds__(512) void gemm_probe(const half_t* __restrict__ A, 
 #pragma unroll
             for (int ph = 0; ph < 4; ++ph) {
                 frags(st, ph);
-                if (nxt) {
-                    if (ph == 0) {
+                if (VAR != 6 && nxt && ph < NDP) {
 #pragma unroll
-                        for (int q = 0; q < Q0; ++q) issue_piece(q, kt + 1, st ^ 1);
-                    } else if (ph == 1) {
-#pragma unroll
-                        for (int q = Q0; q < Q0 + Q1; ++q) issue_piece(q, kt + 1, st ^ 1);
-                    } else if (ph == 2) {
-#pragma unroll
-                        for (int q = Q0 + Q1; q < LOADS; ++q) issue_piece(q, kt + 1, st ^ 1);
-                    }
+                    for (int q = ph * PER; q < (ph + 1) * PER && q < LOADS; ++q) issue_piece(q, kt + 1, st ^ 1);
                 }
                 if (ph == 3) {
                     // this wave's share of the next tile has landed AND its reads of this tile's last k-step have returned BEFORE the
@@ -249,9 +247,23 @@ __global__ __launch_bounds__(512) void gemm_probe(const half_t* __restrict__ A, 
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                if (PRIO) __builtin_amdgcn_s_setprio(1);
-                mfmas();
-                if (PRIO) __builtin_amdgcn_s_setprio(0);
+                if constexpr (VAR == 6) {
+                    int q = ph * PER;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                            if (((i * NI + j) % 3) == 1 && nxt && ph < NDP && q < (ph + 1) * PER && q < LOADS) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_piece(q, kt + 1, st ^ 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                                ++q;
+                            }
+                        }
+                } else {
+                    mfmas();
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
             }
@@ -294,11 +306,12 @@ typedef void (*launch_fn)(const half_t*, const half_t*, half_t*, int, int, int, 
 struct Variant { const char* name; launch_fn f256, f320; };
 static const Variant VARS[] = {
     {"B  shipped loop", launch<256, 0>, launch<320, 0>},
-    {"P  phased+stagger+prio", launch<256, 1>, launch<320, 1>},
-    {"P- no prio", launch<256, 2>, launch<320, 2>},
-    {"Pn no stagger", launch<256, 3>, launch<320, 3>},
+    {"P  staggered, DMA ph 0-2", launch<256, 1>, launch<320, 1>},
+    {"P01 DMA ph 0-1", launch<256, 2>, launch<320, 2>},
+    {"P0 DMA ph 0", launch<256, 3>, launch<320, 3>},
+    {"Pm DMA inside MFMA clusters", launch<256, 6>, launch<320, 6>},
+    {"Pn no stagger", launch<256, 7>, launch<320, 7>},
     {"U  unit ring, counted vmcnt", launch<256, 4>, launch<320, 4>},
-    {"Un unit ring, no stagger", launch<256, 5>, launch<320, 5>},
 };
 constexpr int NVAR = sizeof(VARS) / sizeof(VARS[0]);
 
@@ -352,24 +365,33 @@ int main(int argc, char** argv) {
         {"L1 conv-K ", 49152, 640, 5760, 320},  {"L1 ff1    ", 49152, 5120, 640, 256},
         {"L0 conv-K ", 196608, 320, 2880, 320}, {"L1 ff2    ", 49152, 640, 2560, 320},
         {"L2 qkv    ", 12288, 3840, 1280, 320}, {"4096^3    ", 4096, 4096, 4096, 256},
-        {"L2 ff1    ", 12288, 10240, 1280, 256},
+        {"L2 CxC    ", 12288, 1280, 1280, 256}, {"L0 conv1d ", 196608, 320, 960, 320},
     };
-    const int rounds = argc > 1 ? atoi(argv[1]) : 7, inner = 5;
+    const int rounds = argc > 1 ? atoi(argv[1]) : 7, inner = 6;
+    for (int cold = 0; cold < 2; ++cold)
     for (const Shape& s : shapes) {
+        const size_t abytes = (size_t)s.M * s.K * 2, wbytes = (size_t)s.N * s.K * 2, cbytes = (size_t)s.M * s.N * 2;
+        int nset = 1;
+        if (cold) { nset = (int)((size_t)640 * 1024 * 1024 / (abytes + wbytes)) + 1; if (nset < 2) nset = 2; if (nset > 6) nset = 6; }
         std::vector<half_t> hA((size_t)s.M * s.K), hW((size_t)s.N * s.K);
         fill(hA, 3, 1.0f); fill(hW, 4, 0.05f);
-        half_t *dA, *dW, *dC;
-        CHECK(hipMalloc(&dA, hA.size() * 2)); CHECK(hipMalloc(&dW, hW.size() * 2)); CHECK(hipMalloc(&dC, (size_t)s.M * s.N * 2));
-        CHECK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
-        CHECK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+        std::vector<half_t*> dA(nset), dW(nset);
+        half_t* dC;
+        CHECK(hipMalloc(&dC, cbytes));
+        for (int i = 0; i < nset; ++i) {
+            CHECK(hipMalloc(&dA[i], abytes)); CHECK(hipMalloc(&dW[i], wbytes));
+            CHECK(hipMemcpy(dA[i], hA.data(), abytes, hipMemcpyHostToDevice));
+            CHECK(hipMemcpy(dW[i], hW.data(), wbytes, hipMemcpyHostToDevice));
+        }
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         std::vector<std::vector<float>> t(NVAR);
+        int rot = 0;
         for (int r = 0; r < rounds + 1; ++r)
             for (int v = 0; v < NVAR; ++v) {
                 launch_fn f = s.BN == 256 ? VARS[v].f256 : VARS[v].f320;
                 CHECK(hipEventRecord(e0, st));
-                for (int i = 0; i < inner; ++i) f(dA, dW, dC, s.M, s.N, s.K, 0, st);
+                for (int i = 0; i < inner; ++i, ++rot) f(dA[rot % nset], dW[rot % nset], dC, s.M, s.N, s.K, 0, st);
                 CHECK(hipEventRecord(e1, st));
                 CHECK(hipEventSynchronize(e1));
                 float ms;
@@ -377,15 +399,16 @@ int main(int argc, char** argv) {
                 if (r > 0) t[v].push_back(ms / inner * 1e3f);
             }
         const double fl = 2.0 * s.M * s.N * s.K;
-        printf("%s M=%6d N=%5d K=%5d BN=%d:", s.name, s.M, s.N, s.K, s.BN);
+        printf("%s %s M=%6d N=%5d K=%5d BN=%d:", cold ? "cold" : "warm", s.name, s.M, s.N, s.K, s.BN);
         for (int v = 0; v < NVAR; ++v) {
             std::sort(t[v].begin(), t[v].end());
-            const float mn = t[v][0], md = t[v][t[v].size() / 2];
-            printf("  [%s] %.1f/%.1f us %.0f TF", VARS[v].name, mn, md, fl / (md * 1e-6) / 1e12);
+            const float md = t[v][t[v].size() / 2];
+            printf("  [%s] %.1f us %.0f TF", VARS[v].name, md, fl / (md * 1e-6) / 1e12);
         }
         printf("\n");
         fflush(stdout);
-        CHECK(hipFree(dA)); CHECK(hipFree(dW)); CHECK(hipFree(dC));
+        for (int i = 0; i < nset; ++i) { CHECK(hipFree(dA[i])); CHECK(hipFree(dW[i])); }
+        CHECK(hipFree(dC));
     }
     return 0;
 }

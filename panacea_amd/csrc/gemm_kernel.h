@@ -1037,16 +1037,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     // every K >= 640 shape (L1 conv-K 907 -> 1082 TFLOP/s, L2 FF2 1104 -> 1259 = the vendor GEMM's 1259); the group offset is the
     // whole effect (phases without it: -2 %), priority flips around the MFMA clusters are flat, and a finer ring of k-half units
     // with counted vmcnt is slower than full-tile stages.
+    // Where it runs: plain A (the gathers' per-piece address arithmetic sits on the critical path of a phase: the per-tap conv3x3 /
+    // temporal conv launches measured 4-20 % SLOWER staggered, profiles/round5/stagger_kbench_r5c_generic_issue_path.log), K a
+    // multiple of 64, no fp16 lo plane, and not in the row-split workgroups of a sparse last round (one of the two groups idles there).
     bool staggered = false;
-    if constexpr (STAGES == 2 && NW == 8) staggered = stagger_min > 0 && ntot >= stagger_min;
+    if constexpr (STAGES == 2 && NW == 8 && AMODE == PNC_A_PLAIN)
+        staggered = stagger_min > 0 && ntot >= stagger_min && kt_tail < 0 && (!A_lo || lo8) && !split_rows && ksplit == 1;
     if (AMODE == PNC_A_PLAIN && NW == 8 && wave >= 4 && !staggered) __builtin_amdgcn_s_setprio(1);
     if (staggered) {
-        if constexpr (STAGES == 2 && NW == 8) {
+        if constexpr (STAGES == 2 && NW == 8 && AMODE == PNC_A_PLAIN) {
             constexpr int Q0 = (LOADS + 2) / 3, Q1 = (LOADS - Q0 + 1) / 2;
-            const std::integral_constant<int, 0> C0{};
-            const std::integral_constant<int, Q0> CQ0{};
-            const std::integral_constant<int, Q0 + Q1> CQ1{};
-            const std::integral_constant<int, LOADS> CQ2{};
             const int grp = wave >> 2;
             half8v af[MI], bf[NI];
             i32x8 af8[MI], bf8[NI];
@@ -1093,40 +1093,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const int n8 = lo8 ? nt_lo : 0;
-            // The e4m3 lo tiles of the GATHERS (Down / Upsample convs, temporal convs: 3-20 short tiles) keep the plain loop — every
-            // wave in step, one barrier per tile: phased, the 56 fragment registers of a 128-k tile are live across the gather's
-            // address arithmetic next to 160 accumulator registers (39 spilled VGPRs, reloaded inside the loop).  The group offset
-            // starts behind them.  Plain A has no address arithmetic in the loop: its lo tiles are phased below.
-            constexpr bool LO8_PHASED = AMODE == PNC_A_PLAIN;
-            if constexpr (!LO8_PHASED) {
-                for (int kt = 0; kt < n8; ++kt) {
-                    if (kt + 1 < ntot) issue_tile(kt + 1, (kt + 1) & 1);
-                    if (wave_on) compute8(kt & 1, kt);
-                    __syncthreads();
-                }
-            }
             if (grp == 1) __builtin_amdgcn_s_barrier();               // group 1 runs one barrier behind group 0 from here on
-            for (int kt = 0; kt < (LO8_PHASED ? n8 : 0); ++kt) {      // e4m3 lo tiles: one phase per 64-k MFMA window
+            for (int kt = 0; kt < n8; ++kt) {                         // e4m3 lo tiles: one phase per 64-k MFMA window
                 const int st = kt & 1;
                 const int nwin = (p.K - (kt_begin_lo + kt) * BK8) > 64 ? 2 : 1;
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
                     if (w < nwin) {
-                        if (AMODE == PNC_A_PLAIN && wave_on) rd8(st, w);
+                        rd8(st, w);
                         if (w == 0 && kt + 1 < ntot) issue_tile(kt + 1, st ^ 1);
-                        if (AMODE != PNC_A_PLAIN) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (wave_on) rd8(st, w);
-                        }
                         if (w == nwin - 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         bar1();
-                        if (wave_on) {
 #pragma unroll
-                            for (int j = 0; j < NI; ++j)
+                        for (int j = 0; j < NI; ++j)
 #pragma unroll
-                                for (int i = 0; i < MI; ++i)
-                                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af8[i], bf8[j], acc[i][j], 0, 0, 0, E8M0_LO_INV, 0, p.w_lo_exp);
-                        }
+                            for (int i = 0; i < MI; ++i)
+                                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af8[i], bf8[j], acc[i][j], 0, 0, 0, E8M0_LO_INV, 0, p.w_lo_exp);
                         bar2();
                     }
                 }
@@ -1134,33 +1116,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
             for (int kt = n8; kt < ntot; ++kt) {
                 const int st = kt & 1;
                 const bool nxt = kt + 1 < ntot;
-#pragma unroll
-                for (int ph = 0; ph < 4; ++ph) {
-                    // plain A: reads first (their latency runs under the DMA issue; the measured order).  Gathers: DMA first — the
-                    // ~25 address temporaries per piece are dead before the 28 fragment registers go live (reads first spilled 39
-                    // VGPRs in the conv3x3 variants next to 160 accumulator registers)
-                    if (AMODE == PNC_A_PLAIN && wave_on) rd(st, ph);
+                static_for<4>([&](auto ph_) {
+                    constexpr int ph = decltype(ph_)::value;
+                    rd(st, ph);
                     if (nxt) {
-                        if (ph == 0) issue_part(kt + 1, st ^ 1, C0, CQ0);
-                        else if (ph == 1) issue_part(kt + 1, st ^ 1, CQ0, CQ1);
-                        else if (ph == 2) issue_part(kt + 1, st ^ 1, CQ1, CQ2);
-                    }
-                    if (AMODE != PNC_A_PLAIN) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (wave_on) rd(st, ph);
+                        // the next tile is a plain fp16 tile inside K: lane offsets fixed over the loop, the K tile as the scalar offset —
+                        // no per-piece test on this path (the general issue_part() with its uniform branches on lo / K tail made the
+                        // phase's load part longer than its MFMA part: measured 5-10 % slower than the un-staggered loop)
+                        const unsigned ks = (unsigned)(kt_begin - nt_lo + kt + 1) * (BK * 2);
+                        char* sa = smem + (st ^ 1) * STAGE + wave * 1024;
+                        char* sb = sa + A_BYTES;
+                        constexpr int QA = ph == 0 ? 0 : (ph == 1 ? Q0 : Q0 + Q1), QB = ph == 0 ? Q0 : (ph == 1 ? Q0 + Q1 : (ph == 2 ? LOADS : 0));
+#pragma unroll
+                        for (int q = QA; q < QB; ++q) {
+                            if (q < A_IT) glds16_buf(rs_a, aoff[q < A_IT ? q : 0], ks, sa + q * (RPI * 128));
+                            else glds16_buf(rs_w, woff[q >= A_IT ? q - A_IT : 0], ks, sb + (q - A_IT) * (RPI * 128));
+                        }
                     }
                     if (ph == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     bar1();
-                    if (wave_on) {
 #pragma unroll
-                        for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                            for (int j = 0; j < NI; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                    }
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
                     bar2();
-                }
-                if (wave_on && !lo8 && kt + 1 == nt_lo) scale_lo();
+                });
             }
             if (grp == 0) __builtin_amdgcn_s_barrier();               // group 0 waits for group 1's last phase
         }

@@ -230,13 +230,14 @@ def test_full_size_properties_and_golden(full_net):
 
 # Round 5 (VERDICT r4 weak spot 2): every earlier pin used ONE synthetic weight draw (salt 0) whose residual stream stays far below the
 # |v| = 512 where the e4m3 lo plane of an fp16-rounded operand clamps (include/panacea_hip.h).  Two more pins of the reference's own
-# forward (oracle/gen_golden_full.py --t 500 --wsalt 1 / --wtail 256): a second weight draw, and a heavy-tailed weight set whose
-# "massive activation" channels (synth.synth_tensor: output rows c % 64 == 5 of every residual-out tensor x 256) carry the stream
-# into the clamp range.  TAIL_GATE is the bound the network states for that regime (UNetModel3D.eps_contract_heavy_tail).
+# forward (oracle/gen_golden_full.py --t 500 --wsalt 1 / --wtail 16): a second weight draw, and a heavy-tailed weight set whose
+# "massive activation" channels (synth.synth_tensor: output rows c % 64 == 5 of every residual-out tensor x 16) carry the stream
+# into the clamp range (|v| 512 .. ~2000; a first attempt with gain 256 put the stream at 2.3e4 and an fp16 operand beyond 65504:
+# non-finite eps — an fp16 path's own range limit, stated in UNetModel3D.eps_contract).  TAIL_GATE is the bound asserted there.
 TAIL_GATE = 1.0e-3
 
 
-@pytest.mark.parametrize("fname,wsalt,wtail", [("full_cfg3_t500_w1.npz", 1, 0.0), ("full_cfg3_t500_tail256.npz", 0, 256.0)])
+@pytest.mark.parametrize("fname,wsalt,wtail", [("full_cfg3_t500_w1.npz", 1, 0.0), ("full_cfg3_t500_tail16.npz", 0, 16.0)])
 def test_full_size_other_weight_sets(full_net, fname, wsalt, wtail):
     from panacea_amd import synth
     path = GOLDEN / fname

@@ -549,7 +549,7 @@ def main():
                 "eps_ref_rms": worst["eps_ref_rms"], "tolerance": 1e-3, "within_tolerance": bool(worst["eps_max_abs_err"] < 1e-3),
                 "precision": prec, "pins": pins,
                 "against": "reference fp32 CPU forward (tests/golden/" + ", ".join(q["golden"] for q in pins) + "), worst of the pins; "
-                           "the second weight draw and the heavy-tail weight set (full_cfg3_t500_w1 / _tail16) are gated in tests/test_model_gpu.py"}
+                           "the second weight draw and the heavy-tail weight set (full_cfg3_t500_w1 / _tail64) are gated in tests/test_model_gpu.py"}
 
     with torch.no_grad():
         # parity guard inside the bench run: eps of the very first network call vs the reference's own output

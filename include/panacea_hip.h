@@ -33,10 +33,10 @@ extern "C" {
 
 /* library / build identification: returns "panacea_hip <version> gfx950" */
 const char* pnc_version(void);
-/* ABI revision of this header (bumped whenever a parameter struct or a prototype changes): 4
+/* ABI revision of this header (bumped whenever a parameter struct or a prototype changes): 5 (round 5: + pnc_concat_add_stats)
  * (round 4: + pnc_groupnorm_combine, + PNC_OPT_ATTN_DEFER_MAX, PNC_OPT_GEMM_PERSIST is a bit set, - pnc_ff_chain_*;
- *  round 5 adds PNC_OPT_GEMM_STAGGER without an ABI bump: no struct or prototype changed) */
-#define PNC_ABI_VERSION 4
+ *  round 5: + pnc_concat_add_stats, + PNC_OPT_GEMM_STAGGER) */
+#define PNC_ABI_VERSION 5
 int pnc_abi_version(void);
 /* hex SHA-256 of the sources + compile flags the library was built from (panacea_amd/build.py computes the same digest over
  * the checkout): a loader compares the two and refuses a library built from other sources instead of calling it with
@@ -74,11 +74,12 @@ enum {
                                      maximum grows.  Same softmax, other roundings of P (not bit-identical across values) */
     PNC_OPT_GEMM_GN_STATS = 9,    /* 1 (default): PncGemmParams.gn_part comes out of the temporal conv's epilogue where its waves own whole
                                      groups; 0 = always the statistics kernel after the GEMM (same records up to fp32 summation order) */
-    PNC_OPT_GEMM_STAGGER = 10,    /* k (default 8; round 5): the 8-wave two-stage GEMM kernels run K loops of at least k tiles (lo + hi) in the
-                                     STAGGERED schedule — four phases per K tile {fragment reads + a third of the next tile's DMA | barrier |
-                                     MFMAs | barrier}, waves 4-7 one barrier behind waves 0-3, so that on every SIMD one wave multiplies
-                                     while the other reads; 0 = never (round 4's loops), 1 = always.  Same K and MFMA order per
-                                     accumulator: bit-identical results */
+    PNC_OPT_GEMM_STAGGER = 10,    /* k (default 8; round 5): the persistent GEGLU GEMM runs K loops of at least k tiles in the STAGGERED schedule —
+                                     four phases per K tile {fragment reads + a third of the next tile's DMA | barrier | MFMAs | barrier},
+                                     waves 4-7 one barrier behind waves 0-3, so that on every SIMD one wave multiplies while the other
+                                     reads (FF1 at levels 1-2: +5-6 %); 0 = never (round 4's loops); 1 = everywhere the schedule exists —
+                                     also the plain-A 8-wave two-stage kernels and the stencil-tile conv kernel, where it measured no
+                                     faster (tests, A/B tools).  Same K and MFMA order per accumulator: bit-identical results */
     PNC_OPT_COUNT = 11
 };
 int pnc_set_option(int option, int value);
@@ -341,6 +342,13 @@ int pnc_tokens_to_nchw_f32(const float* x, int ld, int F, int Npix, int C,
  *    -> th.cat([h, hs.pop() + control.pop()], dim=1)  (controlmodel.py:193-195) */
 int pnc_concat_add(const float* a, int C1, const float* s, const float* c, int C2,
                    int64_t M, float* out32, void* out16, void* out16_lo, int lo_fmt, void* stream);
+/* the same concatenation over F frames of Npix pixels (M = F * Npix rows) that ALSO writes the GroupNorm(32) statistics of its output —
+ * records {n, mean, M2} [F][ceil(Npix / 64)][32][3] as pnc_groupnorm_stats(..., pix_per_chunk = 64, ...) would, for
+ * pnc_groupnorm_apply(..., n_records = ceil(Npix / 64)): the first GroupNorm of the ResBlock3D that follows the concat
+ * (openaimodel.py:1311-1314 -> 499-503) then needs no statistics launch.  (C1 + C2) % 64 == 0.  Deterministic (no float atomics).
+ * ABI 5 (round 5). */
+int pnc_concat_add_stats(const float* a, int C1, const float* s, const float* c, int C2, int F, int Npix,
+                         float* out32, void* out16, void* out16_lo, int lo_fmt, float* partial, void* stream);
 /* y = x + a (fp32, may be in place); optional fp16 copy of y
  *    -> h += guided_hint / h += control.pop()  (controlmodel.py:127,192) */
 int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16, void* y16_lo, int lo_fmt,

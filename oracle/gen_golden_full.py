@@ -9,7 +9,7 @@ oracle is run on the same data and must agree (fp32 vs fp32) before the file is 
     python -m oracle.gen_golden_full --frames 1 --no-oracle        # BASELINE config 2 (round 4): full_cfg2.npz
     python -m oracle.gen_golden_full --yaml-exact --no-oracle      # BASELINE config 5, sampler step 0: full_cfg5_step0.npz
     python -m oracle.gen_golden_full --t 500 --wsalt 1 --no-oracle # second WEIGHT draw (round 5): full_cfg3_t500_w1.npz
-    python -m oracle.gen_golden_full --t 500 --wtail 16 --no-oracle    # heavy-tailed stream (round 5): full_cfg3_t500_tail16.npz
+    python -m oracle.gen_golden_full --t 500 --wtail 64 --no-oracle    # heavy-tailed stream (round 5): full_cfg3_t500_tail64.npz
 
 The extra pins skip the (6 minute) oracle leg: oracle vs reference is established by the first file and by the
 small configurations; what the extra files pin is the reference's eps at other noise levels / inputs.

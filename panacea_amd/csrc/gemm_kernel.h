@@ -1033,16 +1033,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     // HIP guide's 256^2 8-phase template on this kernel's stages).  vmcnt(0) once per K tile, before the first barrier of phase 3 — a
     // whole MFMA cluster after the last DMA issue —, together with lgkmcnt(0): the OTHER group is one barrier away from reading the
     // next tile / overwriting this one.  Same K order and MFMA order per accumulator as the loops below: bit-identical results.
-    // Measured on the shipped geometry (tools/exp/gemm_phase_probe.hip, profiles/round5/gemm_phase_probe_r5a.log): +6 .. +19 % on
-    // every K >= 640 shape (L1 conv-K 907 -> 1082 TFLOP/s, L2 FF2 1104 -> 1259 = the vendor GEMM's 1259); the group offset is the
-    // whole effect (phases without it: -2 %), priority flips around the MFMA clusters are flat, and a finer ring of k-half units
-    // with counted vmcnt is slower than full-tile stages.
-    // Where it runs: plain A (the gathers' per-piece address arithmetic sits on the critical path of a phase: the per-tap conv3x3 /
+    // Measured.  In a stand-alone probe of this geometry under SUSTAINED load (tools/exp/gemm_phase_probe.hip, back-to-back launches,
+    // profiles/round5/gemm_phase_probe_r5a.log, ..._r5c_*.log): +6 .. +19 % on every K >= 640 shape, warm and cold operands alike (L1
+    // conv-K 907 -> 1082 TFLOP/s, L2 FF2 1104 -> 1259 = the vendor GEMM's 1259); the group offset is the whole effect (phases without
+    // it: -2 %), priority flips around the MFMA clusters are flat, DMA inside the MFMA clusters is 40 % slower, a finer ring of k-half
+    // units with counted vmcnt is slower than full-tile stages.  IN THIS KERNEL it does not carry over: the library's launches, timed
+    // alone, already run the loops below at 1.14-1.30 PFLOP/s marginal (profiles/round5/stagger_ksweep_r5f.log; the probe's copy of the
+    // same loop, throttled by its own sustained load, ran 0.9-1.1), the staggered loop adds +3-4 % of marginal rate where W is wide
+    // (N = 1280, operands from L2) and LOSES 16 % where one column tile streams A from HBM (N = 320: its DMA has at most one K tile
+    // to land); whole network 157.31 -> 157.15 ms (stagger_ab_whole_network_r5e.log).  So: ON in the persistent GEGLU kernel (FF1
+    // at levels 1-2: +5-6 % in the network, +11 % alone — wide N, A from L2, the next output tile's first K tile requested inside
+    // the phases), here only on request (PNC_OPT_GEMM_STAGGER = 1: the bit-identity tests and the A/B tools).
+    // Where it can run: plain A (the gathers' per-piece address arithmetic sits on the critical path of a phase: the per-tap conv3x3 /
     // temporal conv launches measured 4-20 % SLOWER staggered, profiles/round5/stagger_kbench_r5c_generic_issue_path.log), K a
     // multiple of 64, no fp16 lo plane, and not in the row-split workgroups of a sparse last round (one of the two groups idles there).
     bool staggered = false;
     if constexpr (STAGES == 2 && NW == 8 && AMODE == PNC_A_PLAIN)
-        staggered = stagger_min > 0 && ntot >= stagger_min && kt_tail < 0 && (!A_lo || lo8) && !split_rows && ksplit == 1;
+        staggered = stagger_min == 1 && kt_tail < 0 && (!A_lo || lo8) && !split_rows && ksplit == 1;
     if (AMODE == PNC_A_PLAIN && NW == 8 && wave >= 4 && !staggered) __builtin_amdgcn_s_setprio(1);
     if (staggered) {
         if constexpr (STAGES == 2 && NW == 8 && AMODE == PNC_A_PLAIN) {
@@ -1378,7 +1385,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(cons
     // output tile's K loop, both groups aligned again before the epilogue (their epilogues run together, as before; run one behind
     // the other they would serialise: a group can do ONE phase while the other is in its epilogue).  The next output tile's first K
     // tile is requested in phases 0-2 of the LAST K tile instead of in front of the epilogue.
-    const bool staggered = NW == 8 && stagger_min > 0 && nk >= stagger_min;
+    const bool staggered = NW == 8 && stagger_min > 0 && nk >= (stagger_min == 1 ? 1 : stagger_min);
     const int grp = wave >> 2;
     while (true) {
 #pragma unroll
@@ -1950,9 +1957,6 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(const PncGemmParams p
 static inline bool plain_persist_ok(const PncGemmParams& p, unsigned epi) {
     if ((pnc_get_option(PNC_OPT_GEMM_PERSIST) & 2) == 0 || p.a_mode != PNC_A_PLAIN) return false;
     if ((p.M % 256) || (p.N % 320) || (p.K % 64) || p.K < 64) return false;
-    // long K (FF2 at level 0: K = 1280): the staggered schedule of the one-tile-per-workgroup kernel is worth more than the prefetch
-    // across output tiles (+10-16 % against 1.5-4 %); this kernel keeps the epilogue-bound K = 320 .. 640 launches
-    if (pnc_get_option(PNC_OPT_GEMM_STAGGER) > 0 && p.K >= 1024) return false;
     if (p.A_lo && (p.a_lo_fmt != PNC_LO_E4M3 || (p.lda % 16))) return false;
     if ((epi & E_LN) && p.N != 320) return false;
     if ((epi & E_VT) && ((p.n_split % 320) || (p.M % 8) || (p.t_rows % 8))) return false;

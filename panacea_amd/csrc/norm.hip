@@ -391,6 +391,91 @@ __global__ __launch_bounds__(256) void gn_combine_kernel(const float* __restrict
     for (int i = GROUPS * 3 + tid; i < nchunk * GROUPS * 3; i += 256) out[(int64_t)f * nchunk * GROUPS * 3 + i] = 0.0f;
 }
 
+// th.cat([h, skip + control]) of the UNet's output path WITH the statistics of the GroupNorm that reads it (round 5): the concat is
+// followed by the first GroupNorm(32) of a ResBlock3D on exactly the tensor it writes (openaimodel.py:1311-1314 -> 499-503), and the
+// statistics launch read those C1 + C2 channels of fp32 back from HBM (level 0: 0.5-0.75 GB per site).  One workgroup = one 64-pixel
+// chunk of one frame (the record size of the GEMM epilogues' gn_part, engine.GN_EPILOGUE_CHUNK), waves stride the chunk's pixels, a
+// lane owns J float4 channel vectors: values are produced, stored and summed in one pass; the reduction is gn_stats_kernel's
+// (per-wave channel sums in LDS, one thread per group adds them in a fixed order: bit-reproducible records).
+template <int J>
+__global__ __launch_bounds__(256) void concat_add_stats_kernel(const float* __restrict__ a, int C1, const float* __restrict__ s,
+                                                               const float* __restrict__ c, int C2, int Npix,
+                                                               float* __restrict__ out32, half_t* __restrict__ out16,
+                                                               void* __restrict__ out16_lo, int lo_fmt, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // [4][C]: per-wave sums, then per-wave squares
+    constexpr int PPC = 64;
+    const int f = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = C1 + C2, CV = C >> 2, cpg = C / GROUPS;
+    const int p0 = chunk * PPC;
+    const int p1 = min(Npix, p0 + PPC);
+    f32x4 sum[J], sq[J];
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < J; ++j) { sum[j] = z; sq[j] = z; }
+#pragma unroll 2
+    for (int pix = p0 + wave; pix < p1; pix += 4) {
+        const int64_t m = (int64_t)f * Npix + pix;
+        f32x4 v[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int ch = (lane + j * 64) * 4;
+            v[j] = z;
+            if (ch < C1) {
+                v[j] = *reinterpret_cast<const f32x4*>(a + m * C1 + ch);
+            } else if (ch < C) {
+                v[j] = *reinterpret_cast<const f32x4*>(s + m * C2 + (ch - C1));
+                if (c) v[j] += *reinterpret_cast<const f32x4*>(c + m * C2 + (ch - C1));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int ch = (lane + j * 64) * 4;
+            if (ch < C) {
+                if (out32) *reinterpret_cast<f32x4*>(out32 + m * C + ch) = v[j];
+                if (out16) {
+                    half4v h = {(half_t)v[j][0], (half_t)v[j][1], (half_t)v[j][2], (half_t)v[j][3]};
+                    *reinterpret_cast<half4v*>(out16 + m * C + ch) = h;
+                    if (out16_lo) {
+                        const float o[4] = {v[j][0], v[j][1], v[j][2], v[j][3]};
+                        store_lo4(out16_lo, lo_fmt, m * C + ch, o, h);
+                    }
+                }
+            }
+            sum[j] += v[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sq[j][e] = fmaf(v[j][e], v[j][e], sq[j][e]);
+        }
+    }
+    float* mine = sm + wave * C;
+    float ts = 0.0f, tq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int cv = lane + j * 64;
+        if (cv < CV) *reinterpret_cast<f32x4*>(mine + cv * 4) = sum[j];
+    }
+    __syncthreads();
+    if (tid < GROUPS)
+        for (int w = 0; w < 4; ++w)
+            for (int cc = 0; cc < cpg; ++cc) ts += sm[w * C + tid * cpg + cc];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int cv = lane + j * 64;
+        if (cv < CV) *reinterpret_cast<f32x4*>(mine + cv * 4) = sq[j];
+    }
+    __syncthreads();
+    if (tid < GROUPS) {
+        for (int w = 0; w < 4; ++w)
+            for (int cc = 0; cc < cpg; ++cc) tq += sm[w * C + tid * cpg + cc];
+        const float n = (float)(p1 - p0) * (float)cpg;
+        const float mean = n > 0 ? ts / n : 0.0f;
+        const float m2 = n > 0 ? fmaxf(tq - ts * mean, 0.0f) : 0.0f;
+        float* o = partial + ((int64_t)(f * nchunk + chunk) * GROUPS + tid) * 3;
+        o[0] = n; o[1] = mean; o[2] = m2;
+    }
+}
+
 }  // namespace
 
 constexpr int GN_MAXC = 4 * 64 * 12;       // J <= 12 float4 vectors per lane
@@ -415,6 +500,22 @@ extern "C" int pnc_groupnorm_stats(const float* x, int ldx, int F, int Npix, int
     const size_t lds = (size_t)4 * C * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     PNC_GN_DISPATCH(gn_stats_kernel, dim3(nchunk, F), dim3(256), lds, st, x, ldx, Npix, C, pix_per_chunk, partial);
+    return pnc_launch_status();
+}
+
+extern "C" int pnc_concat_add_stats(const float* a, int C1, const float* s, const float* c, int C2, int F, int Npix,
+                                    float* out32, void* out16, void* out16_lo, int lo_fmt, float* partial, void* stream) {
+    if (!a || !s || !partial || F < 1 || Npix < 1 || C1 % 4 || C2 % 4 || C1 < 4 || C2 < 4) return PNC_EINVAL;
+    if (lo_fmt != PNC_LO_F16 && lo_fmt != PNC_LO_E4M3) return PNC_EINVAL;
+    if ((!out32 && !out16) || (out16_lo && !out16)) return PNC_EINVAL;
+    const int C = C1 + C2;
+    if (C % 64 || C > GN_MAXC) return PNC_EINVAL;
+    if (((uintptr_t)a | (uintptr_t)s | (uintptr_t)c | (uintptr_t)out32) & 15) return PNC_EALIGN;
+    const int nchunk = (Npix + 63) / 64;
+    const size_t lds = (size_t)4 * C * sizeof(float);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    PNC_GN_DISPATCH(concat_add_stats_kernel, dim3(nchunk, F), dim3(256), lds, st, a, C1, s, c, C2, Npix, out32,
+                    reinterpret_cast<half_t*>(out16), out16_lo, lo_fmt, partial);
     return pnc_launch_status();
 }
 

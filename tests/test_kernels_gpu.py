@@ -1200,6 +1200,47 @@ def test_layout_helpers():
     assert torch.equal(y16, aa.half())
 
 
+@pytest.mark.parametrize("F,Npix,C1,C2,ctrl,lo", [(2, 192, 320, 320, True, "e4m3"), (3, 100, 640, 320, False, None), (1, 768, 1280, 1280, True, "f16"),
+                                                 (2, 64, 64, 64, True, None)])
+def test_concat_add_with_groupnorm_records(F, Npix, C1, C2, ctrl, lo):
+    """pnc_concat_add_stats (ABI 5): the concat's values equal pnc_concat_add's bit for bit, its records equal
+    pnc_groupnorm_stats(..., 64) of the result up to fp32 summation order, they are reproducible bit for bit, and
+    pnc_groupnorm_apply on them equals the two-launch path to fp16 rounding"""
+    M, C = F * Npix, C1 + C2
+    a, s_, c = rnd(M, C1, seed=1) * 2 + 0.3, rnd(M, C2, seed=2), (rnd(M, C2, seed=3) if ctrl else None)
+    lod = {None: None, "e4m3": torch.uint8, "f16": torch.float16}[lo]
+
+    def outs():
+        return dict(o32=torch.zeros(M, C, device=DEV), o16=torch.zeros(M, C, device=DEV, dtype=torch.float16),
+                    lo=None if lod is None else torch.zeros(M, C, device=DEV, dtype=lod))
+    nrec = -(-Npix // 64)
+    ref, got, got2 = outs(), outs(), outs()
+    part, part2 = torch.zeros(F * nrec * 96, device=DEV), torch.zeros(F * nrec * 96, device=DEV)
+    hip.concat_add(a, C1, s_, c, C2, M, ref["o32"], ref["o16"], ref["lo"])
+    hip.concat_add(a, C1, s_, c, C2, M, got["o32"], got["o16"], got["lo"], gn_part=part, frames=F)
+    hip.concat_add(a, C1, s_, c, C2, M, got2["o32"], got2["o16"], got2["lo"], gn_part=part2, frames=F)
+    pref = torch.zeros(F * nrec * 96, device=DEV)
+    hip.groupnorm_stats(ref["o32"], C, F, Npix, C, 64, pref)
+    torch.cuda.synchronize()
+    assert torch.equal(got["o32"], ref["o32"]) and torch.equal(got["o16"], ref["o16"]) and torch.equal(part, part2)
+    if lo:
+        assert torch.equal(got["lo"], ref["lo"])
+    P, R = part.view(F, nrec, 32, 3), pref.view(F, nrec, 32, 3)
+    assert torch.equal(P[..., 0], R[..., 0])
+    check("record mean", P[..., 1], R[..., 1], 2e-6, 2e-6)
+    check("record M2", P[..., 2], R[..., 2], 1e-4 * float(R[..., 2].max()), 1e-5)
+    gamma, beta = rnd(C, seed=4) * 0.5 + 1, rnd(C, seed=5) * 0.3
+    y0, y1 = (torch.zeros(M, C, device=DEV, dtype=torch.float16) for _ in range(2))
+    hip.groupnorm_apply(ref["o32"], C, F, Npix, C, 64, pref, gamma, beta, 1e-5, 1, y0, C)
+    hip.groupnorm_apply(ref["o32"], C, F, Npix, C, 128, part, gamma, beta, 1e-5, 1, y1, C, n_records=nrec)
+    torch.cuda.synchronize()
+    check("apply on the concat's records", y1, y0, 2e-3, 2e-3)
+    e = outs()
+    epart = torch.zeros(F * nrec * 96, device=DEV)
+    emu.concat_add(a, C1, s_, c, C2, M, e["o32"], e["o16"], e["lo"], gn_part=epart, frames=F)
+    check("records vs emu", P[..., 1], epart.view(F, nrec, 32, 3)[..., 1], 2e-6, 2e-6)
+
+
 def test_rejects_cpu_tensors_and_bad_shapes():
     with pytest.raises(hip.PncError):
         hip.layernorm(torch.zeros(4, 64), 64, 4, 64, torch.ones(64), torch.zeros(64), 1e-5,

@@ -231,13 +231,13 @@ def test_full_size_properties_and_golden(full_net):
 # Round 5 (VERDICT r4 weak spot 2): every earlier pin used ONE synthetic weight draw (salt 0) whose residual stream stays far below the
 # |v| = 512 where the e4m3 lo plane of an fp16-rounded operand clamps (include/panacea_hip.h).  Two more pins of the reference's own
 # forward (oracle/gen_golden_full.py --t 500 --wsalt 1 / --wtail 16): a second weight draw, and a heavy-tailed weight set whose
-# "massive activation" channels (synth.synth_tensor: output rows c % 64 == 5 of every residual-out tensor x 16) carry the stream
+# "massive activation" channels (synth.synth_tensor: output rows c % 64 == 5 of every residual-out tensor x 64) carry the stream
 # into the clamp range (|v| 512 .. ~2000; a first attempt with gain 256 put the stream at 2.3e4 and an fp16 operand beyond 65504:
 # non-finite eps — an fp16 path's own range limit, stated in UNetModel3D.eps_contract).  TAIL_GATE is the bound asserted there.
 TAIL_GATE = 1.0e-3
 
 
-@pytest.mark.parametrize("fname,wsalt,wtail", [("full_cfg3_t500_w1.npz", 1, 0.0), ("full_cfg3_t500_tail16.npz", 0, 16.0)])
+@pytest.mark.parametrize("fname,wsalt,wtail", [("full_cfg3_t500_w1.npz", 1, 0.0), ("full_cfg3_t500_tail64.npz", 0, 64.0)])
 def test_full_size_other_weight_sets(full_net, fname, wsalt, wtail):
     from panacea_amd import synth
     path = GOLDEN / fname
@@ -255,10 +255,11 @@ def test_full_size_other_weight_sets(full_net, fname, wsalt, wtail):
         extra = {}
         if wtail:
             extra["stream_max_abs"] = max(float(v.abs().max()) for k, v in trace.items() if "blocks" in k or "middle" in k)
-            assert extra["stream_max_abs"] >= 512.0, extra          # the regime the pin exists for: the e4m3 clamp range is reached
             del trace
         print(f"config 3, t=500, weight salt {wsalt}, tail {wtail} vs reference:", st, extra)
         measured("full_cfg3_weights", wsalt=wsalt, wtail=wtail, max_abs=st["max_abs"], mean_abs=st["mean_abs"], **extra)
+        if wtail:
+            assert extra["stream_max_abs"] >= 512.0, extra          # the regime the pin exists for: the e4m3 clamp range is reached
         assert st["max_abs"] <= (TAIL_GATE if wtail else NORTH_STAR), st
     finally:
         w.diffusion_model.load_state_dict(synth.synth_state_dict(manifest("full")), strict=True)     # the module fixture's weights

@@ -488,7 +488,16 @@ class UNetModel3D(nn.Module, Packable):
         if prec in ("fast",):
             return {"policy": prec, "eps_max_abs": None, "note": "plain fp16 operands: measured 2.0-2.6e-3, no stated bound"}
         if gmin >= 4:
-            return {"policy": prec, "eps_max_abs": 1e-3, "values_per_temporal_group": gmin}
+            # Range of the bound (round 5, the heavy-tail pin tests/golden/full_cfg3_t500_tail64.npz): an fp16 operand carries 11 bits
+            # whatever the policy, and the e4m3 lo plane of a split operand — (v - fp16(v)) * 2^11, clamped at 448 — stops adding to them
+            # from |v| = 512 on (include/panacea_hip.h).  With "massive activation" channels that take the residual stream to
+            # |v| = 1.8e3 (synth.synth_tensor tail = 64) the measured eps error is 2.3e-3 max / 3.3e-4 mean against the reference's fp32
+            # forward: the stream-class convs (skip 1x1, Down / Upsample, zero convs) see those channels at fp16 precision.  Beyond
+            # |operand| = 65504 an fp16 path overflows (non-finite eps; the reference's own autocast path does too).
+            return {"policy": prec, "eps_max_abs": 1e-3, "values_per_temporal_group": gmin,
+                    "valid_for": "residual stream |v| < 512 (every operand of a split class inside the e4m3 lo plane's range)",
+                    "beyond": {"stream_max_abs": 1.8e3, "eps_max_abs_measured": 2.3e-3, "eps_mean_abs_measured": 3.3e-4,
+                               "pin": "tests/golden/full_cfg3_t500_tail64.npz"}}
         return {"policy": prec, "eps_max_abs": 2.5e-3, "values_per_temporal_group": gmin,
                 "note": "temporal GroupNorm over fewer than 4 values amplifies its input's rounding (measured 1.0-2.2e-3)"}
 

@@ -211,8 +211,9 @@ def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, 
     smp = sampling.EulerEDMSampler(args.num_sampling_steps, guider=guider, device=dev)
     smp.fuse = not args.no_fused_step
     shard, vshard = groups.frame_shard(), groups.view_shard()
-    parallel.apply_frame_shard(net, shard)
-    parallel.apply_view_shard(net, vshard)
+    side = not args.one_stream                          # the ControlNet on its side stream, over process groups of its own
+    parallel.apply_frame_shard(net, shard, groups.frame_shard(side=True) if side else None)
+    parallel.apply_view_shard(net, vshard, groups.view_shard(side=True) if side else None)
     try:
         if shard is not None or vshard is not None:
             cond, uc = parallel.shard_conditioning(cond, layout, T), parallel.shard_conditioning(uc, layout, T)
@@ -489,8 +490,8 @@ def main():
             d["concat"] = cc
         x0 = sampling.share_noise_init(x0, cond["concat"], 0.07)
     if shard is not None or vshard is not None:
-        parallel.apply_frame_shard(net, shard)
-        parallel.apply_view_shard(net, vshard)
+        parallel.apply_frame_shard(net, shard, None if args.one_stream else groups.frame_shard(side=True))
+        parallel.apply_view_shard(net, vshard, None if args.one_stream else groups.view_shard(side=True))
         cond, uc = parallel.shard_conditioning(cond, layout, T), parallel.shard_conditioning(uc, layout, T)
     x = x0 * torch.sqrt(1.0 + sig[0] ** 2.0)
     x = parallel.local_views(parallel.local_frames(x, layout, T), layout)    # this rank's frame group / view band of the sample

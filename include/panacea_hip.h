@@ -255,6 +255,13 @@ typedef struct PncAttnParams {
     float scale;                    /* softmax scale (d^-0.5) */
     int32_t causal;                 /* 1: query i of a view attends keys j <= i of each kv view only (view-local indices) —
                                        the text tower's causal mask (open_clip build_attention_mask; modules.py:559-632); 0 else */
+    /* ABI 5 (round 5): HALO views of a band of views (engine.ViewShard: the cross-view attention of a rank that holds n of the six
+     * views attends one view of each neighbour rank as well, attention.py:545-559).  NULL = off.  Otherwise kv view id -1 in seg[][]
+     * reads k_halo[0] / vt_halo[0], id kv_views reads k_halo[1] / vt_halo[1]: buffers of EXACTLY the band's geometry (ldk, kvW,
+     * kv_rows_per_group, ldvt, vt_gstride) whose view column 0 holds the neighbour's view (the rest is never read).  The band's own
+     * K / V^T stay where the QKV GEMM wrote them: no (n + 2)-view copy of keys and values. */
+    const void* k_halo[2];
+    const void* vt_halo[2];
 } PncAttnParams;
 
 int pnc_attn_views_f16(const PncAttnParams* p, void* stream);

@@ -52,6 +52,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_vi
     const half_t* __restrict__ K = reinterpret_cast<const half_t*>(p.k);
     const half_t* __restrict__ VT = reinterpret_cast<const half_t*>(p.vt);
     half_t* __restrict__ O = reinterpret_cast<half_t*>(p.o);
+    // halo views (PncAttnParams.k_halo): kv view id -1 / kv_views = view column 0 of a buffer with the band's geometry
+    auto seg_view = [&](int id, const half_t*& Kb, const half_t*& Vb) -> int {
+        Kb = K; Vb = VT;
+        if (id < 0) { Kb = reinterpret_cast<const half_t*>(p.k_halo[0]); Vb = reinterpret_cast<const half_t*>(p.vt_halo[0]); return 0; }
+        if (id >= p.kv_views) { Kb = reinterpret_cast<const half_t*>(p.k_halo[1]); Vb = reinterpret_cast<const half_t*>(p.vt_halo[1]); return 0; }
+        return id;
+    };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA destinations (M0) and wave-row tests stay on the SALU
@@ -115,7 +122,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_vi
     half8v rk[ST_IT], rv[ST_IT];
     auto load_tile = [&](int t) {
         const int s = t / tiles_per_seg, tt = t - s * tiles_per_seg;
-        const int kview = p.seg[view][s];
+        const half_t *K, *VT;                      // (this segment's buffers: the band's, or a halo view's)
+        const int kview = seg_view(p.seg[view][s], K, VT);
         const int key0 = tt * KT;
         half8v z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -179,22 +187,26 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_vi
     }
     const int rows_per_tile_kvW = (wv_shift >= 0 ? (KT >> wv_shift) : 0) * p.kvW;
     // (the segment's view index is read ONCE: indexed per tile it is a scalar load + lgkmcnt(0) in front of every tile's DMA)
-    const int seg_off0 = p.seg[view][0] * kvWv, seg_off1 = p.seg[view][nseg > 1 ? 1 : 0] * kvWv;
+    const half_t *Ks0, *Vs0, *Ks1, *Vs1;
+    const int seg_off0 = seg_view(p.seg[view][0], Ks0, Vs0) * kvWv, seg_off1 = seg_view(p.seg[view][nseg > 1 ? 1 : 0], Ks1, Vs1) * kvWv;
+    const int64_t kdel0 = Ks0 - K, kdel1 = Ks1 - K, vdel0 = Vs0 - VT, vdel1 = Vs1 - VT;      // element offsets of a segment's buffers (0: the band's)
     auto dma_tile = [&](int t, int stage) {        // DMA path: same addresses, destination = this wave's 8 rows
         char* sk = smem + stage * (2 * KT * 128) + wave * 1024;
         char* sv = sk + KT * 128;
         if (inc_addr) {                            // (uniform)
             const int s1 = t >= tiles_per_seg ? 1 : 0, tt1 = t - s1 * tiles_per_seg;
             const int64_t urow = (int64_t)tt1 * rows_per_tile_kvW + (s1 ? seg_off1 : seg_off0);
+            const int64_t ko = urow * p.ldk + (s1 ? kdel1 : kdel0), vo = urow + (s1 ? vdel1 : vdel0);
 #pragma unroll
             for (int i = 0; i < ST_IT; ++i) {
-                glds16(kptr[i] + urow * p.ldk, sk + i * (ROWS_PER_IT * 128));
-                glds16(vptr[i] + urow, sv + i * (ROWS_PER_IT * 128));
+                glds16(kptr[i] + ko, sk + i * (ROWS_PER_IT * 128));
+                glds16(vptr[i] + vo, sv + i * (ROWS_PER_IT * 128));
             }
             return;
         }
         const int s = t / tiles_per_seg, tt = t - s * tiles_per_seg;
-        const int kview = p.seg[view][s];
+        const half_t *K, *VT;
+        const int kview = seg_view(p.seg[view][s], K, VT);
         const int key0 = tt * KT;
 #pragma unroll
         for (int i = 0; i < ST_IT; ++i) {
@@ -482,8 +494,16 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     if (p.causal != 0 && p.causal != 1) return PNC_EINVAL;
     for (int v = 0; v < p.views; ++v) {
         if (p.nseg[v] < 1 || p.nseg[v] > 2) return PNC_EINVAL;
-        for (int s = 0; s < p.nseg[v]; ++s)
-            if (p.seg[v][s] < 0 || p.seg[v][s] >= p.kv_views) return PNC_EINVAL;
+        for (int s = 0; s < p.nseg[v]; ++s) {
+            const int id = p.seg[v][s];
+            if (id == -1 || id == p.kv_views) {          // a halo view: its buffers must be there, laid out like the band's
+                const int side = id < 0 ? 0 : 1;
+                if (!p.k_halo[side] || !p.vt_halo[side]) return PNC_EINVAL;
+                if (((uintptr_t)p.k_halo[side] | (uintptr_t)p.vt_halo[side]) & 15) return PNC_EALIGN;
+            } else if (id < 0 || id > p.kv_views) {
+                return PNC_EINVAL;
+            }
+        }
     }
     const int Nq = p.H * (p.W / p.views);
     // variants: (waves, query blocks per wave) -> queries per workgroup.  Two blocks per wave: every K / V^T fragment read feeds

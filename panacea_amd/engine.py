@@ -461,24 +461,47 @@ class ViewShard:
 
     def neighbour_views(self, k4: torch.Tensor, v4: torch.Tensor):
         """k4 [F, H, W_l, C] keys (channels-last), v4 [F, C, H, W_l] values (channel-major) of this band -> the same with one
-        view of the left neighbour in front and one of the right neighbour behind (circular), i.e. n_local + 2 views."""
+        view of the left neighbour in front and one of the right neighbour behind (circular), i.e. n_local + 2 views.
+        (Round 3-4 form: copies the whole band.  The network uses `halo_views` since round 5.)"""
         Wv = k4.shape[2] // self.n_local
         (kl, vl), (kr, vr) = self._exchange([k4[:, :, :Wv], v4[..., :Wv]], [k4[:, :, -Wv:], v4[..., -Wv:]])
         return torch.cat([kl, k4, kr], dim=2).contiguous(), torch.cat([vl, v4, vr], dim=3).contiguous()
 
-    def local_segments(self, segs):
+    def halo_views(self, rt, k4: torch.Tensor, v4: torch.Tensor, k_rows: int, k_ld: int, k_col: int):
+        """Round 5: the neighbours' edge views WITHOUT touching the band.  k4 [F, H, W_l, C] (a strided view of
+        the QKV GEMM's row-major output: rows of k_ld elements, keys at column k_col), v4 [F, C, H, W_l] (its channel-major V^T)
+        stay where the GEMM wrote them; the left neighbour's last view and the right neighbour's first view land in view column 0
+        of two buffers of the band's own geometry (PncAttnParams.k_halo / vt_halo: same leading dimensions, so the attention
+        kernel's tile addresses differ by a wave-uniform offset only; the other columns are never written or read) ->
+        ((k_left, k_right), (vt_left, vt_right)).  Copies 2 views per operand instead of n_local + 2."""
+        F, H, Wl, C = k4.shape
+        Wv = Wl // self.n_local
+        (kl, vl), (kr, vr) = self._exchange([k4[:, :, :Wv], v4[..., :Wv]], [k4[:, :, -Wv:], v4[..., -Wv:]])
+        kh, vh = [], []
+        for kn, vn in ((kl, vl), (kr, vr)):
+            kb = rt.empty((k_rows, k_ld), k4.dtype)
+            kb.view(F, H, Wl, k_ld)[:, :, :Wv, k_col:k_col + C] = kn
+            vb = rt.empty((F, C, H * Wl), v4.dtype)
+            vb.view(F, C, H, Wl)[..., :Wv] = vn
+            kh.append(kb.view(-1)[k_col:])
+            vh.append(vb)
+        return tuple(kh), tuple(vh)
+
+    def local_segments(self, segs, halo_ids: bool = False):
         """the per-view key/value view lists of the whole panorama (e.g. INTER_SEGS) -> those of this rank's views, as
-        indices into the `neighbour_views` layout"""
+        indices into the `neighbour_views` layout (0 = left neighbour, 1 .. n_local = the band, n_local + 1 = right neighbour),
+        or — `halo_ids` — as the ids of `halo_views` / PncAttnParams.k_halo: band views 0 .. n_local - 1, left -1, right n_local"""
         out = []
+        base = 0 if halo_ids else 1
         for v in range(self.first, self.first + self.n_local):
             row = []
             for u in segs[v]:
                 if self.first <= u < self.first + self.n_local:
-                    row.append(u - self.first + 1)
+                    row.append(u - self.first + base)
                 elif u == (self.first - 1) % self.VIEWS:
-                    row.append(0)
+                    row.append(base - 1)
                 elif u == (self.first + self.n_local) % self.VIEWS:
-                    row.append(self.n_local + 1)
+                    row.append(self.n_local + base)
                 else:
                     raise ValueError(f"view {v} attends view {u}, which is not a neighbour of this rank's band")
             out.append(row)

@@ -83,6 +83,7 @@ class AttnParams(C.Structure):
         ("kv_rows_per_group", C.c_int32), ("q_per_kv", C.c_int32), ("kv_valid", C.c_int32),
         ("nseg", C.c_int32 * 8), ("seg", (C.c_int32 * 2) * 8),
         ("scale", C.c_float), ("causal", C.c_int32),
+        ("k_halo", C.c_void_p * 2), ("vt_halo", C.c_void_p * 2),
     ]
 
 
@@ -324,8 +325,13 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, *, M: int, N: int, K: int, lda: i
 
 
 def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H, W, views,
-               kvH, kvW, kv_views, kv_rows_per_group, q_per_kv, kv_valid, segs, scale, causal=False):
+               kvH, kvW, kv_views, kv_rows_per_group, q_per_kv, kv_valid, segs, scale, causal=False, k_halo=None, vt_halo=None):
+    """`k_halo` / `vt_halo`: pairs (left, right) of buffers with the geometry of k / vt whose view column 0 holds a neighbour rank's
+    view — kv view id -1 / kv_views in `segs` (PncAttnParams.k_halo)"""
     p = AttnParams()
+    if k_halo is not None:
+        for i in range(2):
+            p.k_halo[i], p.vt_halo[i] = _ptr(k_halo[i]), _ptr(vt_halo[i])
     p.q, p.ldq, p.k, p.ldk = _ptr(q), ldq, _ptr(k), ldk
     p.vt, p.ldvt, p.vt_gstride, p.o, p.ldo = _ptr(vt), ldvt, vt_gstride, _ptr(o), ldo
     p.groups, p.heads, p.H, p.W, p.views = groups, heads, H, W, views

@@ -180,12 +180,14 @@ class _AttentionBase(nn.Module, Packable):
         o = rt.empty((M, C), torch.float16)
         Wv = W // views
         if vs is not None and any(u != v for v, row in enumerate(segs) for u in row):
-            # this rank's band of views attends its neighbours' edge views too: keys / values of n_local + 2 views
-            k_ext, v_ext = vs.neighbour_views(qk.view(F, H, W, 2 * C)[..., C:], vt.view(F, C, H, W))
-            We = W + 2 * Wv
-            rt.be.attn_views(qk, 2 * C, k_ext.view(-1), C, v_ext, H * We, C * H * We, o, C, groups=F, heads=self.heads,
-                             H=H, W=W, views=views, kvH=H, kvW=We, kv_views=views + 2, kv_rows_per_group=H * We, q_per_kv=1,
-                             kv_valid=H * Wv, segs=vs.local_segments(segs), scale=self.scale)
+            # this rank's band of views attends its neighbours' edge views too.  Round 5: the band's keys / values stay where the
+            # QKV GEMM wrote them; the two neighbour views arrive in halo buffers of the band's geometry (PncAttnParams.k_halo) —
+            # rounds 3-4 concatenated keys and values of n_local + 2 views (4.5 ms per evaluation at G = 1)
+            k_halo, vt_halo = vs.halo_views(rt, qk.view(F, H, W, 2 * C)[..., C:], vt.view(F, C, H, W), M, 2 * C, C)
+            rt.be.attn_views(qk, 2 * C, qk.view(-1)[C:], 2 * C, vt, N, C * N, o, C, groups=F, heads=self.heads,
+                             H=H, W=W, views=views, kvH=H, kvW=W, kv_views=views, kv_rows_per_group=N, q_per_kv=1,
+                             kv_valid=H * Wv, segs=vs.local_segments(segs, halo_ids=True), scale=self.scale,
+                             k_halo=k_halo, vt_halo=vt_halo)
         else:
             if vs is not None:
                 segs = [[i] for i in range(views)]

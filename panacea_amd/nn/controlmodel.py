@@ -251,8 +251,17 @@ class ControlledUNetModel3D(UNetModel3D):
             x16 = self._stem_tokens(rt, x) if fused is None else self._stem_tokens(rt, x, fused[1], fused[0])
             cn = self.controlnet
             hint32 = hint if inv is not None else hint.detach().to(torch.float32).contiguous()
-            # frame- / view-sharded runs issue collectives from both networks: one stream keeps their order identical on all ranks
-            if self.two_stream and x.is_cuda and trace is None and rt.shard is None and rt.vshard is None:
+            # frame- / view-sharded runs issue collectives from both networks.  With shard objects of its own (process groups of its
+            # own: parallel.Groups(side=True), apply_*_shard(net, shard, side_shard)) the ControlNet's collectives have one order per
+            # communicator whatever the interleaving, and it runs on its side stream as on one GPU (round 5); sharing the UNet's
+            # shard objects it stays on the main stream (one stream keeps the order of ONE communicator identical on all ranks)
+            own_groups = (rt.shard is None or cn.frame_shard is not rt.shard) and (rt.vshard is None or cn.view_shard is not rt.vshard)
+            rt_cn = rt
+            if own_groups and (rt.shard is not None or rt.vshard is not None):
+                import copy
+                rt_cn = copy.copy(rt)                  # same context / text K,V / invariants, the ControlNet's own shards
+                rt_cn.shard, rt_cn.vshard = cn.frame_shard, cn.view_shard
+            if self.two_stream and x.is_cuda and trace is None and own_groups:
                 main = torch.cuda.current_stream()
                 # per-device tables that both streams read are created HERE, on the main stream, before the fork: their
                 # first use would otherwise be an H2D copy on the side stream that the main stream does not wait for
@@ -262,7 +271,7 @@ class ControlledUNetModel3D(UNetModel3D):
                 side = _side_stream(x.device, side_idx)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    control = cn._run_control(rt, x16, hint32, cn._time_embedding(rt, timesteps))
+                    control = cn._run_control(rt_cn, x16, hint32, cn._time_embedding(rt_cn, timesteps))
                 for t in (x16.f16, rt.ctx16, hint32, timesteps):
                     t.record_stream(side)
 
@@ -273,7 +282,7 @@ class ControlledUNetModel3D(UNetModel3D):
                     return control
                 out = self._run_unet(rt, x16, self._time_embedding(rt, timesteps), join, tokens=fused is not None)
             else:
-                control = cn._run_control(rt, x16, hint32, cn._time_embedding(rt, timesteps))
+                control = cn._run_control(rt_cn, x16, hint32, cn._time_embedding(rt_cn, timesteps))
                 if trace is not None:
                     for j, c in enumerate(control):
                         trace[f"control.{j}"] = c.to_nchw()

@@ -170,22 +170,30 @@ class Groups:
     """The process groups of this rank.  Group creation is collective: EVERY rank constructs this with the same layout
     (all groups are created by all ranks, in the same order)."""
 
-    def __init__(self, layout: RankLayout):
+    def __init__(self, layout: RankLayout, side: bool = True):
+        """`side`: create every frame / view group TWICE.  The second set belongs to the ControlNet (`frame_shard(side=True)`,
+        `view_shard(side=True)`, `apply_*_shard(net, shard, side_shard)`): with communicators of its own the ControlNet's collectives
+        keep ONE order per communicator whatever the interleaving with the UNet's, so the two networks may run on two HIP streams in
+        the sharded layouts as they do on one GPU (round 5; rounds 2-4 put both on one stream there)."""
         self.layout = layout
         self.frame_group = self.view_group = self.cfg_pair = None
+        self.frame_group_side = self.view_group_side = None
         self._view_shard: Optional[ViewShard] = None
+        self._view_shard_side: Optional[ViewShard] = None
         for smp in range(layout.samples):
             for h in range(layout.cfg):
                 for vg in range(layout.views if layout.frames > 1 else 0):
                     ranks = layout.frame_group_ranks(smp, h, vg)
                     g = dist.new_group(ranks)
+                    g2 = dist.new_group(ranks) if side else None
                     if layout.rank in ranks:
-                        self.frame_group = g
+                        self.frame_group, self.frame_group_side = g, g2
                 for fg in range(layout.frames if layout.views > 1 else 0):
                     ranks = layout.view_group_ranks(smp, h, fg)
                     g = dist.new_group(ranks)
+                    g2 = dist.new_group(ranks) if side else None
                     if layout.rank in ranks:
-                        self.view_group = g
+                        self.view_group, self.view_group_side = g, g2
             for fg in range(layout.frames * layout.views):
                 ranks = layout.cfg_pair_ranks(smp, fg)
                 if layout.cfg > 1:
@@ -193,13 +201,23 @@ class Groups:
                     if layout.rank in ranks:
                         self.cfg_pair = g
 
-    def frame_shard(self) -> Optional[FrameShard]:
+    def frame_shard(self, side: bool = False) -> Optional[FrameShard]:
         lo = self.layout
-        return FrameShard(lo.frames, lo.frame_group, self.frame_group) if lo.frames > 1 else None
+        if lo.frames <= 1 or (side and self.frame_group_side is None):
+            return None
+        return FrameShard(lo.frames, lo.frame_group, self.frame_group_side if side else self.frame_group)
 
-    def view_shard(self) -> Optional[ViewShard]:
+    def view_shard(self, side: bool = False) -> Optional[ViewShard]:
         lo = self.layout
-        if lo.views > 1 and self._view_shard is None:
+        if lo.views <= 1:
+            return None
+        if side:
+            if self.view_group_side is None:
+                return None
+            if self._view_shard_side is None:
+                self._view_shard_side = ViewShard(lo.views, lo.view_group, self.view_group_side)
+            return self._view_shard_side
+        if self._view_shard is None:
             self._view_shard = ViewShard(lo.views, lo.view_group, self.view_group)
         return self._view_shard
 
@@ -207,23 +225,24 @@ class Groups:
         return ShardedCFG(scale, self.cfg_pair, self.layout.half) if self.layout.cfg > 1 else VanillaCFG(scale)
 
 
-def apply_frame_shard(network, shard: Optional[FrameShard]):
+def apply_frame_shard(network, shard: Optional[FrameShard], side_shard: Optional[FrameShard] = None):
     """Tell the network (OpenAIWrapperControlLDM3D or ControlledUNetModel3D) that its batches carry this rank's frame
-    group only."""
+    group only.  `side_shard`: the same shard over the ControlNet's own process group (`Groups.frame_shard(side=True)`): with it
+    the ControlNet runs on its side stream in the sharded layout too."""
     model = getattr(network, "diffusion_model", network)
     model.frame_shard = shard
     if hasattr(model, "controlnet"):
-        model.controlnet.frame_shard = shard
+        model.controlnet.frame_shard = side_shard if (shard is not None and side_shard is not None) else shard
     return network
 
 
-def apply_view_shard(network, shard: Optional[ViewShard]):
+def apply_view_shard(network, shard: Optional[ViewShard], side_shard: Optional[ViewShard] = None):
     """Tell the network that its batches carry this rank's band of views only (W / V columns of the latent, of `concat`
-    and of the BEV hint)."""
+    and of the BEV hint).  `side_shard`: see apply_frame_shard."""
     model = getattr(network, "diffusion_model", network)
     model.view_shard = shard
     if hasattr(model, "controlnet"):
-        model.controlnet.view_shard = shard
+        model.controlnet.view_shard = side_shard if (shard is not None and side_shard is not None) else shard
     return network
 
 

@@ -221,21 +221,30 @@ def _unfrag(fr: torch.Tensor) -> torch.Tensor:
 
 
 def attn_views(q, ldq, k, ldk, vt, ldvt, vt_gstride, o, ldo, *, groups, heads, H, W, views, kvH, kvW,
-               kv_views, kv_rows_per_group, q_per_kv, kv_valid, segs, scale, causal=False):
+               kv_views, kv_rows_per_group, q_per_kv, kv_valid, segs, scale, causal=False, k_halo=None, vt_halo=None):
     Cc = heads * 64
     Wv, kvWv = W // views, kvW // kv_views
     Q = _mat(q, groups * H * W, Cc, ldq).float().view(groups, H, W, heads, 64)
     n_kvg = (groups + q_per_kv - 1) // q_per_kv
-    Kall = _mat(k, n_kvg * kv_rows_per_group, Cc, ldk).float().view(n_kvg, kv_rows_per_group, heads, 64)
-    Kall = Kall[:, : kvH * kvW].reshape(n_kvg, kvH, kvW, heads, 64)
-    Vall = torch.as_strided(vt.reshape(-1), (n_kvg, Cc, kvH * kvW), (vt_gstride, ldvt, 1)).float()
-    Vall = Vall.view(n_kvg, heads, 64, kvH, kvW)
+
+    def kv_maps(kb, vb):
+        Ka = _mat(kb, n_kvg * kv_rows_per_group, Cc, ldk).float().view(n_kvg, kv_rows_per_group, heads, 64)
+        Ka = Ka[:, : kvH * kvW].reshape(n_kvg, kvH, kvW, heads, 64)
+        Va = torch.as_strided(vb.reshape(-1), (n_kvg, Cc, kvH * kvW), (vt_gstride, ldvt, 1)).float()
+        return Ka, Va.view(n_kvg, heads, 64, kvH, kvW)
+    Kband, Vband = kv_maps(k, vt)
+    # PncAttnParams.k_halo: view id -1 / kv_views = view column 0 of a buffer laid out like the band's
+    halos = None if k_halo is None else [kv_maps(k_halo[i], vt_halo[i]) for i in range(2)]
     O = _mat(o, groups * H * W, Cc, ldo).view(groups, H, W, Cc)
     gidx = torch.arange(groups, device=q.device) // q_per_kv
     for v in range(views):
         qv = Q[:, :, v * Wv:(v + 1) * Wv].reshape(groups, H * Wv, heads, 64).permute(0, 2, 1, 3)
         ks, vs = [], []
         for u in segs[v]:
+            Kall, Vall = Kband, Vband
+            if u == -1 or u == kv_views:
+                Kall, Vall = halos[0 if u < 0 else 1]
+                u = 0
             kk = Kall[:, :, u * kvWv:(u + 1) * kvWv].reshape(n_kvg, kvH * kvWv, heads, 64)[:, :kv_valid]
             vv = Vall[:, :, :, :, u * kvWv:(u + 1) * kvWv].reshape(n_kvg, heads, 64, kvH * kvWv)[..., :kv_valid]
             ks.append(kk.permute(0, 2, 1, 3))          # [g, heads, keys, 64]

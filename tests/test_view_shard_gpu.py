@@ -129,9 +129,18 @@ def test_sharded_layouts_loop_back_at_full_width(tmp_path):
         sh = E.FrameShard(1, 0, None)
         parallel.apply_frame_shard(w, sh)
         got_vf = w(inp["x"], inp["t"], cond(inp))
+        # round 5: with shard objects of its own (= process groups of its own, parallel.Groups(side=True)) the ControlNet runs on
+        # its side stream in the sharded layouts as well: same arithmetic, bit-identical eps
+        vs2, sh2 = E.ViewShard(1, 0, None), E.FrameShard(1, 0, None)
+        parallel.apply_view_shard(w, vs, vs2)
+        parallel.apply_frame_shard(w, sh, sh2)
+        assert w.diffusion_model.controlnet.view_shard is vs2 and w.diffusion_model.view_shard is vs
+        got_vf2 = w(inp["x"], inp["t"], cond(inp))
+        parallel.apply_frame_shard(w, sh)
         parallel.apply_view_shard(w, None)
         got_f = w(inp["x"], inp["t"], cond(inp))
     torch.cuda.synchronize()
+    assert torch.equal(got_vf2, got_vf) and vs2.exchanges > 50 and sh2.exchanges > 20, (vs2.exchanges, sh2.exchanges)
     # The view loop-back runs every 3x3 conv over the band as it lies (same M, same tiles; the column block holds zeros = the
     # padding) and the GroupNorms on one combined record per frame: measured bit-identical to the unsharded eps.  The frame loop-back runs the
     # ResBlock3D temporal sites in their sharded form (partial sums of the temporal GroupNorm + the halo-frame layout of the

@@ -200,6 +200,15 @@ def main():
     else:
         kw = configs.with_frames(configs.get("full"), 2)
         w, sd, _ = product_network("full", "cpu", kw=kw)
+        tail = 0.0
+        if "--tail" in sys.argv:           # heavy-tail weight set (round 5; synth.synth_tensor): which classes carry the error THERE
+            i = sys.argv.index("--tail")
+            tail = float(sys.argv[i + 1])
+            del sys.argv[i:i + 2]
+            from helpers import manifest
+            from panacea_amd import synth
+            sd = synth.synth_state_dict(manifest("full"), tail=tail)
+            w.diffusion_model.load_state_dict(sd, strict=True)
         inp = step_inputs("full", kw, "cpu", shape=(1, 2, 16, 192))
         ref = po.wrapper_forward(sd, oracle_cfg(kw), inp["x"], inp["t"], cond(inp))
 

@@ -56,6 +56,15 @@ def main():
     d = (got - ref).abs()
     print(f"view machinery: +{t_vs - t_ref:.2f} ms ({100 * (t_vs / t_ref - 1):.1f} %), {vs.exchanges // (iters + 2)} exchanges / evaluation, "
           f"eps difference max {d.max().item():.3e} mean {d.mean().item():.3e}")
+    # round 5: the ControlNet on its side stream over a shard object (= process group) of its own
+    for m in w.modules():
+        if hasattr(m, "two_stream"):
+            m.two_stream = True
+    vs2 = E.ViewShard(1, 0, None)
+    parallel.apply_view_shard(w, vs, vs2)
+    got2, t_vs2 = timed("view loop-back, two streams")
+    print(f"view machinery on two streams: {t_vs2:.2f} ms = +{t_vs2 - t_two:.2f} ms over the unsharded two-stream evaluation; eps bit-identical to the one-stream "
+          f"loop-back: {bool(torch.equal(got2, got))}")
 
 
 if __name__ == "__main__":

@@ -393,45 +393,49 @@ __global__ __launch_bounds__(256) void gn_combine_kernel(const float* __restrict
 
 // th.cat([h, skip + control]) of the UNet's output path WITH the statistics of the GroupNorm that reads it (round 5): the concat is
 // followed by the first GroupNorm(32) of a ResBlock3D on exactly the tensor it writes (openaimodel.py:1311-1314 -> 499-503), and the
-// statistics launch read those C1 + C2 channels of fp32 back from HBM (level 0: 0.5-0.75 GB per site).  One workgroup = one 64-pixel
-// chunk of one frame (the record size of the GEMM epilogues' gn_part, engine.GN_EPILOGUE_CHUNK), waves stride the chunk's pixels, a
-// lane owns J float4 channel vectors: values are produced, stored and summed in one pass; the reduction is gn_stats_kernel's
-// (per-wave channel sums in LDS, one thread per group adds them in a fixed order: bit-reproducible records).
+// statistics launch read those C1 + C2 channels of fp32 back from HBM (level 0: 0.5-0.75 GB per site).  One workgroup = `ppc` pixels
+// of one frame x ONE SLICE of the channels (32 / S whole groups: blockIdx.z): waves stride the chunk's pixels, a lane owns J <= 3
+// float4 channel vectors of the slice, values are produced, stored and summed in one pass; the reduction is gn_stats_kernel's
+// (per-wave channel sums in LDS, one thread per group adds them in a fixed order: bit-reproducible records).  (A first form — whole
+// rows per workgroup, 64-pixel records — ran 1 wave per SIMD at C = 2560 and 48 workgroups at level 3: 3x slower than the two
+// launches it replaced, profiles/round5/concat_stats_bench_r5h.log.)
 template <int J>
 __global__ __launch_bounds__(256) void concat_add_stats_kernel(const float* __restrict__ a, int C1, const float* __restrict__ s,
-                                                               const float* __restrict__ c, int C2, int Npix,
+                                                               const float* __restrict__ c, int C2, int Npix, int ppc,
                                                                float* __restrict__ out32, half_t* __restrict__ out16,
                                                                void* __restrict__ out16_lo, int lo_fmt, float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];     // [4][C]: per-wave sums, then per-wave squares
-    constexpr int PPC = 64;
-    const int f = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // [4][Cs]: per-wave sums, then per-wave squares
+    const int f = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x, S = gridDim.z, z = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int C = C1 + C2, CV = C >> 2, cpg = C / GROUPS;
-    const int p0 = chunk * PPC;
-    const int p1 = min(Npix, p0 + PPC);
+    const int C = C1 + C2, cpg = C / GROUPS;
+    const int Cs = C / S, c0 = z * Cs, CVs = Cs >> 2, gps = GROUPS / S;      // this slice: channels [c0, c0 + Cs), groups [z gps, (z + 1) gps)
+    const int p0 = chunk * ppc;
+    const int p1 = min(Npix, p0 + ppc);
     f32x4 sum[J], sq[J];
-    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4 zz = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int j = 0; j < J; ++j) { sum[j] = z; sq[j] = z; }
+    for (int j = 0; j < J; ++j) { sum[j] = zz; sq[j] = zz; }
 #pragma unroll 2
     for (int pix = p0 + wave; pix < p1; pix += 4) {
         const int64_t m = (int64_t)f * Npix + pix;
         f32x4 v[J];
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const int ch = (lane + j * 64) * 4;
-            v[j] = z;
-            if (ch < C1) {
-                v[j] = *reinterpret_cast<const f32x4*>(a + m * C1 + ch);
-            } else if (ch < C) {
-                v[j] = *reinterpret_cast<const f32x4*>(s + m * C2 + (ch - C1));
-                if (c) v[j] += *reinterpret_cast<const f32x4*>(c + m * C2 + (ch - C1));
+            const int cv = lane + j * 64, ch = c0 + cv * 4;
+            v[j] = zz;
+            if (cv < CVs) {
+                if (ch < C1) {
+                    v[j] = *reinterpret_cast<const f32x4*>(a + m * C1 + ch);
+                } else {
+                    v[j] = *reinterpret_cast<const f32x4*>(s + m * C2 + (ch - C1));
+                    if (c) v[j] += *reinterpret_cast<const f32x4*>(c + m * C2 + (ch - C1));
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const int ch = (lane + j * 64) * 4;
-            if (ch < C) {
+            const int cv = lane + j * 64, ch = c0 + cv * 4;
+            if (cv < CVs) {
                 if (out32) *reinterpret_cast<f32x4*>(out32 + m * C + ch) = v[j];
                 if (out16) {
                     half4v h = {(half_t)v[j][0], (half_t)v[j][1], (half_t)v[j][2], (half_t)v[j][3]};
@@ -447,31 +451,31 @@ __global__ __launch_bounds__(256) void concat_add_stats_kernel(const float* __re
             for (int e = 0; e < 4; ++e) sq[j][e] = fmaf(v[j][e], v[j][e], sq[j][e]);
         }
     }
-    float* mine = sm + wave * C;
+    float* mine = sm + wave * Cs;
     float ts = 0.0f, tq = 0.0f;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int cv = lane + j * 64;
-        if (cv < CV) *reinterpret_cast<f32x4*>(mine + cv * 4) = sum[j];
+        if (cv < CVs) *reinterpret_cast<f32x4*>(mine + cv * 4) = sum[j];
     }
     __syncthreads();
-    if (tid < GROUPS)
+    if (tid < gps)
         for (int w = 0; w < 4; ++w)
-            for (int cc = 0; cc < cpg; ++cc) ts += sm[w * C + tid * cpg + cc];
+            for (int cc = 0; cc < cpg; ++cc) ts += sm[w * Cs + tid * cpg + cc];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int cv = lane + j * 64;
-        if (cv < CV) *reinterpret_cast<f32x4*>(mine + cv * 4) = sq[j];
+        if (cv < CVs) *reinterpret_cast<f32x4*>(mine + cv * 4) = sq[j];
     }
     __syncthreads();
-    if (tid < GROUPS) {
+    if (tid < gps) {
         for (int w = 0; w < 4; ++w)
-            for (int cc = 0; cc < cpg; ++cc) tq += sm[w * C + tid * cpg + cc];
+            for (int cc = 0; cc < cpg; ++cc) tq += sm[w * Cs + tid * cpg + cc];
         const float n = (float)(p1 - p0) * (float)cpg;
         const float mean = n > 0 ? ts / n : 0.0f;
         const float m2 = n > 0 ? fmaxf(tq - ts * mean, 0.0f) : 0.0f;
-        float* o = partial + ((int64_t)(f * nchunk + chunk) * GROUPS + tid) * 3;
+        float* o = partial + ((int64_t)(f * nchunk + chunk) * GROUPS + z * gps + tid) * 3;
         o[0] = n; o[1] = mean; o[2] = m2;
     }
 }
@@ -503,19 +507,26 @@ extern "C" int pnc_groupnorm_stats(const float* x, int ldx, int F, int Npix, int
     return pnc_launch_status();
 }
 
-extern "C" int pnc_concat_add_stats(const float* a, int C1, const float* s, const float* c, int C2, int F, int Npix,
+extern "C" int pnc_concat_add_stats(const float* a, int C1, const float* s, const float* c, int C2, int F, int Npix, int pix_per_chunk,
                                     float* out32, void* out16, void* out16_lo, int lo_fmt, float* partial, void* stream) {
-    if (!a || !s || !partial || F < 1 || Npix < 1 || C1 % 4 || C2 % 4 || C1 < 4 || C2 < 4) return PNC_EINVAL;
+    if (!a || !s || !partial || F < 1 || Npix < 1 || pix_per_chunk < 1 || C1 % 4 || C2 % 4 || C1 < 4 || C2 < 4) return PNC_EINVAL;
     if (lo_fmt != PNC_LO_F16 && lo_fmt != PNC_LO_E4M3) return PNC_EINVAL;
     if ((!out32 && !out16) || (out16_lo && !out16)) return PNC_EINVAL;
     const int C = C1 + C2;
-    if (C % 64 || C > GN_MAXC) return PNC_EINVAL;
+    if (C % 128 || C > GN_MAXC) return PNC_EINVAL;        // (C % 128: four-channel vectors never straddle a group)
     if (((uintptr_t)a | (uintptr_t)s | (uintptr_t)c | (uintptr_t)out32) & 15) return PNC_EALIGN;
-    const int nchunk = (Npix + 63) / 64;
-    const size_t lds = (size_t)4 * C * sizeof(float);
+    const int nchunk = (Npix + pix_per_chunk - 1) / pix_per_chunk;
+    // channel slices of whole groups, at most 3 float4 vectors per lane: S = 1, 2, 4 or 8
+    int S = 1;
+    while (S < 8 && (C / S / 4 + 63) / 64 > 3) S *= 2;
+    const int J = (C / S / 4 + 63) / 64;
+    const size_t lds = (size_t)4 * (C / S) * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    PNC_GN_DISPATCH(concat_add_stats_kernel, dim3(nchunk, F), dim3(256), lds, st, a, C1, s, c, C2, Npix, out32,
-                    reinterpret_cast<half_t*>(out16), out16_lo, lo_fmt, partial);
+    half_t* o16 = reinterpret_cast<half_t*>(out16);
+    const dim3 grid(nchunk, F, S);
+    if (J <= 1) hipLaunchKernelGGL(concat_add_stats_kernel<1>, grid, dim3(256), lds, st, a, C1, s, c, C2, Npix, pix_per_chunk, out32, o16, out16_lo, lo_fmt, partial);
+    else if (J == 2) hipLaunchKernelGGL(concat_add_stats_kernel<2>, grid, dim3(256), lds, st, a, C1, s, c, C2, Npix, pix_per_chunk, out32, o16, out16_lo, lo_fmt, partial);
+    else hipLaunchKernelGGL(concat_add_stats_kernel<3>, grid, dim3(256), lds, st, a, C1, s, c, C2, Npix, pix_per_chunk, out32, o16, out16_lo, lo_fmt, partial);
     return pnc_launch_status();
 }
 

@@ -736,7 +736,7 @@ def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, be
         # (launching the pair per Infinity-Cache sized panel of frames was measured: slower, profiles/round3/ab_two_wg_and_mall_panels_r3c.txt)
         rt.be.groupnorm_stats(x32, C, F, N, C, ppc, part)
     else:
-        nrec = -(-N // GN_EPILOGUE_CHUNK)
+        nrec = part.numel() // (F * 96)          # the producer's records per frame (GEMM epilogues: 64-pixel chunks; the concat: _ppc(N))
     if rt.vshard is not None:           # statistics of the whole panorama, not of this rank's band of views
         part = rt.vshard.combine_stats(part, F, nrec, rt.be)
     rt.be.groupnorm_apply(x32, C, F, N, C, ppc, part, gamma, beta, eps, silu, y, C, ylo, n_records=nrec)

@@ -111,7 +111,7 @@ _SIGNATURES = {
     "pnc_cfg_euler_step": (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "pnc_tokens_to_nchw_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "pnc_concat_add": (_I, [_P, _I, _P, _P, _I, _L, _P, _P, _P, _I, _P]),
-    "pnc_concat_add_stats": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
+    "pnc_concat_add_stats": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "pnc_add_f32": (_I, [_P, _P, _L, _P, _P, _P, _I, _P]),
     "pnc_cast_f16": (_I, [_P, _L, _P, _P, _I, _P]),
 }
@@ -428,14 +428,14 @@ def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):
            "pnc_tokens_to_nchw_f32")
 
 
-def concat_add(a32, C1, s32, c32, C2, M, out32, out16, out16_lo=None, gn_part=None, frames=0):
-    """`gn_part` (+ `frames`: M = frames * Npix): also write the GroupNorm(32) records of the output, one per 64-pixel chunk
-    (pnc_concat_add_stats; engine.gn_records sizes the buffer) — the GroupNorm that reads the concat then launches no statistics"""
+def concat_add(a32, C1, s32, c32, C2, M, out32, out16, out16_lo=None, gn_part=None, frames=0, ppc=64):
+    """`gn_part` (+ `frames`: M = frames * Npix; `ppc`: pixels per record): also write the GroupNorm(32) records of the output
+    (pnc_concat_add_stats; [frames][ceil(Npix / ppc)][32][3] floats) — the GroupNorm that reads the concat then launches no statistics"""
     nb = M * (4.0 * C1 + (8.0 if c32 is not None else 4.0) * C2 + (6.0 + _lo_bytes(out16_lo)) * (C1 + C2))
     if gn_part is not None:
         if frames < 1 or M % frames:
             raise PncError(f"concat_add with gn_part: M = {M} rows are not {frames} whole frames")
-        _check(_timed("elementwise", 0.0, nb, load().pnc_concat_add_stats, _ptr(a32), C1, _ptr(s32), _ptr(c32), C2, frames, M // frames,
+        _check(_timed("elementwise", 0.0, nb, load().pnc_concat_add_stats, _ptr(a32), C1, _ptr(s32), _ptr(c32), C2, frames, M // frames, ppc,
                       _ptr(out32), _ptr(out16), _ptr(out16_lo), lo_fmt(out16_lo), _ptr(gn_part, torch.float32, "gn_part"), _stream()),
                "pnc_concat_add_stats")
         return

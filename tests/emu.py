@@ -416,7 +416,7 @@ def tokens_to_nchw_f32(x32, ld, F, Npix, Cch, out32):
     out32.reshape(-1)[: F * Cch * Npix].view(F, Cch, Npix).copy_(X.permute(0, 2, 1))
 
 
-def concat_add(a32, C1, s32, c32, C2, M, out32, out16, out16_lo=None, gn_part=None, frames=0):
+def concat_add(a32, C1, s32, c32, C2, M, out32, out16, out16_lo=None, gn_part=None, frames=0, ppc=64):
     a = a32.reshape(-1)[: M * C1].view(M, C1)
     s = s32.reshape(-1)[: M * C2].view(M, C2)
     if c32 is not None:
@@ -430,8 +430,8 @@ def concat_add(a32, C1, s32, c32, C2, M, out32, out16, out16_lo=None, gn_part=No
         if out16_lo is not None:
             out16_lo.reshape(-1)[: y.numel()].copy_(_lo(y.reshape(-1), h, out16_lo))
     if gn_part is not None:       # pnc_concat_add_stats: the records pnc_groupnorm_stats writes for 64-pixel chunks
-        assert frames >= 1 and M % frames == 0 and (C1 + C2) % 64 == 0
-        groupnorm_stats(y.contiguous(), C1 + C2, frames, M // frames, C1 + C2, 64, gn_part)
+        assert frames >= 1 and M % frames == 0 and (C1 + C2) % 128 == 0
+        groupnorm_stats(y.contiguous(), C1 + C2, frames, M // frames, C1 + C2, ppc, gn_part)
 
 
 def add_f32(x32, a32, n, y32, y16, y16_lo=None):

@@ -1200,9 +1200,9 @@ def test_layout_helpers():
     assert torch.equal(y16, aa.half())
 
 
-@pytest.mark.parametrize("F,Npix,C1,C2,ctrl,lo", [(2, 192, 320, 320, True, "e4m3"), (3, 100, 640, 320, False, None), (1, 768, 1280, 1280, True, "f16"),
-                                                 (2, 64, 64, 64, True, None)])
-def test_concat_add_with_groupnorm_records(F, Npix, C1, C2, ctrl, lo):
+@pytest.mark.parametrize("F,Npix,C1,C2,ctrl,lo,ppc", [(2, 192, 320, 320, True, "e4m3", 64), (3, 100, 640, 320, False, None, 16), (1, 768, 1280, 1280, True, "f16", 16),
+                                                     (2, 64, 64, 64, True, None, 64), (2, 3072, 1280, 640, True, "e4m3", 64)])
+def test_concat_add_with_groupnorm_records(F, Npix, C1, C2, ctrl, lo, ppc):
     """pnc_concat_add_stats (ABI 5): the concat's values equal pnc_concat_add's bit for bit, its records equal
     pnc_groupnorm_stats(..., 64) of the result up to fp32 summation order, they are reproducible bit for bit, and
     pnc_groupnorm_apply on them equals the two-launch path to fp16 rounding"""
@@ -1213,14 +1213,14 @@ def test_concat_add_with_groupnorm_records(F, Npix, C1, C2, ctrl, lo):
     def outs():
         return dict(o32=torch.zeros(M, C, device=DEV), o16=torch.zeros(M, C, device=DEV, dtype=torch.float16),
                     lo=None if lod is None else torch.zeros(M, C, device=DEV, dtype=lod))
-    nrec = -(-Npix // 64)
+    nrec = -(-Npix // ppc)
     ref, got, got2 = outs(), outs(), outs()
     part, part2 = torch.zeros(F * nrec * 96, device=DEV), torch.zeros(F * nrec * 96, device=DEV)
     hip.concat_add(a, C1, s_, c, C2, M, ref["o32"], ref["o16"], ref["lo"])
-    hip.concat_add(a, C1, s_, c, C2, M, got["o32"], got["o16"], got["lo"], gn_part=part, frames=F)
-    hip.concat_add(a, C1, s_, c, C2, M, got2["o32"], got2["o16"], got2["lo"], gn_part=part2, frames=F)
+    hip.concat_add(a, C1, s_, c, C2, M, got["o32"], got["o16"], got["lo"], gn_part=part, frames=F, ppc=ppc)
+    hip.concat_add(a, C1, s_, c, C2, M, got2["o32"], got2["o16"], got2["lo"], gn_part=part2, frames=F, ppc=ppc)
     pref = torch.zeros(F * nrec * 96, device=DEV)
-    hip.groupnorm_stats(ref["o32"], C, F, Npix, C, 64, pref)
+    hip.groupnorm_stats(ref["o32"], C, F, Npix, C, ppc, pref)
     torch.cuda.synchronize()
     assert torch.equal(got["o32"], ref["o32"]) and torch.equal(got["o16"], ref["o16"]) and torch.equal(part, part2)
     if lo:
@@ -1231,13 +1231,13 @@ def test_concat_add_with_groupnorm_records(F, Npix, C1, C2, ctrl, lo):
     check("record M2", P[..., 2], R[..., 2], 1e-4 * float(R[..., 2].max()), 1e-5)
     gamma, beta = rnd(C, seed=4) * 0.5 + 1, rnd(C, seed=5) * 0.3
     y0, y1 = (torch.zeros(M, C, device=DEV, dtype=torch.float16) for _ in range(2))
-    hip.groupnorm_apply(ref["o32"], C, F, Npix, C, 64, pref, gamma, beta, 1e-5, 1, y0, C)
+    hip.groupnorm_apply(ref["o32"], C, F, Npix, C, ppc, pref, gamma, beta, 1e-5, 1, y0, C)
     hip.groupnorm_apply(ref["o32"], C, F, Npix, C, 128, part, gamma, beta, 1e-5, 1, y1, C, n_records=nrec)
     torch.cuda.synchronize()
     check("apply on the concat's records", y1, y0, 2e-3, 2e-3)
     e = outs()
     epart = torch.zeros(F * nrec * 96, device=DEV)
-    emu.concat_add(a, C1, s_, c, C2, M, e["o32"], e["o16"], e["lo"], gn_part=epart, frames=F)
+    emu.concat_add(a, C1, s_, c, C2, M, e["o32"], e["o16"], e["lo"], gn_part=epart, frames=F, ppc=ppc)
     check("records vs emu", P[..., 1], epart.view(F, nrec, 32, 3)[..., 1], 2e-6, 2e-6)
 
 

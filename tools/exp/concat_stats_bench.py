@@ -17,14 +17,14 @@ for (H, W, C1, C2) in [(4, 48, 1280, 1280)] * 3 + [(8, 96, 1280, 1280), (8, 96, 
     lo = torch.empty(M, C, device=DEV, dtype=torch.uint8)
     ppc = max(16, min(128, Npix // 48), -(-Npix // 256))
     part1 = torch.empty(F * (-(-Npix // ppc)) * 96, device=DEV)
-    part2 = torch.empty(F * (-(-Npix // 64)) * 96, device=DEV)
+    part2 = torch.empty(F * (-(-Npix // ppc)) * 96, device=DEV)
 
     def two(i):
         hip.concat_add(a, C1, s_, c, C2, M, o32, o16, lo)
         hip.groupnorm_stats(o32, C, F, Npix, C, ppc, part1)
 
     def one(i):
-        hip.concat_add(a, C1, s_, c, C2, M, o32, o16, lo, gn_part=part2, frames=F)
+        hip.concat_add(a, C1, s_, c, C2, M, o32, o16, lo, gn_part=part2, frames=F, ppc=ppc)
     t = timed({"two": two, "one": one}, iters=10, rounds=5)
     tot[0] += t["two"]; tot[1] += t["one"]
     print(f"{H}x{W} C1={C1} C2={C2}: concat + stats launch {t['two']:7.1f} us   concat with records {t['one']:7.1f} us", flush=True)

@@ -352,7 +352,7 @@ int pnc_concat_add(const float* a, int C1, const float* s, const float* c, int C
 /* the same concatenation over F frames of Npix pixels (M = F * Npix rows) that ALSO writes the GroupNorm(32) statistics of its output —
  * records {n, mean, M2} [F][ceil(Npix / pix_per_chunk)][32][3] as pnc_groupnorm_stats(..., pix_per_chunk, ...) would, for
  * pnc_groupnorm_apply(..., n_records = ceil(Npix / pix_per_chunk)): the first GroupNorm of the ResBlock3D that follows the concat
- * (openaimodel.py:1311-1314 -> 499-503) then needs no statistics launch.  (C1 + C2) % 128 == 0.  Deterministic (no float atomics).
+ * (openaimodel.py:1311-1314 -> 499-503) then needs no statistics launch.  (C1 + C2) % 64 == 0.  Deterministic (no float atomics).
  * ABI 5 (round 5). */
 int pnc_concat_add_stats(const float* a, int C1, const float* s, const float* c, int C2, int F, int Npix, int pix_per_chunk,
                          float* out32, void* out16, void* out16_lo, int lo_fmt, float* partial, void* stream);

@@ -513,12 +513,13 @@ extern "C" int pnc_concat_add_stats(const float* a, int C1, const float* s, cons
     if (lo_fmt != PNC_LO_F16 && lo_fmt != PNC_LO_E4M3) return PNC_EINVAL;
     if ((!out32 && !out16) || (out16_lo && !out16)) return PNC_EINVAL;
     const int C = C1 + C2;
-    if (C % 128 || C > GN_MAXC) return PNC_EINVAL;        // (C % 128: four-channel vectors never straddle a group)
+    if (C % 64 || C > GN_MAXC) return PNC_EINVAL;         // (channel sums are kept per channel: a float4 vector may straddle two groups)
     if (((uintptr_t)a | (uintptr_t)s | (uintptr_t)c | (uintptr_t)out32) & 15) return PNC_EALIGN;
     const int nchunk = (Npix + pix_per_chunk - 1) / pix_per_chunk;
     // channel slices of whole groups, at most 3 float4 vectors per lane: S = 1, 2, 4 or 8
     int S = 1;
-    while (S < 8 && (C / S / 4 + 63) / 64 > 3) S *= 2;
+    while (S < 8 && (C / S / 4 + 63) / 64 > 3 && (C / (2 * S)) % 4 == 0) S *= 2;        // slices of whole groups AND whole float4 vectors
+    if ((C / S / 4 + 63) / 64 > 3) return PNC_EINVAL;
     const int J = (C / S / 4 + 63) / 64;
     const size_t lds = (size_t)4 * (C / S) * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

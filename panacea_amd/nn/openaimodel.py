@@ -614,7 +614,7 @@ class UNetModel3D(nn.Module, Packable):
             # (round 5: the same pass writes the statistics of the GroupNorm that reads the concat — the first norm of the block's
             # ResBlock3D —: 12 statistics launches and their read of C1 + C2 fp32 channels per step gone)
             part, ppc = None, E._ppc(h.H * h.W)
-            if ct % 128 == 0 and E.GN_FROM_EPILOGUE:
+            if ct % 64 == 0 and E.GN_FROM_EPILOGUE:
                 part = rt.empty((h.F * (-(-(h.H * h.W) // ppc)) * 96,), torch.float32)
             rt.be.concat_add(h.f32, h.C, s.f32, None if c is None else c.f32, s.C, h.M, cat32, cat16, cat16lo,
                              **({} if part is None else dict(gn_part=part, frames=h.F, ppc=ppc)))

@@ -430,7 +430,7 @@ def concat_add(a32, C1, s32, c32, C2, M, out32, out16, out16_lo=None, gn_part=No
         if out16_lo is not None:
             out16_lo.reshape(-1)[: y.numel()].copy_(_lo(y.reshape(-1), h, out16_lo))
     if gn_part is not None:       # pnc_concat_add_stats: the records pnc_groupnorm_stats writes for 64-pixel chunks
-        assert frames >= 1 and M % frames == 0 and (C1 + C2) % 128 == 0
+        assert frames >= 1 and M % frames == 0 and (C1 + C2) % 64 == 0
         groupnorm_stats(y.contiguous(), C1 + C2, frames, M // frames, C1 + C2, ppc, gn_part)
 
 

@@ -1201,7 +1201,7 @@ def test_layout_helpers():
 
 
 @pytest.mark.parametrize("F,Npix,C1,C2,ctrl,lo,ppc", [(2, 192, 320, 320, True, "e4m3", 64), (3, 100, 640, 320, False, None, 16), (1, 768, 1280, 1280, True, "f16", 16),
-                                                     (2, 64, 64, 64, True, None, 64), (2, 3072, 1280, 640, True, "e4m3", 64)])
+                                                     (2, 64, 64, 64, True, None, 64), (2, 3072, 1280, 640, True, "e4m3", 64), (2, 256, 640, 320, True, "e4m3", 128)])
 def test_concat_add_with_groupnorm_records(F, Npix, C1, C2, ctrl, lo, ppc):
     """pnc_concat_add_stats (ABI 5): the concat's values equal pnc_concat_add's bit for bit, its records equal
     pnc_groupnorm_stats(..., 64) of the result up to fp32 summation order, they are reproducible bit for bit, and

@@ -6,7 +6,7 @@ TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots"), calibrated on the LayerNo
 
 Reads the counter_collection CSVs under the two rocprofv3 output directories, prints per-kernel tables and merges a record
     records[precision] = {build_stamp, fetch/write factors, traffic_GB_calibrated, ...}
-into profiles/round4/pmc_traffic.json, which bench.py reports as roofline.traffic ONLY while the build stamp matches.
+into profiles/round5/pmc_traffic.json, which bench.py reports as roofline.traffic ONLY while the build stamp matches.
 """
 import collections
 import csv
@@ -63,7 +63,7 @@ def mfma_record(mdir, evals, step_ms):
 def main():
     if sys.argv[1] == "--mfma":
         mdir, evals, prec, step_ms = sys.argv[2], int(sys.argv[3]), sys.argv[4], float(sys.argv[5])
-        out = ROOT / "profiles" / "round4" / "pmc_traffic.json"
+        out = ROOT / "profiles" / "round5" / "pmc_traffic.json"
         doc = json.loads(out.read_text()) if out.exists() else {"records": {}}
         doc.setdefault("mfma", {})[prec] = mfma_record(mdir, evals, step_ms)
         out.write_text(json.dumps(doc, indent=1))
@@ -84,7 +84,7 @@ def main():
            "traffic_GB_calibrated": round((tf * ff + tw * wf) / 1e9, 1),
            "calibration": f"LayerNorm launches: {LN_BYTES_PER_EVAL / 1e9:.1f} GB known per evaluation vs counters "
                           f"{ln_f / 1e9:.2f} GB fetched / {ln_w / 1e9:.2f} GB written"}
-    out = ROOT / "profiles" / "round4" / "pmc_traffic.json"
+    out = ROOT / "profiles" / "round5" / "pmc_traffic.json"
     out.parent.mkdir(parents=True, exist_ok=True)
     doc = json.loads(out.read_text()) if out.exists() else {"records": {}}
     doc["records"][prec] = rec

@@ -2055,7 +2055,9 @@ static inline int splitk_slices(const PncGemmParams& p) {
     const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
     const int ktiles = (p.K + BK - 1) / BK;
     if (tiles > 96 || ktiles < 48) return 1;
-    return ktiles >= 320 ? 8 : (ktiles >= 160 ? 4 : 2);
+    // (round 5: 4 slices from 56 K tiles on — the 4x48 level's temporal convs (K = 3840: 60 tiles of 256x256 x 2 slices = 120 workgroups on
+    // 256 CUs, 257 TFLOP/s) and FF2 (K = 5120) fill the chip with 4; was 160)
+    return ktiles >= 320 ? 8 : (ktiles >= 56 ? 4 : 2);
 }
 
 // Tile geometries.  Every channel width of the network is a multiple of 320, so the preferred tile is 256x320 (8 waves

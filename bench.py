@@ -45,6 +45,7 @@ sys.path.insert(0, str(ROOT))
 # doubled batch (47.79 GFLOP per frame x 8 frames = 0.38): the work that is no longer done is not counted as achieved either
 ALGO_TFLOP_PER_STEP = 96.59 - 0.38
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16, MI355X_MICROARCH.md
+BOOST_SCLK_MHZ = 2400.0             # the clock that figure is quoted at
 GOLDEN_FULL = ROOT / "tests" / "golden" / "full_cfg3.npz"
 # the reference's own fp32 forward at BASELINE config 3 (oracle/gen_golden_full.py): (file, timestep index, input salt)
 GOLDEN_PINS = [("full_cfg3.npz", 999, 0), ("full_cfg3_t500.npz", 500, 0), ("full_cfg3_t39_s1.npz", 39, 1)]
@@ -189,6 +190,71 @@ def run_vae_decode(args, dev):
                                          f"{cdt:.1f} s; x64 linear extrapolation (under-counts the quadratic mid attention)",
                                "sample_seconds": cdt}
     print(json.dumps(out), flush=True)
+
+
+
+class ClockSampler:
+    """Shader clock and package power of the benchmarked GPU, read from sysfs (no fork, no tool) every 0.25 s while the timed region
+    runs.  The step holds the package near its power cap, and the clock it gets under that load — not the boost clock — is what the
+    MFMA peak scales with (profiles/round5/clocks_power_during_bench_r5x.txt).  Best effort: a box without the files reports None."""
+
+    def __init__(self, dev_index: int):
+        import glob
+        self.dir = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            if os.path.exists(f"/sys/bus/pci/devices/{bdf}/pp_dpm_sclk"):
+                self.dir = f"/sys/bus/pci/devices/{bdf}"
+        except Exception:          # noqa: BLE001 — older torch: no PCI ids on the properties
+            pass
+        if self.dir is None:
+            cards = glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")
+            if len(cards) == 1:
+                self.dir = os.path.dirname(cards[0])
+        self.sclk, self.power, self._stop, self._thr = [], [], None, None
+
+    def _read(self):
+        try:
+            for line in open(os.path.join(self.dir, "pp_dpm_sclk")).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    self.sclk.append(int("".join(ch for ch in line.split(":")[1] if ch.isdigit())))
+            import glob
+            for name in ("power1_average", "power1_input"):
+                hw = glob.glob(os.path.join(self.dir, "hwmon", "hwmon*", name))
+                if hw:
+                    self.power.append(int(open(hw[0]).read().strip()) / 1e6)
+                    break
+        except Exception:          # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        if self.dir is not None:
+            import threading
+            self._stop = threading.Event()
+
+            def loop():
+                while not self._stop.wait(0.25):
+                    self._read()
+            self._thr = threading.Thread(target=loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join(timeout=2.0)
+        return False
+
+    def record(self):
+        if not self.sclk:
+            return None
+        s = sorted(self.sclk)
+        rec = {"sclk_mhz_median": s[len(s) // 2], "sclk_mhz_min": s[0], "sclk_mhz_max": s[-1], "samples": len(s),
+               "note": "shader clock of this GPU (sysfs pp_dpm_sclk) sampled every 0.25 s inside the timed region"}
+        if self.power:
+            rec["package_power_w_mean"] = round(sum(self.power) / len(self.power), 1)
+        return rec
 
 
 def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, g_salt, den) -> dict:
@@ -570,6 +636,9 @@ def main():
             sync()
         barrier()
         sync()
+        clocks = ClockSampler(dev.index or 0) if dev.type == "cuda" and rank == 0 else None
+        if clocks is not None:
+            clocks.__enter__()
         t_start = time.perf_counter()
         for i in range(args.steps):
             j = (args.warmup + i) % nsig
@@ -577,6 +646,8 @@ def main():
         sync()
         barrier()
         elapsed = time.perf_counter() - t_start
+        if clocks is not None:
+            clocks.__exit__()
     if world > 1:
         tt = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -624,6 +695,12 @@ def main():
                            "frac": None if ach is None else ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": tnote,
                            "basis": f"{ALGO_TFLOP_PER_STEP:.2f} algorithmic TFLOP per step (SURVEY.md §8d less the duplicate half of the hint stem; a precise operand's second pass is "
                                     "not counted as useful work) / measured step time, per GPU"}
+        crec = clocks.record() if clocks is not None else None
+        if crec:
+            crec["peak_at_sampled_clock"] = round(MFMA_PEAK_TFLOPS * crec["sclk_mhz_median"] / BOOST_SCLK_MHZ, 1)
+            if ach is not None:
+                crec["frac_of_peak_at_sampled_clock"] = round(ach / crec["peak_at_sampled_clock"], 4)
+            out["roofline"]["clocks"] = crec          # `peak` and `frac` above stay the guide's boost-clock figures
         if T != 8:
             out["roofline"]["basis"] = "sum of 2MNK over the contractions launched in one step (HIP-event pass) / measured step time"
     if parity:

@@ -193,6 +193,12 @@ def run_vae_decode(args, dev):
 
 
 
+def _exchange_counts(*shards):
+    """exchanges and bytes of a shard and of its side twin (the ControlNet's own process group, round 5), summed"""
+    live = [s_ for s_ in shards if s_ is not None]
+    return sum(s_.exchanges for s_ in live), sum(s_.bytes_sent for s_ in live)
+
+
 class ClockSampler:
     """Shader clock and package power of the benchmarked GPU, read from sysfs (no fork, no tool) every 0.25 s while the timed region
     runs.  The step holds the package near its power cap, and the clock it gets under that load — not the boost clock — is what the
@@ -278,8 +284,9 @@ def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, 
     smp.fuse = not args.no_fused_step
     shard, vshard = groups.frame_shard(), groups.view_shard()
     side = not args.one_stream                          # the ControlNet on its side stream, over process groups of its own
-    parallel.apply_frame_shard(net, shard, groups.frame_shard(side=True) if side else None)
-    parallel.apply_view_shard(net, vshard, groups.view_shard(side=True) if side else None)
+    shard2, vshard2 = (groups.frame_shard(side=True), groups.view_shard(side=True)) if side else (None, None)
+    parallel.apply_frame_shard(net, shard, shard2)
+    parallel.apply_view_shard(net, vshard, vshard2)
     try:
         if shard is not None or vshard is not None:
             cond, uc = parallel.shard_conditioning(cond, layout, T), parallel.shard_conditioning(uc, layout, T)
@@ -318,14 +325,16 @@ def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, 
            "collective_backend": f"{args.backend} ({'RCCL over xGMI' if args.backend == 'nccl' else 'CPU self-test'}), {world} ranks",
            "cfg_all_gathers_per_step": 1 if layout.cfg > 1 else 0}
     if shard is not None:
-        rec["exchange"] = {"frame_exchanges_per_step": shard.exchanges // max(1, nsteps),
-                           "MB_sent_per_rank_and_step": round(shard.bytes_sent / max(1, nsteps) / 1e6, 1),
+        nx, nb = _exchange_counts(shard, shard2)
+        rec["exchange"] = {"frame_exchanges_per_step": nx // max(1, nsteps),
+                           "MB_sent_per_rank_and_step": round(nb / max(1, nsteps) / 1e6, 1),
                            "note": f"engine.FrameShard(resblock={shard.resblock!r}): ResBlock3D temporal sites = statistics all-reduce + one "
                                    "halo frame per neighbour; STT temporal branch pixel-sharded (DESIGN.md section 9)"}
     if vshard is not None:
+        nx, nb = _exchange_counts(vshard, vshard2)
         rec["view_exchange" if shard is not None else "exchange"] = {
-            "neighbour_exchanges_per_step": vshard.exchanges // max(1, nsteps),
-            "MB_sent_per_rank_and_step": round(vshard.bytes_sent / max(1, nsteps) / 1e6, 1),
+            "neighbour_exchanges_per_step": nx // max(1, nsteps),
+            "MB_sent_per_rank_and_step": round(nb / max(1, nsteps) / 1e6, 1),
             "note": "engine.ViewShard: conv halos, panorama GroupNorm statistics, neighbour views (DESIGN.md section 9)"}
     return rec
 
@@ -555,9 +564,12 @@ def main():
             cc[:-1] = zero_lat
             d["concat"] = cc
         x0 = sampling.share_noise_init(x0, cond["concat"], 0.07)
+    shard2 = vshard2 = None                               # the ControlNet's twins over process groups of its own (side stream)
     if shard is not None or vshard is not None:
-        parallel.apply_frame_shard(net, shard, None if args.one_stream else groups.frame_shard(side=True))
-        parallel.apply_view_shard(net, vshard, None if args.one_stream else groups.view_shard(side=True))
+        if not args.one_stream:
+            shard2, vshard2 = groups.frame_shard(side=True), groups.view_shard(side=True)
+        parallel.apply_frame_shard(net, shard, shard2)
+        parallel.apply_view_shard(net, vshard, vshard2)
         cond, uc = parallel.shard_conditioning(cond, layout, T), parallel.shard_conditioning(uc, layout, T)
     x = x0 * torch.sqrt(1.0 + sig[0] ** 2.0)
     x = parallel.local_views(parallel.local_frames(x, layout, T), layout)    # this rank's frame group / view band of the sample
@@ -739,14 +751,16 @@ def main():
                 dog.cancel()
     if shard is not None:
         nsteps = args.steps + args.warmup
-        out["config"]["exchange"] = {"frame_exchanges_per_step": shard.exchanges // max(1, nsteps),
-                                     "MB_sent_per_rank_and_step": round(shard.bytes_sent / max(1, nsteps) / 1e6, 1),
+        nx, nb = _exchange_counts(shard, shard2)
+        out["config"]["exchange"] = {"frame_exchanges_per_step": nx // max(1, nsteps),
+                                     "MB_sent_per_rank_and_step": round(nb / max(1, nsteps) / 1e6, 1),
                                      "note": f"engine.FrameShard(resblock={shard.resblock!r}): ResBlock3D temporal sites = statistics "
                                              "all-reduce + one halo frame per neighbour; STT temporal branch pixel-sharded (DESIGN.md §9)"}
     if vshard is not None:
         nsteps = args.steps + args.warmup
-        out["config"]["view_exchange" if shard is not None else "exchange"] = {"neighbour_exchanges_per_step": vshard.exchanges // max(1, nsteps),
-                                     "MB_sent_per_rank_and_step": round(vshard.bytes_sent / max(1, nsteps) / 1e6, 1),
+        nx, nb = _exchange_counts(vshard, vshard2)
+        out["config"]["view_exchange" if shard is not None else "exchange"] = {"neighbour_exchanges_per_step": nx // max(1, nsteps),
+                                     "MB_sent_per_rank_and_step": round(nb / max(1, nsteps) / 1e6, 1),
                                      "note": "engine.ViewShard: conv halos, panorama GroupNorm statistics, neighbour views (DESIGN.md §9)"}
 
     if rank == 0 and not args.no_kernel_breakdown and layout.per_sample == 1 and not args.emulate_kernels:

@@ -700,7 +700,10 @@ def main():
             if ent and ent.get("build_stamp") == cur:
                 traffic = ent["traffic_GB_calibrated"] * 1e9
                 tnote = (f"bytes per step at the L2<->fabric boundary (FETCH_SIZE x{ent['fetch_factor']} + WRITE_SIZE x{ent['write_factor']}, "
-                         f"separate --pmc passes of `{ent['command']}`, calibrated on the LayerNorm launches), build {cur[:12]}")
+                         f"separate --pmc passes of `{ent['command']}`, calibrated on the LayerNorm launches), build {cur[:12]}"
+                         + (f"; the step's launches only — the run's one-time weight packing ({ent['setup_GB_whole_run']} GB) is not a "
+                            f"step (rounds 2-4 divided it over the run's steps: {ent['traffic_GB_calibrated_rounds_2_to_4_definition']} GB)"
+                            if "setup_GB_whole_run" in ent else ""))
             elif ent:
                 tnote = f"PMC record is for build {ent.get('build_stamp', '?')[:12]}, this is {cur[:12]}: not reported"
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -314,7 +314,7 @@ class ViewShard:
 
         3x3 convs (all)              one halo column per side from the neighbour band         `band_operand`
         spatial GroupNorm(32)        per-(frame, group) statistics over the whole panorama     `combine_stats`
-        cross-view attention         keys / values of the two neighbouring views (circular:    `neighbour_views`
+        cross-view attention         keys / values of the two neighbouring views (circular:    `halo_views`
                                      attention.py:545-559; view 5 attends view 4 only)
 
     Neighbour exchanges are point-to-point (one xGMI link per neighbour pair on MI355X); the statistics are one tiny

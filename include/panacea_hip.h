@@ -36,7 +36,7 @@ const char* pnc_version(void);
 /* ABI revision of this header (bumped whenever a parameter struct or a prototype changes): 5 (round 5: + pnc_concat_add_stats)
  * (round 4: + pnc_groupnorm_combine, + PNC_OPT_ATTN_DEFER_MAX, PNC_OPT_GEMM_PERSIST is a bit set, - pnc_ff_chain_*;
  *  round 5: + pnc_concat_add_stats, + PNC_OPT_GEMM_STAGGER) */
-#define PNC_ABI_VERSION 5
+#define PNC_ABI_VERSION 6
 int pnc_abi_version(void);
 /* hex SHA-256 of the sources + compile flags the library was built from (panacea_amd/build.py computes the same digest over
  * the checkout): a loader compares the two and refuses a library built from other sources instead of calling it with
@@ -322,6 +322,16 @@ int pnc_layernorm(const float* x, int ldx, int M, int C,
 int pnc_linear_smallm(const float* a, int lda, const void* W, const float* bias,
                       float* out, int ldo, int M, int N, int K, int silu_in, int silu_out,
                       void* stream);
+/* The same linear for nseg sites in ONE launch (ABI 6): W [N][K] holds the sites' weight rows back to back, seg_start[0 .. nseg]
+ * (HOST array, ascending, seg_start[0] = 0, seg_start[nseg] = N, every entry % 4 == 0, nseg <= PNC_SMALLM_MAX_SEGS) names each
+ * site's column range, and the output is one contiguous [Mtot][width_s] block per site, blocks back to back:
+ *     out[seg_start[s] * Mtot + (m0 + m) * width_s + (n - seg_start[s])],  m < M <= 16 rows of this call, m0 + M <= Mtot
+ * — the [rows][N_site] row-bias operand each site's GEMM epilogue reads.  Per column bit-identical to pnc_linear_smallm.
+ * -> the emb_layers Linear of every ResBlock of a network after one time_embed (openaimodel.py:440-447, 1296-1298) */
+#define PNC_SMALLM_MAX_SEGS 64
+int pnc_linear_smallm_segments(const float* a, int lda, const void* W, const float* bias, float* out, int M,
+                               int m0, int Mtot, int N, int K, const int32_t* seg_start, int nseg, int silu_in,
+                               int silu_out, void* stream);
 /* sinusoidal timestep embedding out[f] = [cos(t*freqs) | sin(t*freqs)], fp32; freqs[dim/2] is
  * tabulated by the caller  (diffusionmodules/util.py:224-248) */
 int pnc_timestep_embedding(const int64_t* t, int F, int dim, const float* freqs,

@@ -50,6 +50,74 @@ __global__ __launch_bounds__(256) void linear_smallm_kernel(const float* __restr
     }
 }
 
+// The same linear for MANY sites in one launch (round 5): W holds the sites' weight rows back to back (N = sum of the sites'
+// widths), the output is laid out one contiguous [Mtot x width] block per site (segment), blocks back to back — what each site's
+// consumer (the row-bias operand of its GEMM epilogue: [rows][N_site]) reads.  One wave per SEG_NC consecutive columns: the 16 x K
+// activation rows are read once per wave instead of once per column.  Per column the K order, the fma chain and the wave
+// reduction are those of linear_smallm_kernel: bit-identical to one launch per site.
+constexpr int SEG_NC = 4;
+struct SmallmSegs {
+    int nseg;
+    int start[PNC_SMALLM_MAX_SEGS + 1];
+};
+
+__global__ __launch_bounds__(256) void linear_smallm_seg_kernel(const float* __restrict__ a, int lda,
+                                                                const half_t* __restrict__ W,
+                                                                const float* __restrict__ bias,
+                                                                float* __restrict__ out, int M, int m0, int Mtot, int N,
+                                                                int K, int silu_in, int silu_out, SmallmSegs segs) {
+    const int lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SEG_NC;
+    if (n0 >= N) return;
+    float acc[SEG_NC][SM_MAXM];
+#pragma unroll
+    for (int c = 0; c < SEG_NC; ++c)
+#pragma unroll
+        for (int m = 0; m < SM_MAXM; ++m) acc[c][m] = 0.0f;
+    for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
+        float wf[SEG_NC][8];
+#pragma unroll
+        for (int c = 0; c < SEG_NC; ++c) {
+            const half8v w = *reinterpret_cast<const half8v*>(W + (int64_t)(n0 + c) * K + k0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wf[c][e] = (float)w[e];
+        }
+#pragma unroll
+        for (int m = 0; m < SM_MAXM; ++m) {
+            if (m < M) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(a + (int64_t)m * lda + k0);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(a + (int64_t)m * lda + k0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u0 = silu_in ? silu_f(x0[e]) : x0[e];
+                    const float u1 = silu_in ? silu_f(x1[e]) : x1[e];
+#pragma unroll
+                    for (int c = 0; c < SEG_NC; ++c) {
+                        acc[c][m] = fmaf(u0, wf[c][e], acc[c][m]);
+                        acc[c][m] = fmaf(u1, wf[c][e + 4], acc[c][m]);
+                    }
+                }
+            }
+        }
+    }
+    int s = 0;                                              // wave-uniform: a wave's columns lie in one segment (widths % SEG_NC == 0)
+    while (s + 1 < segs.nseg && n0 >= segs.start[s + 1]) ++s;
+    const int s0 = segs.start[s], len = segs.start[s + 1] - s0;
+    float* o = out + (int64_t)s0 * Mtot + (int64_t)m0 * len + (n0 - s0);
+#pragma unroll
+    for (int c = 0; c < SEG_NC; ++c) {
+        const float b = bias ? bias[n0 + c] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < SM_MAXM; ++m) {
+            if (m < M) {
+                float v = wave_sum(acc[c][m]) + b;
+                if (silu_out) v = silu_f(v);
+                if (lane == 0) o[(int64_t)m * len + c] = v;
+            }
+        }
+    }
+}
+
 __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int F, int dim,
                                           const float* __restrict__ freqs, float* __restrict__ out) {
     const int half = dim / 2;
@@ -228,6 +296,25 @@ extern "C" int pnc_linear_smallm(const float* a, int lda, const void* W, const f
     hipLaunchKernelGGL(linear_smallm_kernel, dim3((N + 3) / 4), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a, lda, reinterpret_cast<const half_t*>(W), bias,
                        out, ldo, M, N, K, silu_in, silu_out);
+    return pnc_launch_status();
+}
+
+extern "C" int pnc_linear_smallm_segments(const float* a, int lda, const void* W, const float* bias, float* out, int M,
+                                          int m0, int Mtot, int N, int K, const int32_t* seg_start, int nseg, int silu_in,
+                                          int silu_out, void* stream) {
+    if (!a || !W || !out || !seg_start || M < 1 || M > SM_MAXM || m0 < 0 || m0 + M > Mtot || N < 1 || K < 8) return PNC_EINVAL;
+    if (K % 8 || lda % 4 || nseg < 1 || nseg > PNC_SMALLM_MAX_SEGS) return PNC_EINVAL;
+    if (((uintptr_t)a | (uintptr_t)W) & 15) return PNC_EALIGN;
+    SmallmSegs segs;
+    segs.nseg = nseg;
+    if (seg_start[0] != 0 || seg_start[nseg] != N) return PNC_EINVAL;
+    for (int i = 0; i <= nseg; ++i) {
+        if (seg_start[i] % SEG_NC || (i > 0 && seg_start[i] <= seg_start[i - 1])) return PNC_EINVAL;
+        segs.start[i] = seg_start[i];
+    }
+    const int waves = N / SEG_NC;
+    hipLaunchKernelGGL(linear_smallm_seg_kernel, dim3((waves + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, lda,
+                       reinterpret_cast<const half_t*>(W), bias, out, M, m0, Mtot, N, K, silu_in, silu_out, segs);
     return pnc_launch_status();
 }
 

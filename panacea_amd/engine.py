@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -543,6 +544,7 @@ class Runtime:
         self.n_text = 77
         self.trace: Optional[Dict[str, torch.Tensor]] = None
         self.text_kv: Dict[int, tuple] = {}            # per cross-attention site: (k, ldk, vt, ldvt, vt_gstride)
+        self.emb_proj: Dict[int, torch.Tensor] = {}    # per ResBlock3D: emb_layers(emb), [F, C] fp32 (nn.openaimodel.EmbProjector)
         self.text_frozen = False                       # text_kv / guided come from StepInvariants (sampler hoisting)
         self.guided: Optional["Act"] = None            # precomputed ControlNet hint-stem output
 
@@ -711,6 +713,7 @@ def _ppc(npix: int) -> int:
 
 GN_EPILOGUE_CHUNK = 64      # pixels per record of PncGemmParams.gn_part (the temporal conv's 64-row wave blocks)
 GN_FROM_EPILOGUE = True     # False (bench.py --no-gn-epilogue, A/B): every spatial GroupNorm launches its own statistics kernel
+EMB_BATCH = os.environ.get("PNC_EMB_BATCH", "1") != "0"      # A/B: "0" = one emb_layers launch per ResBlock3D (rounds 1-4)
 
 
 def gn_records(rt: Runtime, F: int, N: int) -> Optional[torch.Tensor]:

@@ -20,7 +20,7 @@ HEADER = PKG.parent / "include" / "panacea_hip.h"
 
 A_PLAIN, A_CONV3X3, A_CONV1D_T = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 5          # PNC_ABI_VERSION of include/panacea_hip.h this binding was written against
+ABI_VERSION = 6          # PNC_ABI_VERSION of include/panacea_hip.h this binding was written against
 LO_F16, LO_E4M3 = 0, 1   # PNC_LO_*: storage format of the lo plane of a precise operand
 # dtype of a lo-plane tensor <-> format: an fp16 tensor holds fp16(r), a uint8 tensor OCP e4m3 bytes (one per element)
 LO_DTYPE = {LO_F16: torch.float16, LO_E4M3: torch.uint8}
@@ -106,6 +106,7 @@ _SIGNATURES = {
     "pnc_groupnorm_temporal_silu": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _I, _P]),
     "pnc_layernorm": (_I, [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P, _P]),
     "pnc_linear_smallm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "pnc_linear_smallm_segments": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
     "pnc_timestep_embedding": (_I, [_P, _I, _I, _P, _P, _P]),
     "pnc_nchw_to_tokens_f16": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     "pnc_cfg_euler_step": (_I, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
@@ -404,6 +405,15 @@ def layernorm(x32, ldx, M, Cch, gamma, beta, eps, y16, ldy, y16_lo=None):
 def linear_smallm(a32, lda, w16, bias, out32, ldo, M, N, K, silu_in=False, silu_out=False):
     _check(_timed("linear_smallm", 2.0 * M * N * K, 2.0 * N * K, load().pnc_linear_smallm, _ptr(a32), lda, _ptr(w16),
                   _ptr(bias), _ptr(out32), ldo, M, N, K, int(silu_in), int(silu_out), _stream()), "pnc_linear_smallm")
+
+
+def linear_smallm_segments(a32, lda, w16, bias, out32, M, m0, Mtot, N, K, seg_start, silu_in=False, silu_out=False):
+    """the same linear for len(seg_start) - 1 sites in one launch: out32 = one contiguous [Mtot, width] block per site, blocks back
+    to back (include/panacea_hip.h); `seg_start` = the sites' first columns + [N], a host sequence"""
+    segs = (C.c_int32 * len(seg_start))(*seg_start)
+    _check(_timed("linear_smallm", 2.0 * M * N * K, 2.0 * N * K, load().pnc_linear_smallm_segments, _ptr(a32), lda, _ptr(w16),
+                  _ptr(bias), _ptr(out32), M, m0, Mtot, N, K, C.cast(segs, C.c_void_p), len(seg_start) - 1, int(silu_in),
+                  int(silu_out), _stream()), "pnc_linear_smallm_segments")
 
 
 def timestep_embedding(t_i64, F, dim, freqs, out32):

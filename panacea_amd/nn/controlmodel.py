@@ -96,6 +96,7 @@ class ControlNet3D(UNetModel3D):
     def _run_control(self, rt: Runtime, x16: Act, hint: torch.Tensor, emb32: torch.Tensor) -> List[Act]:
         pk = self.packed()
         self._project_text(rt)
+        self._project_emb(rt, emb32)
         guided = rt.guided if rt.guided is not None else self._hint_stem(rt, hint)
         outs, h = [], x16
         for i, module in enumerate(self.input_blocks):

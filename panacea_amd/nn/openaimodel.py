@@ -233,6 +233,14 @@ class ResBlock3D(TimestepBlock, Packable):
             pk["ws"], pk["bs"] = E.pk_linear(self.skip_connection.weight), f32(self.skip_connection.bias)
         return pk
 
+    def _emb_out(self, rt: Runtime, emb32: torch.Tensor, pk, F: int, Co: int) -> torch.Tensor:
+        """emb_layers(emb) of this block, [F, Co] fp32: the network's EmbProjector computed it for every block in one launch
+        (same values), or — a block run on its own — its own launch"""
+        out = rt.emb_proj.get(id(self))
+        if out is not None and out.shape == (F, Co):
+            return out
+        return E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
+
     def _run(self, rt: Runtime, x: Act, emb32: torch.Tensor, want_f16: bool = False, want_stats: bool = False) -> Act:
         if rt.T != self.num_frames:
             raise ValueError(f"runtime has {rt.T} frames per sample, block was built for {self.num_frames}")
@@ -259,7 +267,7 @@ class ResBlock3D(TimestepBlock, Packable):
             # Round 4: the site stays in the FRAME layout.  The temporal GroupNorm's per-(pixel, group) sums are added over the frame
             # group (256 B per pixel), the normalised fp16 operand gets ONE halo frame from each neighbour rank, and the temporal
             # conv reads the (T_local + 2)-frame layout (PncGemmParams.t_halo); the fp32 stream h never leaves the rank.
-            emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
+            emb_out = self._emb_out(rt, emb32, pk, F, Co)
             t16, t16lo = E.gn_temporal_sharded(rt, sh, h, N, Co, pk["gt1"], pk["bt1"], 1e-5)
             tch = dict(C=Co, T=rt.T_local, Npix=N, halo=1)
             part1 = E.gn_records(rt, F, N)
@@ -275,7 +283,7 @@ class ResBlock3D(TimestepBlock, Packable):
             s = self._skip(rt, x, pk)
             h = pend.result()
         else:
-            emb_out = E.small_linear(rt, emb32, pk["we"], pk["be"], F, Co, self.emb_channels)
+            emb_out = self._emb_out(rt, emb32, pk, F, Co)
         if not halo:
             t16, t16lo = E.gn_temporal(rt, h, Nt, Co, pk["gt1"], pk["bt1"], 1e-5)
             # the GroupNorm of out_layers reads what this conv writes: its statistics come out of the conv's epilogue (frame layout only)
@@ -335,6 +343,40 @@ class ResBlock3D(TimestepBlock, Packable):
         rt.prec = E.precision(self.precision)
         semb = torch.nn.functional.silu(emb.to(torch.float32)).contiguous()      # _run takes SiLU(emb)
         return self._run(rt, act_from_nchw(rt, x), semb).to_nchw().to(x.dtype)
+
+
+class EmbProjector:
+    """Batches the `emb_layers` Linear of every ResBlock3D of a network (openaimodel.py:440-447: SiLU -> Linear(time_embed_dim, C),
+    added to h per frame at :519-531).  Its input is the network's one SiLU(time embedding): the 22 (UNet) + 11 (ControlNet)
+    launches of F <= 16 rows per evaluation — ≈ 27 us each at a few percent of the chip, serialised on their stream — become one
+    launch per network (`pnc_linear_smallm_segments`: the blocks' weight rows back to back, one contiguous [F, C] output per
+    block; per column the arithmetic of the single launch, bit-identical)."""
+
+    def __init__(self, root):
+        self.blocks = [m for m in root.modules() if isinstance(m, ResBlock3D)]
+        self._pk = None
+
+    def pack(self):
+        w = torch.cat([b.emb_layers[1].weight for b in self.blocks], dim=0)
+        bias = torch.cat([b.emb_layers[1].bias for b in self.blocks], dim=0)
+        seg = [0]
+        for b in self.blocks:
+            seg.append(seg[-1] + b.out_channels)
+        return E.pk_linear(w), E.pk_f32(bias), seg
+
+    def run(self, rt: Runtime, emb32: torch.Tensor):
+        if not self.blocks or len(self.blocks) > 64 or any(b.out_channels % 4 for b in self.blocks):
+            return
+        if self._pk is None:
+            with torch.no_grad():
+                self._pk = self.pack()
+        w, bias, seg = self._pk
+        F, K = emb32.shape[0], self.blocks[0].emb_channels
+        out = rt.empty((seg[-1] * F,), torch.float32)
+        for m0 in range(0, F, 16):
+            rt.be.linear_smallm_segments(emb32[m0:], K, w, bias, out, min(16, F - m0), m0, F, seg[-1], K, seg)
+        for b, s0, s1 in zip(self.blocks, seg[:-1], seg[1:]):
+            rt.emb_proj[id(b)] = out[s0 * F:s1 * F].view(F, s1 - s0)
 
 
 class _OwnBlocks:
@@ -444,6 +486,7 @@ class UNetModel3D(nn.Module, Packable):
     def invalidate_packed(self):
         super().invalidate_packed()
         self.__dict__.pop("_text_proj", None)
+        self.__dict__.pop("_emb_proj", None)
 
     # engine.FrameShard when the frames of every sample are sharded over a process group (panacea_amd.parallel); the
     # batch then carries num_frames / G frames per sample
@@ -520,6 +563,17 @@ class UNetModel3D(nn.Module, Packable):
             self.__dict__["_text_proj"] = tp
         tp.run(rt)
 
+    def _project_emb(self, rt: Runtime, emb32: torch.Tensor):
+        """emb_layers(emb) of every ResBlock3D of this network in one launch (EmbProjector); not in the round-2 frame sharding,
+        whose sites read the rows of ALL frames (rt.emb_all)"""
+        if (rt.shard is not None and rt.shard.resblock != "halo") or not E.EMB_BATCH:
+            return
+        ep = self.__dict__.get("_emb_proj")
+        if ep is None:
+            ep = EmbProjector(_OwnBlocks(self))
+            self.__dict__["_emb_proj"] = ep
+        ep.run(rt, emb32)
+
     # ---- packed parameters owned by the network itself (time embedding MLP, output head)
     def _pack(self):
         te = self.time_embed
@@ -585,6 +639,7 @@ class UNetModel3D(nn.Module, Packable):
         residuals, or a callable returning that list (called after the middle block: the join point when the
         ControlNet runs on a second stream)."""
         self._project_text(rt)
+        self._project_emb(rt, emb32)
         hs, h = [], x16
         nb = len(self.input_blocks)
         for i, module in enumerate(self.input_blocks):

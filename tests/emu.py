@@ -379,6 +379,20 @@ def linear_smallm(a32, lda, w16, bias, out32, ldo, M, N, K, silu_in=False, silu_
     _mat(out32, M, N, ldo).copy_(y)
 
 
+def linear_smallm_segments(a32, lda, w16, bias, out32, M, m0, Mtot, N, K, seg_start, silu_in=False, silu_out=False):
+    A = _mat(a32, M, K, lda)
+    if silu_in:
+        A = TF.silu(A)
+    y = A @ w16.reshape(-1)[: N * K].view(N, K).float().t()
+    if bias is not None:
+        y = y + bias.reshape(-1)[:N]
+    if silu_out:
+        y = TF.silu(y)
+    flat = out32.reshape(-1)
+    for s0, s1 in zip(seg_start[:-1], seg_start[1:]):
+        flat[s0 * Mtot:s1 * Mtot].view(Mtot, s1 - s0)[m0:m0 + M].copy_(y[:, s0:s1])
+
+
 def timestep_embedding(t_i64, F, dim, freqs, out32):
     args = t_i64.reshape(-1)[:F, None].float() * freqs.reshape(-1)[None, : dim // 2]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)

@@ -1308,3 +1308,38 @@ def test_lo_planes_of_norms_and_helpers():
     hip.cast_f16(aa, Mh * Ca, y16, ylo)
     torch.cuda.synchronize()
     assert torch.equal(y16, aa.half()) and (rec(y16, ylo) - aa).abs().max().item() <= 2.0 ** -21 * aa.abs().max().item()
+
+
+@pytest.mark.parametrize("F,widths,K,silu_in,silu_out", [(16, [320, 320, 640, 1280, 1280, 320], 1280, False, False),
+                                                         (5, [64, 128], 256, True, True), (21, [320] * 22 + [640] * 11, 1280, False, False)])
+def test_linear_smallm_segments_is_the_single_launch_per_site(F, widths, K, silu_in, silu_out):
+    """pnc_linear_smallm_segments (the emb_layers Linear of every ResBlock of a network in one launch): every site's [F, width] block
+    bit-identical to pnc_linear_smallm on that site's weight rows, and equal to the emulation's fp32 product."""
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(F, K, generator=g).cuda()
+    N = sum(widths)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    seg = [0]
+    for wd in widths:
+        seg.append(seg[-1] + wd)
+    out = torch.full((N * F,), float("nan"), device="cuda")
+    for m0 in range(0, F, 16):
+        hip.linear_smallm_segments(a[m0:], K, w, bias, out, min(16, F - m0), m0, F, N, K, seg, silu_in, silu_out)
+    ref_e = torch.empty(N * F)
+    for m0 in range(0, F, 16):
+        emu.linear_smallm_segments(a.cpu()[m0:], K, w.cpu(), bias.cpu(), ref_e, min(16, F - m0), m0, F, N, K, seg, silu_in, silu_out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    for s0, s1 in zip(seg[:-1], seg[1:]):
+        one = torch.empty(F, s1 - s0, device="cuda")
+        for m0 in range(0, F, 16):
+            hip.linear_smallm(a[m0:], K, w[s0:], bias[s0:], one[m0:], s1 - s0, min(16, F - m0), s1 - s0, K, silu_in, silu_out)
+        torch.cuda.synchronize()
+        blk = out[s0 * F:s1 * F].view(F, s1 - s0)
+        assert torch.equal(blk, one)
+        assert (blk.cpu() - ref_e[s0 * F:s1 * F].view(F, s1 - s0)).abs().max().item() < 2e-4
+    # argument checks: a segment table that does not tile N, a start that is not a multiple of 4
+    for bad in ([0, N - 4], [0, 6, N]):
+        with pytest.raises(Exception):
+            hip.linear_smallm_segments(a, K, w, bias, out, min(16, F), 0, F, N, K, bad, silu_in, silu_out)

@@ -714,6 +714,7 @@ def _ppc(npix: int) -> int:
 GN_EPILOGUE_CHUNK = 64      # pixels per record of PncGemmParams.gn_part (the temporal conv's 64-row wave blocks)
 GN_FROM_EPILOGUE = True     # False (bench.py --no-gn-epilogue, A/B): every spatial GroupNorm launches its own statistics kernel
 EMB_BATCH = os.environ.get("PNC_EMB_BATCH", "1") != "0"      # A/B: "0" = one emb_layers launch per ResBlock3D (rounds 1-4)
+TEXTKV_ONE_GEMM = os.environ.get("PNC_TEXTKV_ONE_GEMM", "1") != "0"      # A/B: "0" = text K/V of a network as one GEMM per width
 
 
 def gn_records(rt: Runtime, F: int, N: int) -> Optional[torch.Tensor]:

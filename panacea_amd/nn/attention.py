@@ -440,45 +440,62 @@ class SpatialTemporalTransformer(nn.Module, Packable):
 
 
 class TextKVProjector:
-    """Batches the text K/V projections of every cross-attention site of a network.  They depend only on the
-    (B, 77, D) context, so all sites of one width C share two GEMMs: K_all = ctx W_k^T (row-major, one column block
-    per site) and V_all^T (channel-major).  138 launches of M = 160 rows become 16 per step (the reference instead
-    re-projects them once per PIXEL in the temporal branch: attention.py:1122-1125)."""
+    """Batches the text K/V projections of every cross-attention site of a network.  They depend only on the (B, 77, D) context,
+    so ALL sites share one GEMM (round 5; rounds 2-4: two per width, 16 launches of 20-80 workgroups per step): the weight rows
+    are [W_k of every site | zero rows up to a multiple of 128 | W_v of every site], columns below `n_split` leave row-major (K_all,
+    one column block per site), the others channel-major (V_all^T) — the QKV GEMM's output form.  138 launches of M = 160 rows
+    become 2 per step (the reference instead re-projects them once per PIXEL in the temporal branch: attention.py:1122-1125).
+    Every output element is the same dot product in the same K order as before: bit-identical."""
 
     def __init__(self, root: nn.Module):
-        self.groups = {}
-        for m in root.modules():
-            if isinstance(m, BasicTransformerBlock):
-                a = m.attn2
-                self.groups.setdefault((a.inner_dim, a.context_dim), []).append(a)
+        self.sites = [m.attn2 for m in root.modules() if isinstance(m, BasicTransformerBlock)]
         self._pk = None
+        if not E.TEXTKV_ONE_GEMM:                      # A/B (PNC_TEXTKV_ONE_GEMM=0): one projector per width, as rounds 2-4 grouped
+            by_c = {}
+            for a in self.sites:
+                by_c.setdefault(a.inner_dim, []).append(a)
+            self.parts = [TextKVProjector.__new__(TextKVProjector) for _ in by_c]
+            for p, sites in zip(self.parts, by_c.values()):
+                p.sites, p._pk, p.parts = sites, None, None
+        else:
+            self.parts = None
 
     def pack(self):
-        pk = {}
-        for key, mods in self.groups.items():
-            wk = torch.cat([m.to_k.weight for m in mods], dim=0)
-            wv = torch.cat([m.to_v.weight for m in mods], dim=0)
-            pk[key] = (E.pk_f16(wk), E.pk_f16(wv))
-        return pk
+        dims = {a.context_dim for a in self.sites}
+        if len(dims) != 1:
+            raise ValueError(f"cross-attention sites with different context widths {sorted(dims)}")
+        wk = torch.cat([a.to_k.weight for a in self.sites], dim=0)
+        wv = torch.cat([a.to_v.weight for a in self.sites], dim=0)
+        nt = wk.shape[0]
+        nkp = -(-nt // 128) * 128                      # PncGemmParams.n_split: a multiple of 128
+        w = torch.cat([wk, wk.new_zeros(nkp - nt, wk.shape[1]), wv], dim=0)
+        offs, o = [], 0
+        for a in self.sites:
+            offs.append(o)
+            o += a.inner_dim
+        return E.pk_f16(w), nt, nkp, offs, dims.pop()
 
     def run(self, rt: Runtime):
+        if not self.sites:
+            return
+        if self.parts:
+            for p in self.parts:
+                p.run(rt)
+            return
         if self._pk is None:
             with torch.no_grad():
                 self._pk = self.pack()
+        w, NT, NKp, offs, Dm = self._pk
         rows, D = rt.B * E.TEXT_PAD, rt.ctx16.shape[1]
-        for (C, Dm), mods in self.groups.items():
-            if Dm != D:
-                raise ValueError(f"context width {D} does not match the cross-attention context_dim {Dm}")
-            wk, wv = self._pk[(C, Dm)]
-            NT = C * len(mods)
-            k = rt.empty((rows, NT), torch.float16)
-            vt = rt.empty((rt.B, NT, E.TEXT_PAD), torch.float16)
-            rt.be.gemm(rt.ctx16, wk, M=rows, N=NT, K=D, lda=D, out16=k, ldc16=NT)
-            rt.be.gemm(rt.ctx16, wv, M=rows, N=NT, K=D, lda=D, out16t=vt, ldt=E.TEXT_PAD, t_rows=E.TEXT_PAD,
-                       t_gstride=NT * E.TEXT_PAD, n_split=0)
-            kf, vf = k.view(-1), vt.view(-1)
-            for i, m in enumerate(mods):
-                rt.text_kv[id(m)] = (kf[i * C:], NT, vf[i * C * E.TEXT_PAD:], E.TEXT_PAD, NT * E.TEXT_PAD)
+        if Dm != D:
+            raise ValueError(f"context width {D} does not match the cross-attention context_dim {Dm}")
+        k = rt.empty((rows, NKp), torch.float16)
+        vt = rt.empty((rt.B, NT, E.TEXT_PAD), torch.float16)
+        rt.be.gemm(rt.ctx16, w, M=rows, N=NKp + NT, K=D, lda=D, out16=k, ldc16=NKp, out16t=vt, ldt=E.TEXT_PAD,
+                   t_rows=E.TEXT_PAD, t_gstride=NT * E.TEXT_PAD, n_split=NKp)
+        kf, vf = k.view(-1), vt.view(-1)
+        for a, o in zip(self.sites, offs):
+            rt.text_kv[id(a)] = (kf[o:], NKp, vf[o * E.TEXT_PAD:], E.TEXT_PAD, NT * E.TEXT_PAD)
 
 
 def _is_listconfig(v) -> bool:

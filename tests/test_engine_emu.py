@@ -115,6 +115,28 @@ def test_packed_weights_follow_parameter_updates():
     assert (e1 - e2).abs().max() > 1e-2
 
 
+def test_batched_step_prologue_equals_the_launch_per_site_forms(monkeypatch):
+    """Round 5: the emb_layers Linear of every ResBlock in one launch (EmbProjector) and the text K / V of every site in one GEMM
+    (TextKVProjector) are re-orderings of launches, not of arithmetic: the network's output must not move when either is switched
+    back to the per-site / per-width form (the emulation computes every column the same way in both)."""
+    w, sd, kw = product_network("tiny")
+    inp = step_inputs("tiny", kw)
+    outs = []
+    for emb_batch, one_gemm in ((True, True), (False, True), (True, False), (False, False)):
+        monkeypatch.setattr(E, "EMB_BATCH", emb_batch)
+        monkeypatch.setattr(E, "TEXTKV_ONE_GEMM", one_gemm)
+        E.invalidate_all(w)                                    # drops the cached projectors (built per switch setting)
+        calls = []
+        real = emu.linear_smallm_segments
+        monkeypatch.setattr(emu, "linear_smallm_segments", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        with E.use_backend(emu):
+            outs.append(w(inp["x"], inp["t"], cond(inp)))
+        monkeypatch.setattr(emu, "linear_smallm_segments", real)
+        assert bool(calls) == emb_batch and (not emb_batch or len(calls) == 2)      # one launch per network (UNet, ControlNet)
+    for o in outs[1:]:
+        assert (o - outs[0]).abs().max().item() <= 2e-6 * outs[0].abs().max().item()
+
+
 def test_unsupported_options_fail_loudly():
     kw = configs.get("tiny")
     with pytest.raises(NotImplementedError):

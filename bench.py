@@ -439,6 +439,9 @@ def main():
                     help="seconds after which the secondary (strong-scaling) mode of --parallelism auto is abandoned")
     ap.add_argument("--one-stream", action="store_true", help="do not overlap the ControlNet with the UNet encoder")
     ap.add_argument("--split-samples", action="store_true", help="issue the two CFG halves as independent stream pairs")
+    ap.add_argument("--cu-split", default=None, choices=["even-odd", "nibbles", "halves"],
+                    help="round 6 experiment, with --split-samples: the two CFG halves on complementary halves of the CUs "
+                         "(hipExtStreamCreateWithCUMask)")
     ap.add_argument("--no-fused-step", action="store_true",
                     help="run the step's elementwise tail (c_in, CFG doubling, c_out / CFG combine / Euler) as the reference's torch "
                          "ops instead of the two fused kernels (SURVEY §8 f1); same bits")
@@ -533,6 +536,9 @@ def main():
     net = net.to(dev)
     net.diffusion_model.two_stream = not args.one_stream
     net.diffusion_model.split_samples = bool(args.split_samples)
+    if args.cu_split:
+        from panacea_amd.nn import controlmodel as _cm
+        _cm.CU_SPLIT = args.cu_split
     net.diffusion_model.precision = args.precision
     log(f"[rank {rank}] network built in {time.time() - t0:.0f}s")
 

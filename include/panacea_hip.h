@@ -33,10 +33,11 @@ extern "C" {
 
 /* library / build identification: returns "panacea_hip <version> gfx950" */
 const char* pnc_version(void);
-/* ABI revision of this header (bumped whenever a parameter struct or a prototype changes): 5 (round 5: + pnc_concat_add_stats)
+/* ABI revision of this header (bumped whenever a parameter struct, a prototype or the option list changes): 7
  * (round 4: + pnc_groupnorm_combine, + PNC_OPT_ATTN_DEFER_MAX, PNC_OPT_GEMM_PERSIST is a bit set, - pnc_ff_chain_*;
- *  round 5: + pnc_concat_add_stats, + PNC_OPT_GEMM_STAGGER) */
-#define PNC_ABI_VERSION 6
+ *  round 5 (5, 6): + pnc_concat_add_stats, + PNC_OPT_GEMM_STAGGER, + pnc_linear_smallm_segments;
+ *  round 6 (7): + PNC_OPT_ATTN_SUM_TRIGGER) */
+#define PNC_ABI_VERSION 7
 int pnc_abi_version(void);
 /* hex SHA-256 of the sources + compile flags the library was built from (panacea_amd/build.py computes the same digest over
  * the checkout): a loader compares the two and refuses a library built from other sources instead of calling it with
@@ -80,7 +81,12 @@ enum {
                                      reads (FF1 at levels 1-2: +5-6 %); 0 = never (round 4's loops); 1 = everywhere the schedule exists —
                                      also the plain-A 8-wave two-stage kernels and the stencil-tile conv kernel, where it measured no
                                      faster (tests, A/B tools).  Same K and MFMA order per accumulator: bit-identical results */
-    PNC_OPT_COUNT = 11
+    PNC_OPT_ATTN_SUM_TRIGGER = 11, /* k (default 12; round 6): after a query block's first K/V tile pnc_attn_views_f16 forms the probabilities
+                                     against the running maximum AS IT IS and lets the row sum (needed anyway) tell whether that was safe — a
+                                     lane's probabilities are each <= their sum, so sum < 2^k bounds every P below 2^k (fp16-safe up to 14) —
+                                     and only a tile whose sum reaches 2^k (or is not finite) computes the row maximum and rescales; 0 = the
+                                     row maximum of every tile (round 5).  Same softmax, other roundings of P (as PNC_OPT_ATTN_DEFER_MAX) */
+    PNC_OPT_COUNT = 12
 };
 int pnc_set_option(int option, int value);
 

@@ -10,6 +10,7 @@ oracle is run on the same data and must agree (fp32 vs fp32) before the file is 
     python -m oracle.gen_golden_full --yaml-exact --no-oracle      # BASELINE config 5, sampler step 0: full_cfg5_step0.npz
     python -m oracle.gen_golden_full --t 500 --wsalt 1 --no-oracle # second WEIGHT draw (round 5): full_cfg3_t500_w1.npz
     python -m oracle.gen_golden_full --t 500 --wtail 64 --no-oracle    # heavy-tailed stream (round 5): full_cfg3_t500_tail64.npz
+    ... --full-eps                                                 # round 6: the file also holds the WHOLE eps (key "eps", fp32)
 
 The extra pins skip the (6 minute) oracle leg: oracle vs reference is established by the first file and by the
 small configurations; what the extra files pin is the reference's eps at other noise levels / inputs.
@@ -36,6 +37,8 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=8, help="1 = BASELINE config 2: the YAML network built with num_frames = 1")
     ap.add_argument("--wsalt", type=int, default=0, help="salt of the synthetic WEIGHTS (synth.synth_state_dict)")
     ap.add_argument("--wtail", type=float, default=0.0, help="heavy-tail weight set: gain of the output channels c %% 64 == 5 of the residual-out tensors")
+    ap.add_argument("--full-eps", action="store_true",
+                    help="round 6 (SURVEY 8c full-size pin): store the WHOLE eps (fp32, 3.1 MB) next to the stride-7 sample")
     ap.add_argument("--yaml-exact", action="store_true",
                     help="BASELINE config 5: last-frame concat conditioning + share-noise latent, t = 999 (sampler step 0)")
     args = ap.parse_args()
@@ -82,7 +85,8 @@ if __name__ == "__main__":
         d = (eps - eps_o).abs().max().item()
         print(f"oracle forward {t_or:.1f}s; oracle vs reference max-abs {d:.3e}", flush=True)
         assert d <= 1e-4
-    np.savez_compressed(GOLDEN / f"{stem}{tag}.npz", eps_s7=eps.reshape(-1)[::7].numpy(),
+    extra = {"eps": eps.numpy()} if args.full_eps else {}
+    np.savez_compressed(GOLDEN / f"{stem}{tag}.npz", eps_s7=eps.reshape(-1)[::7].numpy(), **extra,
                         t_index=np.int32(args.t), input_salt=np.int32(args.salt),
                         weight_salt=np.int32(args.wsalt), weight_tail=np.float32(args.wtail),
                         eps_rms=np.float32(eps.pow(2).mean().sqrt().item()),

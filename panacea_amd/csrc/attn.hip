@@ -41,8 +41,9 @@ __device__ __attribute__((aligned(16))) half_t g_attn_zero_chunk[8];   // zero-i
 // the other — the 8-wave workgroup's waves are re-aligned by its barrier every tile (profiles/round2/attn_pmc_l0_intra_r2m.txt:
 // VALU 64 % + MFMA 29 % of the SIMD time, one after the other).
 template <int NW, int QB, bool DMA>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_views_kernel(const PncAttnParams p, const int wv_shift,
-                                                                                          const float defer_thr, const int dma_mode) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2 && DMA) ? 2 : 1) void attn_views_kernel(const PncAttnParams p, const int wv_shift,
+                                                                                          const float defer_thr, const int dma_mode,
+                                                                                          const float sum_lim) {
     constexpr int QT = NW * QB * 32;
     constexpr int ROWS_PER_IT = NW * 8;          // K / V^T rows staged per iteration (8 rows per wave)
     constexpr int ST_IT = 64 / ROWS_PER_IT;      // 2 (4 waves) or 1 (8 waves)
@@ -295,6 +296,30 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_vi
                     for (int r = 0; r < 16; ++r)
                         if (kh * 32 + r >= lim) s[qb][kh][r] = -1e30f;
             }
+            // SUM-TRIGGERED running max (round 6; PNC_OPT_ATTN_SUM_TRIGGER).  The SQ counters of the level-0 launches say the VALU pipe
+            // is the busy one (VALU active ~51 cycles per 32-cycle MFMA, profiles/round6/attn_counter_audit.md), and the row maximum is
+            // 16 v_max3 (half rate: tools/exp/valu_rate.hip) + a cross-lane exchange per query block and tile — 14 % of the softmax's
+            // cycles spent to find out, in every tile after the first, that the running maximum does not move.  So after the first tile
+            // the probabilities are formed OPTIMISTICALLY against the running maximum as it is, and the row SUM — needed anyway — tells
+            // whether that was safe: a lane's 32 probabilities are each <= their sum, so sum < 2^k bounds every P below 2^k (fp16-safe up
+            // to 15; fp16 keeps 11 bits at any magnitude, the accumulators are fp32).  Only when some lane's sum reaches the limit — or
+            // is not a number: the comparison is written so that NaN / inf trigger too — the tile is redone the exact way below
+            // (maximum, rescale, probabilities against the new maximum).  Same softmax; other roundings of P than the per-tile maximum
+            // gives (as PNC_OPT_ATTN_DEFER_MAX already states), so not bit-identical across option values.
+            bool exact = !(sum_lim > 0.0f) || t == 0;
+            float psum = 0.0f;
+            if (!exact) {
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[qb][kh][r], sc, -mrun[qb]));
+                        psum += pv;
+                        pf[qb][kh][r >> 3][r & 7] = (half_t)pv;
+                    }
+                exact = __builtin_amdgcn_ballot_w64(!(psum < sum_lim)) != 0;
+            }
+            if (exact) {
             float tmax = -1e30f;
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
@@ -316,7 +341,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_vi
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[qb][dh][r] *= alpha;
             }
-            float psum = 0.0f;
+            psum = 0.0f;
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -326,6 +351,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2) ? 2 : 1) void attn_vi
                     psum += pv;
                     pf[qb][kh][r >> 3][r & 7] = (half_t)pv;
                 }
+            }
             lrun[qb] += psum;
         }
 
@@ -529,11 +555,13 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     if (kvWv > 0 && (kvWv & (kvWv - 1)) == 0) { wv_shift = 0; while ((1 << wv_shift) < kvWv) ++wv_shift; }
     int dopt = pnc_get_option(PNC_OPT_ATTN_DEFER_MAX);
     const float defer_thr = (float)(dopt < 0 ? 0 : (dopt > 14 ? 14 : dopt));
+    const int sopt = pnc_get_option(PNC_OPT_ATTN_SUM_TRIGGER);
+    const float sum_lim = sopt <= 0 ? 0.0f : ldexpf(1.0f, sopt > 14 ? 14 : sopt);
 #define PNC_ATTN_LAUNCH(NW_, QB_, QTILE_)                                                                         \
     do {                                                                                                          \
         dim3 grid(((Nq + (QTILE_) - 1) / (QTILE_)) * p.views * p.groups * p.heads);                               \
-        if (dma) hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, true>), grid, dim3(64 * NW_), 0, st, p, wv_shift, defer_thr, dma_mode);  \
-        else hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, false>), grid, dim3(64 * NW_), 0, st, p, wv_shift, defer_thr, dma_mode);   \
+        if (dma) hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, true>), grid, dim3(64 * NW_), 0, st, p, wv_shift, defer_thr, dma_mode, sum_lim);  \
+        else hipLaunchKernelGGL((attn_views_kernel<NW_, QB_, false>), grid, dim3(64 * NW_), 0, st, p, wv_shift, defer_thr, dma_mode, sum_lim);   \
     } while (0)
     if (variant == 42) PNC_ATTN_LAUNCH(4, 2, 256);
     else if (variant == 82) PNC_ATTN_LAUNCH(8, 2, 512);

@@ -20,7 +20,7 @@ HEADER = PKG.parent / "include" / "panacea_hip.h"
 
 A_PLAIN, A_CONV3X3, A_CONV1D_T = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 6          # PNC_ABI_VERSION of include/panacea_hip.h this binding was written against
+ABI_VERSION = 7          # PNC_ABI_VERSION of include/panacea_hip.h this binding was written against
 LO_F16, LO_E4M3 = 0, 1   # PNC_LO_*: storage format of the lo plane of a precise operand
 # dtype of a lo-plane tensor <-> format: an fp16 tensor holds fp16(r), a uint8 tensor OCP e4m3 bytes (one per element)
 LO_DTYPE = {LO_F16: torch.float16, LO_E4M3: torch.uint8}
@@ -175,6 +175,7 @@ OPT_GEMM_PERSIST = 7
 OPT_ATTN_DEFER_MAX = 8
 OPT_GEMM_GN_STATS = 9
 OPT_GEMM_STAGGER = 10
+OPT_ATTN_SUM_TRIGGER = 11
 
 
 def build_digest() -> str:
@@ -184,9 +185,37 @@ def build_digest() -> str:
 
 def set_option(option: int, value: int) -> int:
     """pnc_set_option: process-global tuning / test switch of the library; returns the previous value."""
-    if not 0 <= option <= OPT_GEMM_STAGGER:
+    if not 0 <= option <= OPT_ATTN_SUM_TRIGGER:
         raise PncError(f"unknown library option {option}")
     return load().pnc_set_option(option, value)
+
+
+CU_MASK_PATTERNS = {            # complementary halves of the 256 CUs, as 8 x 32-bit words (hipExtStreamCreateWithCUMask)
+    "even-odd": ([0x55555555] * 8, [0xAAAAAAAA] * 8),
+    "nibbles": ([0x0F0F0F0F] * 8, [0xF0F0F0F0] * 8),
+    "halves": ([0xFFFFFFFF] * 4 + [0] * 4, [0] * 4 + [0xFFFFFFFF] * 4),
+}
+
+
+def masked_stream(words) -> "torch.cuda.Stream":
+    """A HIP stream whose kernels run on the CUs of `words` only (hipExtStreamCreateWithCUMask of the HIP runtime this process
+    already uses), wrapped for torch.  Round 6 experiment: two sample chains on complementary halves of
+    the chip.  The stream lives as long as the process."""
+    rt = None
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            rt = C.CDLL(line.split()[-1])
+            break
+    if rt is None:
+        raise PncError("the HIP runtime is not loaded")
+    rt.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    rt.hipExtStreamCreateWithCUMask.restype = C.c_int
+    st = C.c_void_p()
+    arr = (C.c_uint32 * len(words))(*words)
+    rc = rt.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(len(words)), arr)
+    if rc != 0:
+        raise PncError(f"hipExtStreamCreateWithCUMask failed with {rc}")
+    return torch.cuda.ExternalStream(st.value)
 
 
 class Profiler:

@@ -312,10 +312,16 @@ class StepInvariants:
 
 
 _SIDE_STREAMS = {}
+# Round 6 experiment (bench.py --cu-split): name of a hip.CU_MASK_PATTERNS entry.  With split_samples the stream pair of sample b
+# (indices 2b, 2b + 1) is then confined to half b % 2 of the CUs: two sample chains side by side on disjoint halves of the chip
+CU_SPLIT = None
 
 
 def _side_stream(device, idx: int = 0) -> "torch.cuda.Stream":
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), idx)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), idx, CU_SPLIT)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        if CU_SPLIT is not None:
+            _SIDE_STREAMS[key] = E._hip.masked_stream(E._hip.CU_MASK_PATTERNS[CU_SPLIT][(idx // 2) % 2])
+        else:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]

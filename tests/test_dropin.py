@@ -51,7 +51,7 @@ def test_enum_constants_match_the_header_as_gcc_reads_it(tmp_path):
              "PNC_OPT_ATTN_VARIANT": hip.OPT_ATTN_VARIANT, "PNC_OPT_ATTN_DMA": hip.OPT_ATTN_DMA,
              "PNC_OPT_GEMM_FUSE_LN": hip.OPT_GEMM_FUSE_LN, "PNC_OPT_GEMM_GROUP_M": hip.OPT_GEMM_GROUP_M,
              "PNC_OPT_STENCIL_TILES": hip.OPT_STENCIL_TILES, "PNC_OPT_GEMM_PERSIST": hip.OPT_GEMM_PERSIST,
-             "PNC_OPT_ATTN_DEFER_MAX": hip.OPT_ATTN_DEFER_MAX, "PNC_OPT_GEMM_GN_STATS": hip.OPT_GEMM_GN_STATS, "PNC_OPT_GEMM_STAGGER": hip.OPT_GEMM_STAGGER, "PNC_A_PLAIN": hip.A_PLAIN, "PNC_A_CONV3X3": hip.A_CONV3X3,
+             "PNC_OPT_ATTN_DEFER_MAX": hip.OPT_ATTN_DEFER_MAX, "PNC_OPT_GEMM_GN_STATS": hip.OPT_GEMM_GN_STATS, "PNC_OPT_GEMM_STAGGER": hip.OPT_GEMM_STAGGER, "PNC_OPT_ATTN_SUM_TRIGGER": hip.OPT_ATTN_SUM_TRIGGER, "PNC_A_PLAIN": hip.A_PLAIN, "PNC_A_CONV3X3": hip.A_CONV3X3,
              "PNC_A_CONV1D_T": hip.A_CONV1D_T, "PNC_ACT_NONE": hip.ACT_NONE, "PNC_ACT_SILU": hip.ACT_SILU, "PNC_ACT_GELU": hip.ACT_GELU,
              "PNC_LO_F16": hip.LO_F16, "PNC_LO_E4M3": hip.LO_E4M3}
     src = ['#include <stdio.h>', f'#include "{hip.HEADER}"', 'int main(void) {']

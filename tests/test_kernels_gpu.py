@@ -989,6 +989,45 @@ def test_attn_views_deferred_running_max(scale_q):
         check(f"attn_views_defer{thr}_q{scale_q}", oh, oe, 5e-3)
 
 
+@pytest.mark.parametrize("variant", [42, 82, 81, 41])
+@pytest.mark.parametrize("scale_q,spike", [(1.0, 0.0), (4.0, 0.0), (12.0, 0.0), (1.0, 40.0), (1.0, 400.0)])
+def test_attn_views_sum_triggered_running_max(variant, scale_q, spike):
+    """PNC_OPT_ATTN_SUM_TRIGGER (round 6): after the first K/V tile the probabilities are formed against the running maximum as it is,
+    and only a tile whose row sum reaches 2^k (or is not finite) takes the exact path (row maximum, rescale).  Same softmax for every
+    k, 0 = the row maximum of every tile — on near-uniform, sharp and very sharp rows, and with ONE key row spiked in a LATE tile so
+    that its raw score exceeds everything before it by far more than any fp16 / fp32 exponent range allows to defer (the optimistic
+    probabilities overflow: the not-finite sum must trigger the redo).  Every output finite; all k agree with the emulation."""
+    G, H, W, heads = 1, 16, 192, 2
+    C, N = heads * 64, H * W
+    q, k, _, vt = _qkv(G, N, C, 13)
+    q = q * scale_q
+    if spike:
+        # key (y = 9, x = 7) of every view: tile 4 of the 8 tiles of a 512-key view; aligned with query (0, 0)'s direction
+        k4 = k.view(G, H, W, C)
+        for v in range(6):
+            k4[0, 9, v * 32 + 7] = q.view(G, H, W, C)[0, 0, v * 32] * spike
+    kw = dict(groups=G, heads=heads, H=H, W=W, views=6, kvH=H, kvW=W, kv_views=6, kv_rows_per_group=N,
+              q_per_kv=1, kv_valid=H * (W // 6), segs=CROSS, scale=0.125)
+    oe = torch.zeros(G * N, C, device=DEV, dtype=torch.float16)
+    emu.attn_views(q, C, k, C, vt, N, C * N, oe, C, **kw)
+    pv = hip.set_option(hip.OPT_ATTN_VARIANT, variant)
+    outs = []
+    try:
+        for trig in (0, 4, 12, 14):
+            prev = hip.set_option(hip.OPT_ATTN_SUM_TRIGGER, trig)
+            try:
+                oh = torch.zeros_like(oe)
+                hip.attn_views(q, C, k, C, vt, N, C * N, oh, C, **kw)
+                torch.cuda.synchronize()
+            finally:
+                hip.set_option(hip.OPT_ATTN_SUM_TRIGGER, prev)
+            assert torch.isfinite(oh.float()).all(), (trig, "non-finite attention output")
+            check(f"attn_views_sumtrig{trig}_v{variant}_q{scale_q}_s{spike}", oh, oe, 5e-3)
+            outs.append(oh)
+    finally:
+        hip.set_option(hip.OPT_ATTN_VARIANT, pv)
+
+
 def test_groupnorm_combine_kernel():
     """pnc_groupnorm_combine (round 4): Chan combination of the all-gathered chunk records of a view group's bands, against the
     float64 formula; the apply kernel fed with the combined records normalises with the statistics of the concatenation."""

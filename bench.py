@@ -85,7 +85,29 @@ def cpu_baseline(kw, sd, shape, mode="auto", budget_s=900.0):
     from panacea_amd import synth
     B, T, h, w = shape
     cfg = _oracle_cfg(kw)
-    out = {"unit": "denoising steps/s", "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(), "kind": "port"}
+    # Round 6: the baseline is stated at the host's BEST thread count, not its largest — the reference itself runs
+    # one whole step in 326-334 s on 8 vCPUs of the build container, torch's default of one thread per logical CPU of a 128-thread
+    # box took 434 s.  Sweep on a bounded piece of the same workload (1 CFG half x T frames on an 8x96 latent: every layer, 1/16 of
+    # the pixels), then run the sample / the whole step at the winner; every candidate's time is reported.
+    sweep = {}
+    host = os.cpu_count() or 8
+    default_threads = torch.get_num_threads()
+    if True:
+        inp = synth.synth_inputs(1, T, max(8, h // 4), max(96, w // 4), context_dim=kw["context_dim"])
+        c = {k: inp[k] for k in ("concat", "crossattn", "cond_feat")}
+        for nt in sorted({t for t in (8, 16, 32, 64, 128, default_threads) if t <= host}, reverse=True):
+            torch.set_num_threads(nt)
+            t0 = time.time()
+            po.wrapper_forward(sd, cfg, inp["x"], inp["t"], c)
+            sweep[nt] = round(time.time() - t0, 2)
+            log(f"cpu_baseline thread sweep: {nt} threads {sweep[nt]:.1f} s")
+            if sweep[nt] > 40.0 and len(sweep) >= 2:
+                break                                     # a slow host: keep the leg bounded
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+    out = {"unit": "denoising steps/s", "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(), "kind": "port",
+           "threads_sweep": {"seconds_by_threads": sweep, "default_threads": default_threads,
+                             "workload": f"oracle forward, 1 CFG half x {T} frames x {max(8, h // 4)}x{max(96, w // 4)} latent"}}
     sample_dt = None
     if mode in ("auto", "sample"):
         inp = synth.synth_inputs(1, T, h // 2, w // 2, context_dim=kw["context_dim"])
@@ -271,7 +293,8 @@ def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, 
     import torch.distributed as dist
     T, (h, w) = kw["num_frames"], hw
     layout = parallel.layout_for(world, rank, parallelism, num_frames=T)
-    groups = parallel.Groups(layout)
+    side = bool(getattr(args, "sharded_side_stream", False)) and not args.one_stream
+    groups = parallel.Groups(layout, side=side)
     # every rank of a sample starts from the SAMPLE's inputs (salt = sample index; the synthetic generator is deterministic):
     # `g` was drawn for this rank's sample of the headline layout, which is another sample for most ranks
     if layout.sample != g_salt:
@@ -283,7 +306,7 @@ def run_sharded_mode(args, parallelism, net, kw, hw, dev, sync, rank, world, g, 
     smp = sampling.EulerEDMSampler(args.num_sampling_steps, guider=guider, device=dev)
     smp.fuse = not args.no_fused_step
     shard, vshard = groups.frame_shard(), groups.view_shard()
-    side = not args.one_stream                          # the ControlNet on its side stream, over process groups of its own
+    # side (opt-in, --sharded-side-stream): the ControlNet on its side stream, over process groups of its own
     shard2, vshard2 = (groups.frame_shard(side=True), groups.view_shard(side=True)) if side else (None, None)
     parallel.apply_frame_shard(net, shard, shard2)
     parallel.apply_view_shard(net, vshard, vshard2)
@@ -438,6 +461,10 @@ def main():
     ap.add_argument("--strong-timeout", type=float, default=240.0,
                     help="seconds after which the secondary (strong-scaling) mode of --parallelism auto is abandoned")
     ap.add_argument("--one-stream", action="store_true", help="do not overlap the ControlNet with the UNet encoder")
+    ap.add_argument("--sharded-side-stream", action="store_true",
+                    help="sharded layouts (N > 1): run the ControlNet on its side stream over a second set of process groups (round 5's "
+                         "default; opt-in since round 6 — two RCCL communicators driven from two streams have not been validated on "
+                         "a multi-GPU node: ADVICE r5).  Default: both networks on one stream in the sharded layouts")
     ap.add_argument("--split-samples", action="store_true", help="issue the two CFG halves as independent stream pairs")
     ap.add_argument("--cu-split", default=None, choices=["even-odd", "nibbles", "halves"],
                     help="round 6 experiment, with --split-samples: the two CFG halves on complementary halves of the CUs "
@@ -523,7 +550,7 @@ def main():
         hip.set_option(getattr(hip, "OPT_" + name.upper()), int(val))
     primary = "replica" if args.parallelism == "auto" else args.parallelism
     layout = parallel.layout_for(world, rank, primary, num_frames=args.frames)
-    groups = parallel.Groups(layout) if (layout.per_sample > 1) else None
+    groups = parallel.Groups(layout, side=bool(args.sharded_side_stream) and not args.one_stream) if (layout.per_sample > 1) else None
     kw = configs.with_frames(configs.get(args.config), args.frames) if (args.config == "full" or args.frames != 8) \
         else configs.get(args.config)
     B, T, h, w = configs.SHAPES[args.config]
@@ -572,7 +599,7 @@ def main():
         x0 = sampling.share_noise_init(x0, cond["concat"], 0.07)
     shard2 = vshard2 = None                               # the ControlNet's twins over process groups of its own (side stream)
     if shard is not None or vshard is not None:
-        if not args.one_stream:
+        if args.sharded_side_stream and not args.one_stream:
             shard2, vshard2 = groups.frame_shard(side=True), groups.view_shard(side=True)
         parallel.apply_frame_shard(net, shard, shard2)
         parallel.apply_view_shard(net, vshard, vshard2)
@@ -624,15 +651,23 @@ def main():
                 gi = synth.synth_inputs(2, T, h, w, context_dim=kw["context_dim"], t_index=t_index, salt=salt)
             gi = {k: v.to(dev) for k, v in gi.items()}
             eps = net(gi["x"], gi["t"], {k: gi[k] for k in ("concat", "crossattn", "cond_feat")})
-            d = (eps.reshape(-1)[::7].float().cpu() - torch.from_numpy(gold["eps_s7"])).abs()
+            # round 6: over ALL elements where the pin holds the whole eps (SURVEY 8c full-size pin), else over its stride-7 sample
+            whole = "eps" in gold.files
+            d = (eps.float().cpu() - torch.from_numpy(gold["eps"])).abs() if whole \
+                else (eps.reshape(-1)[::7].float().cpu() - torch.from_numpy(gold["eps_s7"])).abs()
             pins.append({"golden": fname, "t_index": t_index, "input_salt": salt, "eps_max_abs_err": d.max().item(),
-                         "eps_mean_abs_err": d.mean().item(), "eps_ref_rms": float(gold["eps_rms"])})
+                         "eps_mean_abs_err": d.mean().item(), "eps_ref_rms": float(gold["eps_rms"]),
+                         "elements": "all" if whole else "stride-7 sample",
+                         # range monitor: e4m3 lo-plane quads that saturated in THIS evaluation (0 = inside the contract's range)
+                         "e4m3_lo_clamped": getattr(net.diffusion_model, "lo_clamped", None)})
             del gi, eps
         net.diffusion_model.precision = args.precision
         worst = max(pins, key=lambda q: q["eps_max_abs_err"])
         return {"eps_max_abs_err": worst["eps_max_abs_err"], "eps_mean_abs_err": max(q["eps_mean_abs_err"] for q in pins),
                 "eps_ref_rms": worst["eps_ref_rms"], "tolerance": 1e-3, "within_tolerance": bool(worst["eps_max_abs_err"] < 1e-3),
                 "precision": prec, "pins": pins,
+                "range_monitor": {"e4m3_lo_clamped_quads": max((q["e4m3_lo_clamped"] or 0) for q in pins),
+                                  "note": "pnc_range_monitor_collect: 0 = no split operand left |v| < 512, the range the contract is written for"},
                 "against": "reference fp32 CPU forward (tests/golden/" + ", ".join(q["golden"] for q in pins) + "), worst of the pins; "
                            "the second weight draw and the heavy-tail weight set (full_cfg3_t500_w1 / _tail64) are gated in tests/test_model_gpu.py"}
 
@@ -697,6 +732,7 @@ def main():
         # HBM-side bytes per step come from separate rocprofv3 --pmc passes of this same command (they cannot be collected
         # inside a timed run).  The record names the build it was measured on: a stale record reports null, not a number.
         traffic, tnote = None, "no PMC record for this build (tools/pmc_traffic.py writes profiles/round<N>/pmc_traffic.json)"
+        mfma_busy = {"value": None, "note": "no SQ_VALU_MFMA_BUSY_CYCLES record for this build"}
         cands = sorted((ROOT / "profiles").glob("round*/pmc_traffic.json"), key=lambda q: int(q.parent.name[5:]))
         pmc = cands[-1] if cands else ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists() and T == 8:
@@ -712,8 +748,17 @@ def main():
                             if "setup_GB_whole_run" in ent else ""))
             elif ent:
                 tnote = f"PMC record is for build {ent.get('build_stamp', '?')[:12]}, this is {cur[:12]}: not reported"
+            # the matrix-pipe occupancy of the same command (SQ_VALU_MFMA_BUSY_CYCLES pass): reported only for THIS build (round 6)
+            ment = rec.get("mfma", {}).get(args.precision)
+            if ment and ment.get("build_stamp") == cur:
+                mfma_busy = {"mfma_busy_cycles_per_step": ment["mfma_busy_cycles_per_step"],
+                             "utilisation_at_2p1GHz": ment.get("utilisation_at_2p1GHz"), "build": cur[:12]}
+            else:
+                mfma_busy = {"value": None, "note": "no SQ_VALU_MFMA_BUSY_CYCLES record for this build"
+                             if not ment else f"record is for build {str(ment.get('build_stamp'))[:12]}, this is {cur[:12]}: not reported"}
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": None if ach is None else ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": tnote,
+                           "mfma_busy": mfma_busy,
                            "basis": f"{ALGO_TFLOP_PER_STEP:.2f} algorithmic TFLOP per step (SURVEY.md §8d less the duplicate half of the hint stem; a precise operand's second pass is "
                                     "not counted as useful work) / measured step time, per GPU"}
         crec = clocks.record() if clocks is not None else None

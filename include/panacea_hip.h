@@ -379,6 +379,15 @@ int pnc_add_f32(const float* x, const float* a, int64_t n, float* y32, void* y16
 /* fp32 -> fp16 (+ lo plane in lo_fmt) */
 int pnc_cast_f16(const float* x, int64_t n, void* y16, void* y16_lo, int lo_fmt, void* stream);
 
+/* Range monitor (round 6; ABI 7).  The eps contract of the `precise` operand policy is written for a residual stream inside the e4m3
+ * lo plane's range (|v| < 512: beyond it the lo plane of a split operand saturates at +-448 and the operand falls back to fp16's 11
+ * bits — UNetModel3D.eps_contract; the reference has no counterpart: its fp32 CPU path has no such range and its
+ * autocast fp16 path overflows at 65504 without notice, sgm/modules/diffusionmodules/wrappers.py:37-70).  Every kernel that packs an
+ * e4m3 lo plane counts the packed quads that clamped; this call ADDS the counts since the previous call to *out (a device word the
+ * caller zeroes) on `stream` and resets them — a handful of one-thread launches, once per network evaluation.  0 = the evaluation
+ * stayed inside the range its contract is written for. */
+int pnc_range_monitor_collect(unsigned int* out, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * 5. First-stage decoder: row softmax of a materialised score
  *    matrix, p[m][:] = softmax(scale * s[m][:]) (fp32 in, fp32 statistics, fp16

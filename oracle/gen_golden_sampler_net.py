@@ -32,7 +32,7 @@ from panacea_amd import configs, synth                         # noqa: E402
 
 P = "sgm.modules.diffusionmodules."
 STEPS, CFG_SCALE = 3, 5.0
-TOL = 2.5e-3        # |x_dropin - x_reference| per step, relative to max|x|: the emulated fp16 operand path over 3 network evaluations
+TOL = 1e-3          # |x_dropin - x_reference| per step, relative to max|x| (measured 3.4e-4: the emulated fp16 operand path over 3 network evaluations)
 
 
 def reference_stack(ns):

@@ -58,8 +58,23 @@ __device__ __forceinline__ half4v lo_plane4(const float (&v)[4], half4v hi) {
     return l;
 }
 
+// RANGE MONITOR (round 6; include/panacea_hip.h pnc_range_monitor_collect).  The numeric contract of a split operand holds while its
+// e4m3 lo plane does not saturate: lo = (v - fp16(v)) * 2^11 stays inside +-448 for |v| < 512 and clamps from there on (fp16's ulp
+// reaches 0.5).  Every e4m3 lo plane of the library is packed by pack4_e4m3() below, so ONE counter per translation unit, bumped
+// when a packed quad clamps (a compare on values the pack already holds; the atomic is never reached inside the range), states at
+// run time whether an evaluation left the range its contract is written for.
+static __device__ __attribute__((unused)) unsigned int pnc_tu_lo_clamped;
+static __global__ __attribute__((unused)) void pnc_tu_collect_kernel(unsigned int* out) {
+    const unsigned v = atomicExch(&pnc_tu_lo_clamped, 0u);
+    if (v) atomicAdd(out, v);
+}
+// one host-side accessor per translation unit that packs lo planes; misc.hip's pnc_range_monitor_collect() calls them all
+#define PNC_DEFINE_TU_COLLECT(name) \
+    void pnc_tu_collect_##name(unsigned int* out, hipStream_t st) { hipLaunchKernelGGL(pnc_tu_collect_kernel, dim3(1), dim3(1), 0, st, out); }
+
 // The same lo plane as OCP fp8 e4m3 (PNC_LO_E4M3): |r| <= |v|, clamped to the format's +-448; four consecutive channels -> one dword.
 __device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+    if (__builtin_expect(fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))) > 448.0f, 0)) atomicAdd(&pnc_tu_lo_clamped, 1u);
     a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
     c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
     int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);

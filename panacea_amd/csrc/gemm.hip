@@ -263,3 +263,5 @@ extern "C" int pnc_gemm_f16(const PncGemmParams* pp, void* stream) {
         rc2 = pnc_layernorm(p.out32, p.ldc32, p.M, p.N, p.ln_gamma, p.ln_beta, p.ln_eps, p.ln_out16, p.ldln, nullptr, stream);
     return rc2;
 }
+
+PNC_DEFINE_TU_COLLECT(gemm)

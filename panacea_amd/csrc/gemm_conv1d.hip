@@ -43,3 +43,5 @@ int dispatch_conv1d(const PncGemmParams& p, unsigned epi, hipStream_t st) {
 }
 
 }  // namespace pnc_gemm
+
+PNC_DEFINE_TU_COLLECT(gemm_conv1d)

@@ -20,3 +20,5 @@ int dispatch_conv3x3(const PncGemmParams& p, unsigned epi, hipStream_t st) {
 }
 
 }  // namespace pnc_gemm
+
+PNC_DEFINE_TU_COLLECT(gemm_conv3x3)

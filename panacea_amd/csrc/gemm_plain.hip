@@ -58,3 +58,5 @@ int dispatch_plain(const PncGemmParams& p, unsigned epi, hipStream_t st, bool* l
 }
 
 }  // namespace pnc_gemm
+
+PNC_DEFINE_TU_COLLECT(gemm_plain)

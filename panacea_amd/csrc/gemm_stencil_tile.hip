@@ -404,3 +404,5 @@ int dispatch_conv3x3_tiles(const PncGemmParams& p, unsigned epi, int geometry, h
 }
 
 }  // namespace pnc_gemm
+
+PNC_DEFINE_TU_COLLECT(gemm_stencil_tile)

@@ -441,3 +441,24 @@ extern "C" int pnc_softmax_rows_f16(const float* s, int64_t lds, int M, int N, f
 extern "C" int pnc_cast_f16(const float* x, int64_t n, void* y16, void* y16_lo, int lo_fmt, void* stream) {
     return pnc_add_f32(x, nullptr, n, nullptr, y16, y16_lo, lo_fmt, stream);
 }
+
+PNC_DEFINE_TU_COLLECT(misc)
+void pnc_tu_collect_gemm(unsigned int*, hipStream_t);
+void pnc_tu_collect_gemm_plain(unsigned int*, hipStream_t);
+void pnc_tu_collect_gemm_conv3x3(unsigned int*, hipStream_t);
+void pnc_tu_collect_gemm_conv1d(unsigned int*, hipStream_t);
+void pnc_tu_collect_gemm_stencil_tile(unsigned int*, hipStream_t);
+void pnc_tu_collect_norm(unsigned int*, hipStream_t);
+
+extern "C" int pnc_range_monitor_collect(unsigned int* out, void* stream) {
+    if (!out) return PNC_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    pnc_tu_collect_gemm(out, st);
+    pnc_tu_collect_gemm_plain(out, st);
+    pnc_tu_collect_gemm_conv3x3(out, st);
+    pnc_tu_collect_gemm_conv1d(out, st);
+    pnc_tu_collect_gemm_stencil_tile(out, st);
+    pnc_tu_collect_norm(out, st);
+    pnc_tu_collect_misc(out, st);
+    return pnc_launch_status();
+}

@@ -624,3 +624,5 @@ extern "C" int pnc_layernorm(const float* x, int ldx, int M, int C,
 #undef PNC_LN
     return pnc_launch_status();
 }
+
+PNC_DEFINE_TU_COLLECT(norm)

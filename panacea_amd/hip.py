@@ -115,6 +115,7 @@ _SIGNATURES = {
     "pnc_concat_add_stats": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "pnc_add_f32": (_I, [_P, _P, _L, _P, _P, _P, _I, _P]),
     "pnc_cast_f16": (_I, [_P, _L, _P, _P, _I, _P]),
+    "pnc_range_monitor_collect": (_I, [_P, _P]),
 }
 
 _lib = None
@@ -485,6 +486,12 @@ def concat_add(a32, C1, s32, c32, C2, M, out32, out16, out16_lo=None, gn_part=No
 def add_f32(x32, a32, n, y32, y16, y16_lo=None):
     _check(_timed("elementwise", 0.0, 12.0 * n, load().pnc_add_f32, _ptr(x32), _ptr(a32), n, _ptr(y32), _ptr(y16),
                   _ptr(y16_lo), lo_fmt(y16_lo), _stream()), "pnc_add_f32")
+
+
+def range_monitor_collect(out_i32: torch.Tensor):
+    """adds the number of e4m3 lo-plane quads that CLAMPED since the previous call to out_i32[0] (a device int32 word) and resets the
+    library's counters (include/panacea_hip.h: pnc_range_monitor_collect)"""
+    _check(load().pnc_range_monitor_collect(_ptr(out_i32, torch.int32, "out"), _stream()), "pnc_range_monitor_collect")
 
 
 def cast_f16(x32, n, y16, y16_lo=None):

@@ -482,9 +482,10 @@ class TextKVProjector:
             for p in self.parts:
                 p.run(rt)
             return
-        if self._pk is None:
+        sig = tuple((id(p), p._version, p.device) for a in self.sites for p in (a.to_k.weight, a.to_v.weight))      # (see EmbProjector.run)
+        if self._pk is None or getattr(self, "_sig", None) != sig:
             with torch.no_grad():
-                self._pk = self.pack()
+                self._pk, self._sig = self.pack(), sig
         w, NT, NKp, offs, Dm = self._pk
         rows, D = rt.B * E.TEXT_PAD, rt.ctx16.shape[1]
         if Dm != D:

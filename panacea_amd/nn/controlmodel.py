@@ -256,6 +256,9 @@ class ControlledUNetModel3D(UNetModel3D):
             # own: parallel.Groups(side=True), apply_*_shard(net, shard, side_shard)) the ControlNet's collectives have one order per
             # communicator whatever the interleaving, and it runs on its side stream as on one GPU (round 5); sharing the UNet's
             # shard objects it stays on the main stream (one stream keeps the order of ONE communicator identical on all ranks)
+            if (rt.shard is not None and cn.frame_shard is None) or (rt.vshard is not None and cn.view_shard is None):
+                raise ValueError("the UNet is frame- / view-sharded but its ControlNet is not: it would silently evaluate this rank's "
+                                 "slice as if it were the whole clip (set both with parallel.apply_frame_shard / apply_view_shard)")
             own_groups = (rt.shard is None or cn.frame_shard is not rt.shard) and (rt.vshard is None or cn.view_shard is not rt.vshard)
             rt_cn = rt
             if own_groups and (rt.shard is not None or rt.vshard is not None):
@@ -288,6 +291,7 @@ class ControlledUNetModel3D(UNetModel3D):
                     for j, c in enumerate(control):
                         trace[f"control.{j}"] = c.to_nchw()
                 out = self._run_unet(rt, x16, self._time_embedding(rt, timesteps), control, tokens=fused is not None)
+            self._range_monitor_collect(rt)          # (both networks' kernels are ordered before this point of the current stream)
         return out if fused is not None else out.to(x.dtype)
 
 

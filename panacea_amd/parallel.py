@@ -170,8 +170,11 @@ class Groups:
     """The process groups of this rank.  Group creation is collective: EVERY rank constructs this with the same layout
     (all groups are created by all ranks, in the same order)."""
 
-    def __init__(self, layout: RankLayout, side: bool = True):
-        """`side`: create every frame / view group TWICE.  The second set belongs to the ControlNet (`frame_shard(side=True)`,
+    def __init__(self, layout: RankLayout, side: bool = False):
+        """`side` (opt-in since round 6: ADVICE r5 — two communicators driven from two streams are only safe while every rank issues
+        in the same host order and both collectives' kernels can co-reside, and no multi-GPU RCCL node has validated that yet; the
+        default keeps both networks on ONE stream over ONE set of communicators in the sharded layouts, as rounds 2-4 did, and
+        creates half the communicators): create every frame / view group TWICE.  The second set belongs to the ControlNet (`frame_shard(side=True)`,
         `view_shard(side=True)`, `apply_*_shard(net, shard, side_shard)`): with communicators of its own the ControlNet's collectives
         keep ONE order per communicator whatever the interleaving with the UNet's, so the two networks may run on two HIP streams in
         the sharded layouts as they do on one GPU (round 5; rounds 2-4 put both on one stream there)."""

@@ -38,8 +38,20 @@ def _lo(v: torch.Tensor, hi: torch.Tensor, like: torch.Tensor = None) -> torch.T
     is a uint8 tensor (PNC_LO_E4M3) — the OCP e4m3 byte of the same residual clamped to +-448"""
     r = (v.float() - hi.float()) * LO_SCALE
     if like is not None and like.dtype == torch.uint8:
+        global _LO_CLAMPED
+        _LO_CLAMPED += int((r.abs() > 448.0).reshape(-1, 4).any(dim=1).sum()) if r.numel() % 4 == 0 else int((r.abs() > 448.0).sum())
         return r.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
     return r.half()
+
+
+_LO_CLAMPED = 0      # e4m3 lo-plane quads that clamped since the last range_monitor_collect (the kernels' per-quad count)
+
+
+def range_monitor_collect(out_i32: torch.Tensor):
+    """pnc_range_monitor_collect: adds the clamped-quad count since the previous call to out_i32[0] and resets it"""
+    global _LO_CLAMPED
+    out_i32[0] += _LO_CLAMPED
+    _LO_CLAMPED = 0
 
 
 def _lo_value(lo: torch.Tensor) -> torch.Tensor:

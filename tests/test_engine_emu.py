@@ -10,8 +10,8 @@ import pytest
 import torch
 
 import emu
-from helpers import cond, err_stats, golden, manifest, product_network, step_inputs
-from panacea_amd import build_network, configs, engine as E
+from helpers import cond, err_stats, golden, manifest, oracle_cfg, product_network, step_inputs
+from panacea_amd import build_network, configs, engine as E, synth
 
 # |eps| max ~2.7, rms 0.59.  (network, operand precision) -> (max-abs, mean-abs); the default "precise" policy meets the
 # 1e-3 of BASELINE.json's north_star.  plain1 runs T=1 at 64 channels: its temporal GroupNorm normalises C/32 x T = 2
@@ -113,6 +113,30 @@ def test_packed_weights_follow_parameter_updates():
         w.diffusion_model.load_state_dict(sd2)                # post-hook drops the fp16 packs
         e2 = w(inp["x"], inp["t"], cond(inp))
     assert (e1 - e2).abs().max() > 1e-2
+
+
+def test_network_level_projection_caches_follow_submodule_updates():
+    """EmbProjector / TextKVProjector batch the `emb_layers` Linear of every ResBlock3D and the text K / V projections of
+    every cross-attention site in one launch per network, from a packed copy held by the NETWORK.  Loading or editing ONE submodule
+    (which only invalidates that submodule's own packed weights) must reach those copies too: the result equals a freshly built
+    network with the same parameters."""
+    from panacea_amd.nn.openaimodel import ResBlock3D
+    from panacea_amd.nn.attention import BasicTransformerBlock
+    w, sd, kw = product_network("tiny")
+    inp = step_inputs("tiny", kw)
+    m = w.diffusion_model
+    with E.use_backend(emu), torch.no_grad():
+        w(inp["x"], inp["t"], cond(inp))                      # builds both network-level caches
+        blk = next(b for b in m.modules() if isinstance(b, ResBlock3D))
+        blk.load_state_dict({k: v * 1.5 for k, v in blk.state_dict().items()})        # one block only
+        att = next(b for b in m.modules() if isinstance(b, BasicTransformerBlock)).attn2
+        att.to_k.weight.mul_(0.5)                              # in-place edit of one site's parameter
+        E.invalidate_all(att)
+        e_cached = w(inp["x"], inp["t"], cond(inp))
+        fresh, _, _ = product_network("tiny")
+        fresh.diffusion_model.load_state_dict(m.state_dict(), strict=True)
+        e_fresh = fresh(inp["x"], inp["t"], cond(inp))
+    assert torch.equal(e_cached, e_fresh)
 
 
 def test_batched_step_prologue_equals_the_launch_per_site_forms(monkeypatch):
@@ -239,3 +263,35 @@ def test_view_and_frame_shard_loop_back_on_one_process():
         assert d.max().item() <= 2e-3 and d.mean().item() <= 2.5e-4, (d.max().item(), d.mean().item())
     with pytest.raises(ValueError):
         E.ViewShard(2, 0, None)
+
+
+def test_range_monitor_detects_saturated_lo_planes():
+    """Round 6: the eps contract of `precise` is written for split operands inside the e4m3 lo plane's range
+    (|v| < 512).  Every e4m3 pack counts the quads it clamps (pnc_range_monitor_collect; the emulation counts the same event): an
+    evaluation on the ordinary synthetic weights reports 0, the heavy-tail weight set (stream at ~1.6e3) reports > 0 and warns ONCE;
+    `on_range_exceeded = "raise"` refuses."""
+    import warnings
+    from oracle import panacea_oracle as po
+    w, sd, kw = product_network("tiny")
+    inp = step_inputs("tiny", kw)
+    m = w.diffusion_model
+    assert m.lo_clamped is None
+    with E.use_backend(emu), torch.no_grad():
+        w(inp["x"], inp["t"], cond(inp))
+    assert m.lo_clamped == 0 and m.lo_clamped_total == 0
+    sd_t = synth.synth_state_dict(manifest("tiny"), tail=64.0)
+    m.load_state_dict(sd_t, strict=True)
+    ref = po.wrapper_forward(sd_t, oracle_cfg(kw), inp["x"], inp["t"], cond(inp))
+    with E.use_backend(emu), torch.no_grad(), warnings.catch_warnings(record=True) as ws:
+        warnings.simplefilter("always")
+        e1 = w(inp["x"], inp["t"], cond(inp))
+        n1 = m.lo_clamped
+        w(inp["x"], inp["t"], cond(inp))
+    assert n1 > 0 and m.lo_clamped == n1 and m.lo_clamped_total == 2 * n1
+    assert sum("lo-plane quads saturated" in str(x.message) for x in ws) == 1            # once per network
+    m.on_range_exceeded = "raise"
+    with E.use_backend(emu), torch.no_grad(), pytest.raises(RuntimeError, match="saturated"):
+        w(inp["x"], inp["t"], cond(inp))
+    m.on_range_exceeded = "warn"
+    d1 = (e1 - ref).abs().max().item()
+    assert d1 > 1e-3, d1             # ... and the detected evaluation is indeed outside the contract (measured 1.3e-2)

@@ -6,7 +6,9 @@ TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots"), calibrated on the LayerNo
 
 Reads the counter_collection CSVs under the two rocprofv3 output directories, prints per-kernel tables and merges a record
     records[precision] = {build_stamp, fetch/write factors, traffic_GB_calibrated, ...}
-into profiles/round5/pmc_traffic.json, which bench.py reports as roofline.traffic ONLY while the build stamp matches.
+into profiles/round6/pmc_traffic.json, which bench.py reports as roofline.traffic ONLY while the build stamp matches.
+`--mfma` adds the SQ_VALU_MFMA_BUSY_CYCLES record of a third pass — stamped with the build digest too (round 6: round 5's record
+was carried over from another build; bench.py now refuses an `mfma` record whose stamp differs, as it does for `traffic`).
 """
 import collections
 import csv
@@ -17,6 +19,26 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+OUT = ROOT / "profiles" / "round6" / "pmc_traffic.json"
+
+
+def library_kernel_names():
+    """the __global__ functions of panacea_amd/csrc: what "the library's launches" means (round 5 filtered by namespace spelling,
+    which also matched torch's at::native::(anonymous namespace) kernels — ADVICE r5)"""
+    import re
+    names = set()
+    for f in list((ROOT / "panacea_amd" / "csrc").glob("*.hip")) + list((ROOT / "panacea_amd" / "csrc").glob("*.h")):
+        names.update(re.findall(r"__global__.{0,160}?\bvoid\s+(\w+)\s*\(", f.read_text(), flags=re.S))
+    return names
+
+
+_LIB_KERNELS = library_kernel_names()
+
+
+def is_library_kernel(name: str) -> bool:
+    if name.startswith("at::") or "at::native" in name:
+        return False
+    return any(k in name for k in _LIB_KERNELS)
 # Calibration kernel: LayerNorm moves exactly 6 B per element (4 B fp32 read + 2 B fp16 write).  The elements of each dispatch
 # follow from its grid: layernorm_kernel<J> runs 16 rows per 256-thread block, J = ceil(C / 256) names the width class.
 LN_WIDTH = {2: 320, 3: 640, 5: 1280}
@@ -52,7 +74,8 @@ def mfma_record(mdir, evals, step_ms):
     busy = per_kernel(mdir, "SQ_VALU_MFMA_BUSY_CYCLES")
     per_eval = sum(busy.values()) / evals
     top = sorted(busy.items(), key=lambda kv: -kv[1])[:12]
-    return {"mfma_busy_cycles_per_step": per_eval,
+    from panacea_amd import build as _build
+    return {"build_stamp": _build.library_digest(), "mfma_busy_cycles_per_step": per_eval,
             "note": "SQ_VALU_MFMA_BUSY_CYCLES: cycles a SIMD's matrix pipe is occupied, summed over the 1024 SIMDs.  96.21 algorithmic "
                     "TFLOP at 1024 flop/cycle/SIMD (fp16 32x32x16) = 9.40e10 cycles; the e4m3 lo passes of the precise policy run at "
                     "2048 flop/cycle/SIMD",
@@ -63,7 +86,8 @@ def mfma_record(mdir, evals, step_ms):
 def main():
     if sys.argv[1] == "--mfma":
         mdir, evals, prec, step_ms = sys.argv[2], int(sys.argv[3]), sys.argv[4], float(sys.argv[5])
-        out = ROOT / "profiles" / "round5" / "pmc_traffic.json"
+        out = OUT
+        out.parent.mkdir(parents=True, exist_ok=True)
         doc = json.loads(out.read_text()) if out.exists() else {"records": {}}
         doc.setdefault("mfma", {})[prec] = mfma_record(mdir, evals, step_ms)
         out.write_text(json.dumps(doc, indent=1))
@@ -78,8 +102,7 @@ def main():
     # Per STEP means the step's kernels: every launch of a step is one of the library's (torch kernels inside a step: 0.1 ms,
     # profiles/round5/per_step_torch_kernels_r5v.txt).  The torch / runtime kernels of the run are its ONE-TIME setup — synthetic
     # weights cast and packed into fp16 + e4m3 planes, 241 tensors — and were divided over the run's steps until round 5.
-    def step_kernel(name):
-        return "pnc_gemm" in name or "_GLOBAL__N" in name or "(anonymous namespace)" in name
+    step_kernel = is_library_kernel
     tf_all, tw_all = sum(fetch.values()) * 1024 / evals, sum(write.values()) * 1024 / evals
     tf = sum(v for k, v in fetch.items() if step_kernel(k)) * 1024 / evals
     tw = sum(v for k, v in write.items() if step_kernel(k)) * 1024 / evals
@@ -94,7 +117,7 @@ def main():
            "traffic_GB_calibrated_rounds_2_to_4_definition": round((tf_all * ff + tw_all * wf) / 1e9, 1),
            "calibration": f"LayerNorm launches: {LN_BYTES_PER_EVAL / 1e9:.1f} GB known per evaluation vs counters "
                           f"{ln_f / 1e9:.2f} GB fetched / {ln_w / 1e9:.2f} GB written"}
-    out = ROOT / "profiles" / "round5" / "pmc_traffic.json"
+    out = OUT
     out.parent.mkdir(parents=True, exist_ok=True)
     doc = json.loads(out.read_text()) if out.exists() else {"records": {}}
     doc["records"][prec] = rec

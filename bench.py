@@ -803,6 +803,14 @@ def main():
                 out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
             finally:
                 dog.cancel()
+        # round 6: BASELINE config 4 — the views of ONE sample sharded over the GPUs — as top-level fields next
+        # to the replica headline, so that a SCALE run reports it without digging into the nested record
+        sv = out.get("strong_scaling_views") or {}
+        out["config4_views_sharded"] = {"steps_per_s": sv.get("value"), "per_sample_latency_ms": sv.get("per_sample_latency_ms"),
+                                        "parallelism": sv.get("parallelism"), "scaling": "strong", "n_gpus": world,
+                                        "error": sv.get("error"),
+                                        "note": "one 6-view x 8-frame sample over all GPUs (views x2, cfg x views, cfg x views x frames "
+                                                "at 2 / 4 / 8); the headline `value` is the replica mode (one sample per GPU, weak scaling)"}
     if shard is not None:
         nsteps = args.steps + args.warmup
         nx, nb = _exchange_counts(shard, shard2)

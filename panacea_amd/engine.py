@@ -221,6 +221,36 @@ class FrameShard:
             work.wait()
         return recv.permute(1, 2, 0, 3, 4).contiguous().view(B * Tl * N, C)
 
+    # ---- round 6: the planes of ONE operand (fp16 hi + e4m3 / fp16 lo) travel in ONE exchange — row-wise byte concatenation, one
+    #      all_to_all instead of one per plane: the STT temporal branch goes from 4 to 2 exchanges per site (92 -> 46 per evaluation)
+    @staticmethod
+    def _pack_planes(planes):
+        keep = [p for p in planes if p is not None]
+        rows = keep[0].shape[0]
+        return torch.cat([p.contiguous().view(rows, -1).view(torch.uint8) for p in keep], dim=1), [(p.dtype, p.shape[1]) for p in keep]
+
+    @staticmethod
+    def _unpack_planes(buf, spec, planes):
+        out, o, it = [], 0, iter(spec)
+        for p in planes:
+            if p is None:
+                out.append(None)
+                continue
+            dt, C = next(it)
+            nb = C * torch.empty((), dtype=dt).element_size()
+            out.append(buf[:, o:o + nb].contiguous().view(dt).view(buf.shape[0], C))
+            o += nb
+        return out
+
+    def to_pixels_planes(self, planes, B: int, N: int):
+        """`to_pixels` of several planes of one operand (None entries pass through) in one exchange"""
+        buf, spec = self._pack_planes(planes)
+        return self._unpack_planes(self.to_pixels(buf, B, N), spec, planes)
+
+    def to_frames_planes(self, planes, B: int, N: int):
+        buf, spec = self._pack_planes(planes)
+        return self._unpack_planes(self.to_frames(buf, B, N), spec, planes)
+
     # ---- round 4: the ResBlock3D temporal sites WITHOUT moving the fp32 stream (VERDICT r3 next 6).  The temporal GroupNorm only
     #      needs per-(pixel, group) sums over all T frames: every rank reduces its frames, the frame group adds the partial sums
     #      (256 B per pixel, whatever C and T); the k = 3 temporal conv only needs ONE frame of the normalised fp16 operand from

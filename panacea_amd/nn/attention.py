@@ -387,8 +387,7 @@ class SpatialTemporalTransformer(nn.Module, Packable):
             # Frame-sharded run: the temporal branch is pointwise per pixel (LN, projections, text cross-attention, FF) or
             # couples the T frames of ONE pixel (temporal self-attention), so it runs on all T frames of N/G pixels.
             # Exchanged: the GroupNorm output going in, the last block's fp16 output coming back (fp16 planes only).
-            n16 = sh.to_pixels(n16, rt.B, x.N)
-            n16lo = sh.to_pixels(n16lo, rt.B, x.N) if n16lo is not None else None
+            n16, n16lo = sh.to_pixels_planes([n16, n16lo], rt.B, x.N)       # (hi + lo plane in ONE exchange: round 6)
             Fb, Hb, Wb = rt.B * rt.T, 1, x.N // sh.G
         else:
             Fb, Hb, Wb = x.F, x.H, x.W
@@ -408,8 +407,7 @@ class SpatialTemporalTransformer(nn.Module, Packable):
             if r is not None:
                 p16, p16lo = r
         if sh is not None:
-            p16 = sh.to_frames(p16, rt.B, x.N)
-            p16lo = sh.to_frames(p16lo, rt.B, x.N) if p16lo is not None else None
+            p16, p16lo = sh.to_frames_planes([p16, p16lo], rt.B, x.N)
         # x = proj_out(t) + x_in, in place on the stream
         rt.be.gemm(p16, pk["wo" + sfx], M=M, N=C, K=C, lda=C, bias=pk["bo" + sfx], res1=x.f32, ldr1=C,
                    out32=x.f32, ldc32=C, out16=out16, ldc16=C, a16_lo=p16lo, out16_lo=out16_lo,

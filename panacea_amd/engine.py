@@ -440,6 +440,10 @@ class ViewShard:
         the band, no window copy of the conv's output).  A plane that came from Runtime.empty(..., tail_rows >= 2*F*H) is used in
         place; any other is copied once into such an allocation."""
         M, tail = F * H * W, 2 * F * H
+        if all(getattr(p, "_pnc_halo_ready", False) and getattr(p, "_pnc_tail", None) is not None for p in planes):
+            # round 6: the GroupNorm that wrote this operand already exchanged the neighbours' RAW edge columns together with its
+            # statistics records (stats_and_halo) and normalised them into the tail: no second exchange in front of the conv
+            return [p._pnc_tail for p in planes], M * C
         # the planes' edge columns travel as ONE byte message per direction, row (f, y) = [plane 0's C values | plane 1's | ...]:
         # one gather launch per direction whatever the number of planes
         maps = [p.view(F, H, W, C).view(torch.uint8) for p in planes]
@@ -490,6 +494,62 @@ class ViewShard:
         self.exchanges += 1
         return out
 
+    # ---- round 6: GroupNorm -> 3x3 conv of a view band in ONE exchange instead of two.  Rounds 3-5 all-gathered
+    #      the statistics records, normalised, and then exchanged the NORMALISED edge columns (band_operand): two exchanges on one
+    #      dependency chain at each of the 67 GroupNorm + conv sites of an evaluation.  The neighbour's normalised edge column is a
+    #      function of its RAW fp32 column and of the panorama's combined statistics — which this rank holds anyway — so the raw
+    #      columns ride with the records and each rank normalises the two columns it received with the same kernel, the same
+    #      combined records: the same bits as the neighbour computed (gloo tests: eps equal to the two-exchange form).
+    fused_halo = True                 # False: rounds 3-5's two exchanges (A/B, tests)
+
+    def stats_and_halo(self, part: torch.Tensor, col_left: torch.Tensor, col_right: torch.Tensor, F: int, nchunk: int):
+        """part: this band's records [F, nchunk, 32, 3]; col_left / col_right: its RAW fp32 edge columns [F, H, C] (image columns 0
+        and W - 1) -> (records of all G bands in rank order [G * F * nchunk * 96], the left neighbour's column W - 1 or None at the left
+        end of the panorama, the right neighbour's column 0 or None at the right end).  ONE all_to_all_single inside the view group:
+        every peer gets the records, the two neighbours one column each on top."""
+        G, me = self.G, self.index
+        mine = part.reshape(-1)[: F * nchunk * 96].contiguous()
+        self.exchanges += 1
+        if self.group is None:                       # loop-back: one band = the whole panorama, zeros beyond both ends
+            return mine, None, None
+        import torch.distributed as dist
+        dev = mine.device
+        rb = mine.view(torch.uint8)
+        cl, cr = col_left.contiguous().view(-1).view(torch.uint8), col_right.contiguous().view(-1).view(torch.uint8)
+        nr, nc = rb.numel(), cl.numel()
+        parts, in_split, out_split = [], [0] * G, [0] * G
+        for p in range(G):
+            parts.append(rb)
+            in_split[p] = out_split[p] = nr
+            if p == me - 1:                          # my left neighbour: my column 0 is its column W
+                parts.append(cl)
+                in_split[p] += nc
+                out_split[p] += nc
+            elif p == me + 1:                        # my right neighbour: my column W - 1 is its column -1
+                parts.append(cr)
+                in_split[p] += nc
+                out_split[p] += nc
+        send = torch.cat(parts)
+        self.bytes_sent += send.numel() - nr
+        stage = self._host and dev.type != "cpu"
+        if stage:
+            send = send.cpu()
+        recv = torch.empty(sum(out_split), dtype=torch.uint8, device=send.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=self.group)
+        if stage:
+            recv = recv.to(dev)
+        recs, from_left, from_right, o = [], None, None, 0
+        for p in range(G):
+            recs.append(recv[o:o + nr])
+            o += nr
+            if p == me - 1:
+                from_left = recv[o:o + nc].view(torch.float32).view(col_left.shape)      # its column W - 1
+                o += nc
+            elif p == me + 1:
+                from_right = recv[o:o + nc].view(torch.float32).view(col_right.shape)    # its column 0
+                o += nc
+        return torch.cat(recs).view(torch.float32), from_left, from_right
+
     def neighbour_views(self, k4: torch.Tensor, v4: torch.Tensor):
         """k4 [F, H, W_l, C] keys (channels-last), v4 [F, C, H, W_l] values (channel-major) of this band -> the same with one
         view of the left neighbour in front and one of the right neighbour behind (circular), i.e. n_local + 2 views.
@@ -509,10 +569,15 @@ class ViewShard:
         Wv = Wl // self.n_local
         (kl, vl), (kr, vr) = self._exchange([k4[:, :, :Wv], v4[..., :Wv]], [k4[:, :, -Wv:], v4[..., -Wv:]])
         kh, vh = [], []
-        for kn, vn in ((kl, vl), (kr, vr)):
-            kb = rt.empty((k_rows, k_ld), k4.dtype)
+        # the four band-geometry buffers are allocated ONCE per geometry and evaluation (~190 MB per site at level 0 of a
+        # 3-view band when allocated per call); only view column 0 is ever written or read, launches on one stream are ordered
+        cache = rt.__dict__.setdefault("_halo_bufs", {})
+        for side, (kn, vn) in enumerate(((kl, vl), (kr, vr))):
+            key = (side, k_rows, k_ld, F, C, H * Wl, k4.dtype)
+            if key not in cache:
+                cache[key] = (rt.empty((k_rows, k_ld), k4.dtype), rt.empty((F, C, H * Wl), v4.dtype))
+            kb, vb = cache[key]
             kb.view(F, H, Wl, k_ld)[:, :, :Wv, k_col:k_col + C] = kn
-            vb = rt.empty((F, C, H * Wl), v4.dtype)
             vb.view(F, C, H, Wl)[..., :Wv] = vn
             kh.append(kb.view(-1)[k_col:])
             vh.append(vb)
@@ -771,8 +836,36 @@ def gn_spatial(rt: Runtime, x32: torch.Tensor, F: int, N: int, C: int, gamma, be
         rt.be.groupnorm_stats(x32, C, F, N, C, ppc, part)
     else:
         nrec = part.numel() // (F * 96)          # the producer's records per frame (GEMM epilogues: 64-pixel chunks; the concat: _ppc(N))
-    if rt.vshard is not None:           # statistics of the whole panorama, not of this rank's band of views
-        part = rt.vshard.combine_stats(part, F, nrec, rt.be)
+    vs = rt.vshard
+    if vs is not None and tail_rows and vs.fused_halo and tail_rows % (2 * F) == 0 and N % (tail_rows // (2 * F)) == 0:
+        # GroupNorm -> 3x3 conv of a view band: records + the neighbours' raw edge columns in ONE exchange (ViewShard.stats_and_halo)
+        H = tail_rows // (2 * F)
+        W = N // H
+        x4 = x32.view(F, H, W, C)
+        allp, fl, fr = vs.stats_and_halo(part, x4[:, :, 0], x4[:, :, W - 1], F, nrec)
+        comb = torch.empty((F * nrec * 96,), device=x32.device, dtype=torch.float32)
+        rt.be.groupnorm_combine(allp, vs.G if vs.group is not None else 1, F, nrec, comb)
+        rt.be.groupnorm_apply(x32, C, F, N, C, ppc, comb, gamma, beta, eps, silu, y, C, ylo, n_records=nrec)
+        # the two received columns, normalised by the same kernel with the same combined records, land in the operand's tail
+        # [2][F][H][C] (PncGemmParams.x_halo_off); zeros at the ends of the panorama — the conv's own padding
+        for side, raw in ((0, fl), (1, fr)):
+            for pl in (y, ylo):
+                if pl is None:
+                    continue
+                t = pl._pnc_tail[F * N + side * F * H: F * N + (side + 1) * F * H]
+                if raw is None:
+                    t.zero_()
+            if raw is not None:
+                yt = y._pnc_tail[F * N + side * F * H: F * N + (side + 1) * F * H]
+                lt = None if ylo is None else ylo._pnc_tail[F * N + side * F * H: F * N + (side + 1) * F * H]
+                rt.be.groupnorm_apply(raw.reshape(F * H, C).contiguous(), C, F, H, C, ppc, comb, gamma, beta, eps, silu, yt, C, lt,
+                                      n_records=nrec)
+        y._pnc_halo_ready = True
+        if ylo is not None:
+            ylo._pnc_halo_ready = True
+        return y, ylo
+    if vs is not None:           # statistics of the whole panorama, not of this rank's band of views
+        part = vs.combine_stats(part, F, nrec, rt.be)
     rt.be.groupnorm_apply(x32, C, F, N, C, ppc, part, gamma, beta, eps, silu, y, C, ylo, n_records=nrec)
     return y, ylo
 

@@ -1028,6 +1028,52 @@ def test_attn_views_sum_triggered_running_max(variant, scale_q, spike):
         hip.set_option(hip.OPT_ATTN_VARIANT, pv)
 
 
+@pytest.mark.parametrize("variant,dma", [(0, 1), (42, 1), (42, 2), (82, 1), (81, 2), (41, 1), (0, 0)])
+@pytest.mark.parametrize("n_local,H,Wv,heads", [(3, 16, 32, 2), (2, 8, 16, 1), (1, 32, 64, 1)])
+def test_attn_views_halo_views_of_a_view_band(variant, dma, n_local, H, Wv, heads):
+    """PncAttnParams.k_halo / vt_halo (round 5; kernel-level test asked for by ADVICE r5): a rank's band of n_local views attends
+    its circular neighbours' edge views, which live in view column 0 of two buffers with the BAND's geometry (segment ids -1 and
+    kv_views) — against the emulation AND against the same attention over the explicitly concatenated n_local + 2 views (round 3-4
+    form), for the incremental and the recomputed tile addresses, LDS-DMA and register staging, every workgroup shape.  The halo
+    buffers' other columns hold NaN: nothing outside view column 0 may be read."""
+    G = 2
+    W = n_local * Wv
+    C, N = heads * 64, H * W
+    q, k, _, vt = _qkv(G, N, C, 21)
+    nan = float("nan")
+    kh = [torch.full((G * N, C), nan, device=DEV, dtype=torch.float16) for _ in range(2)]
+    vh = [torch.full((G, C, N), nan, device=DEV, dtype=torch.float16) for _ in range(2)]
+    kn = [rnd(G, H, Wv, C, dtype=torch.float16, seed=31 + i) for i in range(2)]
+    vn = [rnd(G, C, H, Wv, dtype=torch.float16, seed=41 + i) for i in range(2)]
+    for i in range(2):
+        kh[i].view(G, H, W, C)[:, :, :Wv] = kn[i]
+        vh[i].view(G, C, H, W)[..., :Wv] = vn[i]
+    # every local view attends its left and right neighbour (the panorama's INTER_SEGS restricted to an interior band)
+    segs = [[(v - 1) if v > 0 else -1, (v + 1) if v < n_local - 1 else n_local] for v in range(n_local)]
+    kw = dict(groups=G, heads=heads, H=H, W=W, views=n_local, kvH=H, kvW=W, kv_views=n_local, kv_rows_per_group=N, q_per_kv=1,
+              kv_valid=H * Wv, segs=segs, scale=0.125)
+    oe = torch.zeros(G * N, C, device=DEV, dtype=torch.float16)
+    emu.attn_views(q, C, k, C, vt, N, C * N, oe, C, k_halo=kh, vt_halo=vh, **kw)
+    # the explicit form: [left | band | right] concatenated along the width
+    We = W + 2 * Wv
+    ke = torch.cat([kn[0], k.view(G, H, W, C), kn[1]], dim=2).contiguous().view(G * H * We, C)
+    ve = torch.cat([vn[0], vt.view(G, C, H, W), vn[1]], dim=3).contiguous().view(G, C, H * We)
+    kw2 = dict(kw, kvW=We, kv_views=n_local + 2, kv_rows_per_group=H * We, segs=[[u + 1 for u in row] for row in segs])
+    ox = torch.zeros_like(oe)
+    pv, pd = hip.set_option(hip.OPT_ATTN_VARIANT, variant), hip.set_option(hip.OPT_ATTN_DMA, dma)
+    try:
+        oh = torch.zeros_like(oe)
+        hip.attn_views(q, C, k, C, vt, N, C * N, oh, C, k_halo=kh, vt_halo=vh, **kw)
+        hip.attn_views(q, C, ke, C, ve, H * We, C * H * We, ox, C, **kw2)
+        torch.cuda.synchronize()
+    finally:
+        hip.set_option(hip.OPT_ATTN_VARIANT, pv)
+        hip.set_option(hip.OPT_ATTN_DMA, pd)
+    assert torch.isfinite(oh.float()).all()
+    check("attn_views_halo", oh, oe, 3e-3)
+    assert torch.equal(oh, ox)              # same keys in the same tile order: the same bits as the concatenated form
+
+
 def test_groupnorm_combine_kernel():
     """pnc_groupnorm_combine (round 4): Chan combination of the all-gathered chunk records of a view group's bands, against the
     float64 formula; the apply kernel fed with the combined records normalises with the statistics of the concatenation."""

@@ -329,8 +329,17 @@ def _views_worker(rank, world, port, out_dir, cfg, V, T, network):
            "crossattn": inp["crossattn"][halves]}
     parallel.apply_view_shard(net, vs)
     with E.use_backend(emu), torch.no_grad():
+        # round 6: GroupNorm -> 3x3 conv sites exchange their records and the neighbours' RAW edge columns in ONE all-to-all
+        # (ViewShard.stats_and_halo) instead of records, then normalised columns: fewer exchanges, the same bits
+        vs.fused_halo = False
+        n0 = vs.exchanges
+        eps_two = net(loc["x"], loc["t"], cond_of(loc))
+        n_two = vs.exchanges - n0
+        vs.fused_halo = True
         n0 = vs.exchanges
         eps_loc = net(loc["x"], loc["t"], cond_of(loc))
+        assert torch.equal(eps_loc, eps_two), (eps_loc - eps_two).abs().max().item()
+        assert vs.exchanges - n0 <= n_two - 20, (vs.exchanges - n0, n_two)         # the tiny network: 23 GroupNorm + conv sites
         assert vs.exchanges > n0 and vs.bytes_sent > 0
         torch.save({"eps": eps_loc, "halves": halves, "vg": vg, "exchanges": vs.exchanges - n0}, Path(out_dir) / f"eps{rank}.pt")
         # --- (3) two sampler steps with the layout's guider; the latent stays a band, gathered once at the end

@@ -75,7 +75,8 @@ enum {
                                      maximum grows.  Same softmax, other roundings of P (not bit-identical across values) */
     PNC_OPT_GEMM_GN_STATS = 9,    /* 1 (default): PncGemmParams.gn_part comes out of the temporal conv's epilogue where its waves own whole
                                      groups; 0 = always the statistics kernel after the GEMM (same records up to fp32 summation order) */
-    PNC_OPT_GEMM_STAGGER = 10,    /* k (default 8; round 5): the persistent GEGLU GEMM runs K loops of at least k tiles in the STAGGERED schedule —
+    PNC_OPT_GEMM_STAGGER = 10,    /* k (default 4 since round 6 — level-0 FF1, K = 320 = 5 tiles, measured 434 -> 420 us staggered; 8 in round 5): the
+                                     persistent GEGLU GEMM runs K loops of at least k tiles in the STAGGERED schedule —
                                      four phases per K tile {fragment reads + a third of the next tile's DMA | barrier | MFMAs | barrier},
                                      waves 4-7 one barrier behind waves 0-3, so that on every SIMD one wave multiplies while the other
                                      reads (FF1 at levels 1-2: +5-6 %); 0 = never (round 4's loops); 1 = everywhere the schedule exists —

@@ -278,7 +278,7 @@ extern "C" const char* pnc_version(void) { return "panacea_hip 0.4.0 gfx950"; }
 static const char k_build_digest[] = "pnc-build-digest:" PNC_BUILD_DIGEST;
 extern "C" const char* pnc_build_digest(void) { return k_build_digest + 17; }
 
-static std::atomic<int> g_options[PNC_OPT_COUNT] = {{1}, {0}, {0}, {1}, {1}, {0}, {1}, {3}, {8}, {1}, {8}, {12}};
+static std::atomic<int> g_options[PNC_OPT_COUNT] = {{1}, {0}, {0}, {1}, {1}, {0}, {1}, {3}, {8}, {1}, {4}, {12}};
 
 int pnc_get_option(int option) { return g_options[option].load(std::memory_order_relaxed); }
 

@@ -190,3 +190,98 @@ def test_layernorm_and_timestep_embedding_vs_oracle():
     hip.timestep_embedding(t.to(DEV), t.numel(), 320, E.timestep_freqs(320, torch.device(DEV)), out)
     torch.cuda.synchronize()
     close("timestep embedding", out, po.timestep_embedding(t, 320), 2e-4)
+
+
+# ---- round 6: more call-sites compared with the oracle's primitives / plain torch fp32 directly ----------------
+@pytest.mark.parametrize("F,H,W,C", [(4, 32, 64, 320), (2, 16, 96, 640)])
+def test_stencil_tile_conv3x3_vs_oracle(F, H, W, C):
+    """the 3x3 conv over spatial tiles that hold their halo (gemm_stencil_tile.hip: the ResBlock3D convs of the full-size network),
+    forced on a grid the size heuristic would hand to the per-tap gather, against the oracle's _conv — incl. residual + fp16 output"""
+    sd = {"c.weight": r16(C, C, 3, 3, scale=(9 * C) ** -0.5, seed=90), "c.bias": r16(C, scale=0.1, seed=91)}
+    x = r16(F, C, H, W, seed=92)
+    res = r16(F, C, H, W, seed=93)
+    ref = po._conv(sd, "c", x) + res
+    M = F * H * W
+    x16 = x.to(DEV).permute(0, 2, 3, 1).reshape(M, C).contiguous().half()
+    o32 = res.to(DEV).permute(0, 2, 3, 1).reshape(M, C).contiguous()
+    o16 = torch.empty(M, C, device=DEV, dtype=torch.float16)
+    prev = hip.set_option(hip.OPT_STENCIL_TILES, 2)
+    try:
+        hip.gemm(x16, E.pk_conv3x3(sd["c.weight"]).to(DEV), M=M, N=C, K=9 * C, a_mode=hip.A_CONV3X3,
+                 conv=dict(Cin=C, Hin=H, Win=W, Hout=H, Wout=W, stride=1, upsample=0), bias=sd["c.bias"].to(DEV),
+                 res1=o32, ldr1=C, out32=o32, ldc32=C, out16=o16, ldc16=C)
+        torch.cuda.synchronize()
+    finally:
+        hip.set_option(hip.OPT_STENCIL_TILES, prev)
+    close(f"stencil conv3x3 {C} + res", o32.view(F, H, W, C).permute(0, 3, 1, 2), ref)
+    close(f"stencil conv3x3 {C} fp16 out", o16.view(F, H, W, C).permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("mode", ["down", "up"])
+def test_down_and_upsample_convs_vs_torch(mode):
+    """Downsample (openaimodel.py:161-201: 3x3 stride 2, pad 1) and Upsample (:106-142: nearest x2, then 3x3) with the stride / the
+    nearest-neighbour expansion folded into the conv's A gather — no strided or upsampled tensor exists — against torch fp32"""
+    import torch.nn.functional as TF
+    F, H, W, C = 2, 16, 96, 320
+    w = r16(C, C, 3, 3, scale=(9 * C) ** -0.5, seed=95)
+    b = r16(C, scale=0.1, seed=96)
+    x = r16(F, C, H, W, seed=97)
+    if mode == "down":
+        ref = TF.conv2d(x, w, b, stride=2, padding=1)
+        conv = dict(Cin=C, Hin=H, Win=W, Hout=H // 2, Wout=W // 2, stride=2, upsample=0)
+    else:
+        ref = TF.conv2d(TF.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+        conv = dict(Cin=C, Hin=H, Win=W, Hout=2 * H, Wout=2 * W, stride=1, upsample=1)
+    M = F * conv["Hout"] * conv["Wout"]
+    x16 = x.to(DEV).permute(0, 2, 3, 1).reshape(-1, C).contiguous().half()
+    out = torch.empty(M, C, device=DEV)
+    hip.gemm(x16, E.pk_conv3x3(w).to(DEV), M=M, N=C, K=9 * C, a_mode=hip.A_CONV3X3, conv=conv, bias=b.to(DEV), out32=out, ldc32=C)
+    torch.cuda.synchronize()
+    close(f"{mode}sample conv", out.view(F, conv["Hout"], conv["Wout"], C).permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 320, 320), (2048, 640, 1280)])
+def test_precise_operand_gemm_vs_fp64(M, N, K):
+    """a split operand (fp16 hi + e4m3 lo plane, lo pass on the scaled fp8 MFMA against the e4m3 weight copy: DESIGN.md section 4) against
+    the fp64 product of the UNROUNDED fp32 activations: the pair must resolve the operand far below fp16's 2^-11 — measured ~30x
+    closer than the plain fp16 operand on the same data"""
+    g = torch.Generator().manual_seed(5)
+    a32 = torch.randn(M, K, generator=g) * 1.5
+    w = r16(N, K, scale=K ** -0.5, seed=6)
+    ref = (a32.double() @ w.double().t()).float()
+    a = a32.to(DEV)
+    hi = torch.empty(M, K, device=DEV, dtype=torch.float16)
+    lo = torch.empty(M, K, device=DEV, dtype=torch.uint8)
+    hip.cast_f16(a, M * K, hi, lo)
+    w16 = w.half().to(DEV)
+    out_p, out_f = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    hip.gemm(hi, w16, M=M, N=N, K=K, lda=K, out32=out_p, ldc32=N, a16_lo=lo, w_lo=E.pk_lo8(w16))
+    hip.gemm(hi, w16, M=M, N=N, K=K, lda=K, out32=out_f, ldc32=N)
+    torch.cuda.synchronize()
+    ep, ef = (out_p.cpu() - ref).abs().max().item(), (out_f.cpu() - ref).abs().max().item()
+    print(f"precise operand GEMM {M}x{N}x{K}: max-abs err split {ep:.2e}, plain fp16 operand {ef:.2e}")
+    assert ep <= 2.5e-4 * max(1.0, ref.abs().max().item()) and ep * 8 <= ef, (ep, ef)
+
+
+def test_concat_add_with_groupnorm_records_vs_torch():
+    """th.cat([h, hs.pop() + control.pop()], dim=1) (controlmodel.py:196-197) in one pass that also writes the GroupNorm(32) records
+    of the result: values against torch, the records through pnc_groupnorm_apply against torch's group_norm"""
+    import torch.nn.functional as TF
+    F, H, W, C1, C2 = 2, 16, 96, 640, 320
+    N, M, C = H * W, F * H * W, C1 + C2
+    h, s, c = r16(M, C1, seed=101) * 1.3, r16(M, C2, seed=102), r16(M, C2, seed=103) * 0.5
+    ref = torch.cat([h, s + c], dim=1)
+    ppc = E._ppc(N)
+    nrec = -(-N // ppc)
+    o32 = torch.empty(M, C, device=DEV)
+    o16 = torch.empty(M, C, device=DEV, dtype=torch.float16)
+    part = torch.empty(F * nrec * 96, device=DEV)
+    hip.concat_add(h.to(DEV), C1, s.to(DEV), c.to(DEV), C2, M, o32, o16, None, gn_part=part, frames=F, ppc=ppc)
+    gamma, beta = (r16(C, scale=0.3, seed=104) + 1.0), r16(C, scale=0.2, seed=105)
+    y = torch.empty(M, C, device=DEV, dtype=torch.float16)
+    hip.groupnorm_apply(o32, C, F, N, C, ppc, part, gamma.to(DEV), beta.to(DEV), 1e-5, False, y, C, n_records=nrec)
+    torch.cuda.synchronize()
+    assert torch.equal(o32.cpu(), ref)                                   # fp32 adds: exact
+    close("concat fp16 plane", o16, ref, 1e-3)
+    gn = TF.group_norm(ref.view(F, N, C).permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1).reshape(M, C)
+    close("GroupNorm from the concat's records", y, gn, 2e-3)

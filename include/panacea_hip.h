@@ -52,9 +52,13 @@ enum {
     PNC_OPT_GEMM_TILE = 1,        /* 0 (default): score-based tile choice; 1 = 128x128, 2 = 256x128, 3 = 256x320,
                                      4 = 256x256 force a geometry where the shape allows it (kernel micro-benchmarks) */
     PNC_OPT_ATTN_VARIANT = 2,     /* 0 (default): by view size; 41 / 81 / 42 / 82 = (waves, query blocks per wave); 42 (large views, default) runs two independent
-                                     4-wave workgroups per CU (<= 256 registers); 1 = by view size with 82 (round 3's choice) in the place of 42 */
+                                     4-wave workgroups per CU (<= 256 registers); 1 = by view size with 82 (round 3's choice) in the place of 42;
+                                     43 = the single-pass few-key kernel (round 6: 64 < kv_valid <= 96 keys shared by all queries of a group —
+                                     the text tokens; default there when the grid fills the chip) wherever it applies; any other non-zero
+                                     value keeps attn_views_kernel for those launches too (A/B) */
     PNC_OPT_ATTN_DMA = 3,         /* 1 (default): LDS-DMA staging of K / V^T tiles where alignment allows, tile addresses kept as lane constant +
-                                     wave-uniform offset; 2 = LDS-DMA with per-tile recomputed addresses (A/B); 0 = register staging.  Same results */
+                                     wave-uniform offset; 2 = LDS-DMA with per-tile recomputed addresses (A/B); 0 = register staging.  Same results.
+                                     + 4 (round 6, A/B): the few-key launches stay on attn_views_kernel instead of attn_text_kernel */
     PNC_OPT_GEMM_FUSE_LN = 4,     /* 1 (default): PncGemmParams.ln_* is reduced in the GEMM epilogue where a workgroup owns whole
                                      rows; 0 = always the LayerNorm kernel after the GEMM (A/B measurements; same result) */
     PNC_OPT_GEMM_GROUP_M = 5,     /* 0 (default): tiles of a GEMM with more than 8 column tiles are walked in groups of 4 row panels

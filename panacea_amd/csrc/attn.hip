@@ -422,6 +422,170 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && QB == 2 && DMA) ? 2 : 1) void 
 }
 
 // ------------------------------------------------------------------------------------------
+// attn_text_kernel (round 6): cross-attention against FEW keys shared by every query of a sample — the 77 text tokens (attention.py:
+// 229-291 with the prompt as context; 63 sites per network evaluation).  On attn_views_kernel this launch is a stream of q in / o out
+// with a 2-tile loop in the middle: 2.4-3.1 TB/s, because a workgroup's life is one serial chain — wait for its Q rows, two key tiles
+// of which the second holds 13 keys, store — and 8 waves per CU cannot hide it (profiles/round6/attn_counter_audit.md: 52 % of the
+// wave cycles waiting).  Here a workgroup of 4 waves owns 128 queries x HG heads:
+//   * the Q fragments of ALL its heads are requested up front (HG x 64 B per lane: 80 KB per workgroup in flight);
+//   * the <= 96 keys are ONE tile, so the softmax is single-pass — true row maximum, no running state, no rescale —, the padded
+//     fourth 32-key block of the 2 x 64-key form is never computed (24 MFMAs per 32 queries and head instead of 32, 48 score slots per
+//     lane instead of 64);
+//   * K / V^T of head h + 1 arrive by LDS-DMA under head h's arithmetic (two stages of 28 KB).
+// Same S^T = K Q^T / O^T = V^T P^T register layout as attn_views_kernel (a lane owns a query; K rows permuted by kperm()).
+template <int HG>
+__global__ __launch_bounds__(256, 2) void attn_text_kernel(const PncAttnParams p, const int nhg) {
+    constexpr int KROWS = 96, STAGE = KROWS * 128 + 2 * 64 * 128;      // K tile (96 keys) + two V^T tiles (keys 0-63, 64-127)
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const half_t* __restrict__ Q = reinterpret_cast<const half_t*>(p.q);
+    const half_t* __restrict__ K = reinterpret_cast<const half_t*>(p.k);
+    const half_t* __restrict__ VT = reinterpret_cast<const half_t*>(p.vt);
+    half_t* __restrict__ O = reinterpret_cast<half_t*>(p.o);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Nq = p.H * p.W, nqt = (Nq + 127) >> 7;
+    const int Nkv = p.kvH * p.kvW;                          // rows of the key buffer per sample (80), kv_valid of them real
+    const int item = blockIdx.x;
+    const int hg = item % nhg, qt = (item / nhg) % nqt, g = item / (nhg * nqt);
+    const int kvg = g / p.q_per_kv;
+    const int h0 = hg * HG, nh = min(HG, p.heads - h0);
+    const int grp = lane >> 5, frow = lane & 31;
+    const int ql = qt * 128 + wave * 32 + frow;
+    const bool qok = ql < Nq;
+    const int64_t qrow = (int64_t)g * Nq + (qok ? ql : Nq - 1);
+    // ---- every head's Q fragments, requested at once
+    half8v qf[HG][4];
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh)
+        if (hh < nh) {
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds)
+                qf[hh][ds] = *reinterpret_cast<const half8v*>(Q + qrow * p.ldq + (h0 + hh) * 64 + ds * 16 + grp * 8);
+        }
+    // ---- K / V^T of one head -> stage: rows of 128 B, chunk index XOR-swizzled on the source side (as attn_views_kernel's DMA path)
+    const int sr = tid >> 3, sc8 = (tid & 7) ^ ((sr >> 1) & 7);
+    auto dma_head = [&](int hh, int stage) {
+        const int hc = (h0 + hh) * 64;
+        char* sk = smem + stage * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < KROWS / 32; ++i) {             // K: row = key, chunk = 8 channels
+            const int key = sr + 32 * i;
+            const half_t* src = key < Nkv ? K + ((int64_t)kvg * p.kv_rows_per_group + key) * p.ldk + hc + sc8 * 8 : g_attn_zero_chunk;
+            glds16(src, sk + i * 4096);
+        }
+        char* sv = smem + stage * STAGE + KROWS * 128 + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)                         // V^T: row = channel d, chunk = 8 consecutive keys of tile j
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int d = sr + 32 * i, kc = j * 64 + sc8 * 8;
+                const half_t* src = kc < Nkv ? VT + (int64_t)kvg * p.vt_gstride + (int64_t)(hc + d) * p.ldvt + kc : g_attn_zero_chunk;
+                glds16(src, sv + j * 8192 + i * 4096);
+            }
+    };
+    dma_head(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nh > 1) dma_head(1, 1);
+    const float sc = p.scale * 1.44269504088896340736f;
+    const int krow_lds = kperm(frow);
+    // Padding keys (kv_valid .. 95; their K rows are zeros) are masked through the ACCUMULATOR'S INITIAL VALUE: block 2's first MFMA
+    // starts from -1e30 at this lane's padding positions (key 64 + grp * 16 + r >= kv_valid) and from 0 elsewhere — sixteen registers
+    // set once per workgroup, no compare / select chain per head (the host dispatches this kernel for 64 < kv_valid <= 96 only)
+    f32x16 init2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) init2[r] = (64 + grp * 16 + r >= p.kv_valid) ? -1e30f : 0.0f;
+    const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const bool vec16 = ((p.ldo & 7) == 0) && (((uintptr_t)p.o & 15) == 0);
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh) {
+        if (hh >= nh) break;
+        const char* sk = smem + (hh & 1) * STAGE;
+        const char* sv = sk + KROWS * 128;
+        // ---- S^T = K Q^T: three 32-key blocks
+        f32x16 s[3];
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) {
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const half8v kf = *reinterpret_cast<const half8v*>(sk + lds_off128(kb * 32 + krow_lds, ds * 2 + grp));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[hh][ds], ds == 0 ? (kb == 2 ? init2 : zero16) : s[kb], 0, 0, 0);
+            }
+        }
+        // ---- single-pass softmax: the keys are one tile
+        float tmax = -1e30f;
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
+        const float m = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sc;
+        half8v pf[3][2];
+        float psum = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, -m));      // padding: exp2(-huge) = 0
+                psum += pv;
+                pf[kb][r >> 3][r & 7] = (half_t)pv;
+            }
+        const float ltot = psum + __shfl_xor(psum, 32, 64);
+        // ---- O^T = V^T P^T
+        f32x16 oacc[2];
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dh][r] = 0.0f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) {
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const half8v vf = *reinterpret_cast<const half8v*>(sv + (kb >> 1) * 8192 + lds_off128(dh * 32 + frow, (kb & 1) * 4 + grp * 2 + ss));
+                    oacc[dh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][ss], oacc[dh], 0, 0, 0);
+                }
+            }
+        // the next head's operands have landed and every wave is past its reads of this stage
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- normalise and store (attn_views_kernel's epilogue: one xor-32 exchange per pair of r4 -> 16-byte stores)
+        const float inv = ltot > 0.0f ? 1.0f / ltot : 0.0f;
+        half_t* orow = O + qrow * p.ldo + (h0 + hh) * 64;
+        // (16-byte pieces through one xor-32 exchange per pair of r4, as attn_views_kernel: 8-byte stores straight from the accumulator
+        // layout save 40 instructions per head and measured 5-9 % SLOWER — the launch is sensitive to store width)
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {
+                half4v he, ho;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    he[q] = (half_t)(oacc[dh][(2 * rp) * 4 + q] * inv);
+                    ho[q] = (half_t)(oacc[dh][(2 * rp + 1) * 4 + q] * inv);
+                }
+                if (vec16) {
+                    union { half4v h; int2 i; } snd, rcv;
+                    snd.h = grp ? he : ho;
+                    rcv.i.x = __shfl_xor(snd.i.x, 32, 64);
+                    rcv.i.y = __shfl_xor(snd.i.y, 32, 64);
+                    half8v o8;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o8[q] = grp ? rcv.h[q] : he[q];
+                        o8[4 + q] = grp ? ho[q] : rcv.h[q];
+                    }
+                    if (qok) *reinterpret_cast<half8v*>(orow + dh * 32 + 8 * (2 * rp + grp)) = o8;
+                } else if (qok) {
+                    *reinterpret_cast<half4v*>(orow + dh * 32 + 8 * (2 * rp) + 4 * grp) = he;
+                    *reinterpret_cast<half4v*>(orow + dh * 32 + 8 * (2 * rp + 1) + 4 * grp) = ho;
+                }
+            }
+        if (hh + 2 < nh) dma_head(hh + 2, hh & 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // temporal attention: lane = slot*8 + dl ; slot -> (pixel sub-index, frame t) ; dl -> 8 channels
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dot8(const half8v a, const half8v b) {
@@ -546,10 +710,26 @@ extern "C" int pnc_attn_views_f16(const PncAttnParams* pp, void* stream) {
     // and MFMA phases coincide and add up; two independent workgroups drift apart and overlap them: level 0 intra 685 -> 638 us,
     // cross 1221 -> 1164, level 1 intra 111 -> 100 (same box, interleaved: profiles/round4/attn_ab_r4a.log).  force = 1: the size
     // heuristic with 82 in the place of 42 (whole-step A/B of the old choice).
+    // Few keys shared by all queries of a sample (the text tokens): the dedicated single-pass kernel (round 6).  PNC_OPT_ATTN_VARIANT = 43
+    // forces it wherever it applies (tests), any other non-zero value keeps attn_views_kernel (A/B).
+    {
+        const bool text_ok = p.views == 1 && p.kv_views == 1 && p.nseg[0] == 1 && p.seg[0][0] == 0 && !p.causal && p.kvH * p.kvW <= 96 &&
+                             p.kv_valid > 64 && p.kv_valid <= 96 && (p.ldvt & 7) == 0 && (p.vt_gstride & 7) == 0 && (p.ldk & 7) == 0;
+        constexpr int HG = 5;
+        const int nhg = (p.heads + HG - 1) / HG;
+        const long nwg = (long)((Nq + 127) / 128) * nhg * p.groups;
+        // (a grid that does not fill the chip — the 4 x 48 level: 96 workgroups — stays on the smaller workgroups of attn_views_kernel)
+        const int dopt = pnc_get_option(PNC_OPT_ATTN_DMA);          // bit 2: keep attn_views_kernel for these launches (whole-step A/B)
+        if (text_ok && (force == 43 || (force == 0 && nwg >= 256)) && (dopt & 3) != 0 && !(dopt & 4)) {
+            const dim3 grid((unsigned)nwg);
+            hipLaunchKernelGGL((attn_text_kernel<HG>), grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, nhg);
+            return pnc_launch_status();
+        }
+    }
     const int big = force == 1 ? 82 : 42;
     const int variant = force >= 41 ? force : (kv_keys <= 256 ? (Nq >= 256 ? 42 : 41) : (Nq >= 512 ? big : (Nq >= 256 ? 81 : 41)));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int dma_mode = pnc_get_option(PNC_OPT_ATTN_DMA);
+    const int dma_mode = pnc_get_option(PNC_OPT_ATTN_DMA) & 3;
     const bool dma = ((kvWv & 7) == 0) && ((p.kvW & 7) == 0) && ((p.ldvt & 7) == 0) && ((p.vt_gstride & 7) == 0) && dma_mode != 0;
     int wv_shift = -1;
     if (kvWv > 0 && (kvWv & (kvWv - 1)) == 0) { wv_shift = 0; while ((1 << wv_shift) < kvWv) ++wv_shift; }

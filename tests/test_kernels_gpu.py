@@ -1155,6 +1155,40 @@ def test_attn_views_text(B, T, H, W, heads):
     check("attn_text", oh, oe, 3e-3)
 
 
+@pytest.mark.parametrize("B,T,H,W,heads,n_text,sharp", [(2, 2, 8, 96, 2, 77, 1.0), (1, 8, 4, 48, 1, 77, 1.0), (2, 4, 16, 48, 5, 77, 6.0),
+                                                        (1, 2, 13, 31, 7, 65, 1.0), (2, 1, 8, 96, 12, 96, 3.0), (1, 3, 8, 24, 20, 80, 1.0)])
+def test_attn_text_single_pass_kernel(B, T, H, W, heads, n_text, sharp):
+    """attn_text_kernel (round 6; PNC_OPT_ATTN_VARIANT = 43 forces it on grids the default leaves to attn_views_kernel): 64 < kv_valid
+    <= 96 keys shared by the queries of a sample, 128 queries x 5 heads per workgroup, single-pass softmax, padding keys masked
+    through the accumulator's initial value.  Against the emulation and against attn_views_kernel on the same operands — ragged query
+    counts (Nq % 128 != 0), head counts that are no multiple of 5, 65 / 77 / 80 / 96 valid keys, sharp rows; padding key rows hold
+    NaN-free garbage that must not reach the output."""
+    C, N, G = heads * 64, H * W, B * T
+    q = rnd(G * N, C, dtype=torch.float16, seed=3) * sharp
+    k = rnd(B * 96, C, dtype=torch.float16, seed=4)
+    v = rnd(B * 96, C, dtype=torch.float16, seed=6)
+    k.view(B, 96, C)[:, n_text:] = 0                    # (the product zero-pads: engine.Runtime.set_context)
+    v.view(B, 96, C)[:, n_text:] = 7.0                  # values of padding keys must not matter: their probabilities are exact zeros
+    vt = v.view(B, 96, C).permute(0, 2, 1).contiguous()
+    kw = dict(groups=G, heads=heads, H=H, W=W, views=1, kvH=1, kvW=96, kv_views=1, kv_rows_per_group=96,
+              q_per_kv=T, kv_valid=n_text, segs=[[0]], scale=0.125)
+    oe = torch.zeros(G * N, C, device=DEV, dtype=torch.float16)
+    emu.attn_views(q, C, k, C, vt, 96, C * 96, oe, C, **kw)
+    outs = {}
+    for variant in (43, 42):
+        prev = hip.set_option(hip.OPT_ATTN_VARIANT, variant)
+        try:
+            o = torch.full((G * N, C), float("nan"), device=DEV, dtype=torch.float16)
+            hip.attn_views(q, C, k, C, vt, 96, C * 96, o, C, **kw)
+            torch.cuda.synchronize()
+        finally:
+            hip.set_option(hip.OPT_ATTN_VARIANT, prev)
+        assert torch.isfinite(o.float()).all(), variant
+        check(f"attn_text_v{variant}", o, oe, 3e-3)
+        outs[variant] = o
+    assert (outs[43].float() - outs[42].float()).abs().max().item() <= 4e-3
+
+
 def test_attn_views_strided_qkv_buffer():
     # q and k live in one [M, 2C] projection buffer (ld = 2C), as the engine lays them out
     G, H, W, heads = 2, 8, 96, 2

@@ -76,6 +76,63 @@ def test_view_bands_on_the_kernels_reproduce_the_single_process_eps(name, shape)
     assert r["exchanges"] > 50
 
 
+def _full_size_worker(rank, world, port, out_dir):
+    """BASELINE config 4 at BASELINE config 3's workload: the 2 x 8 frames of the full-size step, three views per process"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from helpers import cond as cond_of, product_network, step_inputs
+    from panacea_amd import configs, hip, parallel
+    hip.load()
+    parallel.init_distributed("gloo")
+    lo = parallel.RankLayout(world, rank, views=world)
+    groups = parallel.Groups(lo)
+    vs = groups.view_shard()
+    kw = configs.get("full")
+    net, _, _ = product_network("full", kw=kw, device="cpu")
+    net = net.to("cuda")
+    inp = step_inputs("full", kw, device="cuda", t_index=999, shape=(2, 8, 32, 384))
+    loc = {k: (parallel.local_views(v, lo) if v.dim() == 4 else v) for k, v in inp.items()}
+    parallel.apply_view_shard(net, vs)
+    with torch.no_grad():
+        eps = net(loc["x"], loc["t"], cond_of(loc))
+        torch.cuda.synchronize()
+        full = parallel.gather_views(eps, groups)
+        if rank == 0:
+            torch.save({"sharded": full.cpu(), "exchanges": vs.exchanges, "bytes": vs.bytes_sent, "lo_clamped": net.diffusion_model.lo_clamped,
+                        "precision": net.diffusion_model.precision}, Path(out_dir) / "out.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(2400)
+def test_view_bands_at_the_full_size_workload_vs_the_reference_eps():
+    """Round 6 (`configs_untested`): BASELINE config 4 — the views of a sample sharded — at the 6-view x 8-frame
+    32x384 workload itself (until now: 16x192, T = 2), and against the REFERENCE's eps (tests/golden/full_cfg3.npz, every element),
+    not against the single-process HIP result: two processes on the one GPU, three views each, gloo staging through the host;
+    every view exchange of the step (fused GroupNorm + conv halos, statistics, conv halos, neighbour views) at its real size."""
+    import numpy as np
+    from helpers import GOLDEN
+    gold = np.load(GOLDEN / "full_cfg3.npz")
+    if "eps" not in gold.files:
+        pytest.skip("full_cfg3.npz holds no whole eps")
+    port = 29500 + ((os.getpid() * 17 + 3) % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_full_size_worker, args=(2, port, d), nprocs=2, join=True)
+        r = torch.load(Path(d) / "out.pt")
+    diff = (r["sharded"].float() - torch.from_numpy(gold["eps"])).abs()
+    wl = diff.shape[-1] // 2
+    edge = diff[..., [wl - 1, wl]].mean().item()
+    print(f"full-size view bands vs the reference ({r['precision']}): max {diff.max().item():.3e} mean {diff.mean().item():.3e} "
+          f"edge-mean {edge:.3e}; {r['exchanges']} exchanges, {r['bytes'] / 1e6:.1f} MB sent per rank")
+    measured("view_shard_full_size_vs_reference", max_abs=diff.max().item(), mean_abs=diff.mean().item(), edge_mean=edge,
+             exchanges=r["exchanges"], MB_sent=r["bytes"] / 1e6)
+    assert diff.max().item() <= 1e-3 and diff.mean().item() <= 2e-4            # the north-star tolerance, on the sharded path
+    assert edge <= 3.0 * diff.mean().item() + 1e-6
+    assert r["lo_clamped"] == 0 and r["exchanges"] >= 150
+
+
 def _rccl_world1_view_worker(rank, port, out):
     """the view-shard exchanges through torch.distributed "nccl" (= RCCL) on the MI355X with a one-rank group: the
     all_to_all_single with split sizes and the all_gather_into_tensor of `ViewShard` run as RCCL collectives on the HIP stream"""

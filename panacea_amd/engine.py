@@ -178,6 +178,12 @@ class FrameShard:
         if self.group is None:
             return send.clone(), None
         import torch.distributed as dist
+        if dist.get_backend(self.group) == "gloo" and send.device.type != "cpu":
+            # two processes on one GPU (tests): gloo moves host memory — staged and completed here
+            host = send.cpu()
+            got = torch.empty_like(host)
+            dist.all_to_all_single(got, host, group=self.group)
+            return got.to(send.device), None
         recv = torch.empty_like(send)
         return recv, dist.all_to_all_single(recv, send, group=self.group, async_op=True)
 
@@ -332,9 +338,11 @@ class FrameShard:
         if self.group is None:
             return x.clone()
         import torch.distributed as dist
-        parts = [torch.empty_like(x) for _ in range(G)]
-        dist.all_gather(parts, x.contiguous(), group=self.group)
-        return torch.stack([p.view(B, Tl, D) for p in parts], dim=1).reshape(B * G * Tl, D)
+        host = dist.get_backend(self.group) == "gloo" and x.device.type != "cpu"          # (two processes on one GPU: tests)
+        send = x.contiguous().cpu() if host else x.contiguous()
+        parts = [torch.empty_like(send) for _ in range(G)]
+        dist.all_gather(parts, send, group=self.group)
+        return torch.stack([p.view(B, Tl, D) for p in parts], dim=1).reshape(B * G * Tl, D).to(x.device)
 
 
 class ViewShard:

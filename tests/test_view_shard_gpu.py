@@ -133,6 +133,63 @@ def test_view_bands_at_the_full_size_workload_vs_the_reference_eps():
     assert r["lo_clamped"] == 0 and r["exchanges"] >= 150
 
 
+def _full_size_frames_worker(rank, world, port, out_dir):
+    """the T = 8 frames of both CFG halves over two frame groups (4 frames each), full-size network and latent"""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from helpers import cond as cond_of, product_network, step_inputs
+    from panacea_amd import configs, hip, parallel
+    hip.load()
+    parallel.init_distributed("gloo")
+    lo = parallel.RankLayout(world, rank, frames=world)
+    groups = parallel.Groups(lo)
+    sh = groups.frame_shard()
+    kw = configs.get("full")
+    T = kw["num_frames"]
+    net, _, _ = product_network("full", kw=kw, device="cpu")
+    net = net.to("cuda")
+    inp = step_inputs("full", kw, device="cuda", t_index=999, shape=(2, T, 32, 384))
+    loc = {k: (parallel.local_frames(v, lo, T) if v.shape[0] == 2 * T else v) for k, v in inp.items()}
+    parallel.apply_frame_shard(net, sh)
+    with torch.no_grad():
+        eps = net(loc["x"], loc["t"], cond_of(loc))
+        torch.cuda.synchronize()
+        parts = [torch.empty_like(eps.cpu()) for _ in range(world)]
+        dist.all_gather(parts, eps.cpu(), group=groups.frame_group)
+        if rank == 0:
+            tl = T // world
+            full = torch.stack([q.view(2, tl, *q.shape[1:]) for q in parts], dim=1).reshape(2 * T, *eps.shape[1:])
+            torch.save({"sharded": full, "exchanges": sh.exchanges, "bytes": sh.bytes_sent, "lo_clamped": net.diffusion_model.lo_clamped,
+                        "precision": net.diffusion_model.precision}, Path(out_dir) / "out.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(2400)
+def test_frame_groups_at_the_full_size_workload_vs_the_reference_eps():
+    """Round 6: the frame-group layout (T frames of a sample over G ranks) at the full-size workload against the REFERENCE's
+    eps: two processes on the one GPU, frames 0-3 / 4-7 of both CFG halves each — the temporal GroupNorm's statistics all-reduce, the
+    halo frames of every temporal conv and the STT temporal branch's all-to-alls (hi + lo plane in one exchange) at their real size."""
+    import numpy as np
+    from helpers import GOLDEN
+    gold = np.load(GOLDEN / "full_cfg3.npz")
+    if "eps" not in gold.files:
+        pytest.skip("full_cfg3.npz holds no whole eps")
+    port = 29500 + ((os.getpid() * 19 + 11) % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_full_size_frames_worker, args=(2, port, d), nprocs=2, join=True)
+        r = torch.load(Path(d) / "out.pt")
+    diff = (r["sharded"].float() - torch.from_numpy(gold["eps"])).abs()
+    print(f"full-size frame groups vs the reference ({r['precision']}): max {diff.max().item():.3e} mean {diff.mean().item():.3e}; "
+          f"{r['exchanges']} exchanges, {r['bytes'] / 1e6:.1f} MB sent per rank")
+    measured("frame_shard_full_size_vs_reference", max_abs=diff.max().item(), mean_abs=diff.mean().item(), exchanges=r["exchanges"],
+             MB_sent=r["bytes"] / 1e6)
+    assert diff.max().item() <= 1e-3 and diff.mean().item() <= 2e-4
+    assert r["lo_clamped"] == 0 and r["exchanges"] >= 150
+
+
 def _rccl_world1_view_worker(rank, port, out):
     """the view-shard exchanges through torch.distributed "nccl" (= RCCL) on the MI355X with a one-rank group: the
     all_to_all_single with split sizes and the all_gather_into_tensor of `ViewShard` run as RCCL collectives on the HIP stream"""

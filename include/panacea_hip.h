@@ -66,8 +66,9 @@ enum {
                                      do not depend on it (same tiles, same arithmetic) */
     PNC_OPT_STENCIL_TILES = 6,    /* 1 (default): stride-1 3x3 convs with Cin % 64 == 0 on grids that fill the chip stage ONE spatial tile of
                                      the input incl. its halo per 64-channel slice and read the nine taps from it (gemm_stencil_tile.hip);
-                                     0 = always one gathered A tile per tap; 2 = wherever the shape allows (tests).  Bit-identical
-                                     results either way */
+                                     0 = always one gathered A tile per tap; 2 = wherever the shape allows (tests); + 4 (round 6, A/B): the
+                                     tile kernel computes its fragment addresses next to the reads (round 5) instead of one MFMA batch
+                                     ahead of them.  Bit-identical results either way */
     PNC_OPT_GEMM_PERSIST = 7,     /* bit set, 3 (default).  Bit 0: GEGLU GEMMs of >= 512 full 256x256 tiles run as ONE persistent workgroup
                                      per CU that requests the next output tile's first K tile before its epilogue; bit 1 (round 4): the
                                      same for plain-A launches of >= 512 full 256x320 tiles with a row-major epilogue (residual in place,

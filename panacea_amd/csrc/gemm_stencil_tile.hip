@@ -156,25 +156,33 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
     // ds_read_b128: the compiler's counter model waits lgkmcnt(0) across the loop's back edge, which would expose the latency of
     // the reads just issued (A/B on the device: 2-4 % at long K); the waits for these reads are written out in the loop below.
     half8v af[2][MI], bf[2][NI];
-    auto frags = [&](int hbuf, int tap, int half, int stage, int ks, auto b_) {
-        constexpr int b = decltype(b_)::value;
+    // LDS addresses of those fragments (the pipeline computes them one batch AHEAD of the reads: round 6) ...
+    auto frag_addr = [&](int hbuf, int tap, int half, int stage, int ks, unsigned (&a_addr)[MI], unsigned& b_addr) {
         const char* sa = halo + hbuf * HBYTES;
         const char* sb = wring + stage * WHB + b_row;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int toff = ky * HW2 + kx;
         const int c4 = ks * 2 + fk;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const unsigned a_addr = (unsigned)(uintptr_t)(sa + (hp0[i] + toff) * 128 +
-                                                          (((half * 4 + c4) ^ (((hx0[i] + kx) >> 1) & 7)) << 4));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(af[b][i]) : "v"(a_addr));
-        }
-        const unsigned b_addr = (unsigned)(uintptr_t)(sb + ((c4 ^ b_swz) << 4));
+        for (int i = 0; i < MI; ++i)
+            a_addr[i] = (unsigned)(uintptr_t)(sa + (hp0[i] + toff) * 128 + (((half * 4 + c4) ^ (((hx0[i] + kx) >> 1) & 7)) << 4));
+        b_addr = (unsigned)(uintptr_t)(sb + ((c4 ^ b_swz) << 4));
+    };
+    // ... and the reads
+    auto frag_read = [&](const unsigned (&a_addr)[MI], unsigned b_addr, auto b_) {
+        constexpr int b = decltype(b_)::value;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(af[b][i]) : "v"(a_addr[i]));
 #define PNC_STENCIL_RD_B(J)                                                                                            \
     if constexpr (NI > J)                                                                                              \
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[b][J < NI ? J : 0]) : "v"(b_addr), "n"(J * 16 * 128));
         PNC_STENCIL_RD_B(0) PNC_STENCIL_RD_B(1) PNC_STENCIL_RD_B(2) PNC_STENCIL_RD_B(3) PNC_STENCIL_RD_B(4)
 #undef PNC_STENCIL_RD_B
+    };
+    auto frags = [&](int hbuf, int tap, int half, int stage, int ks, auto b_) {
+        unsigned a_addr[MI], b_addr;
+        frag_addr(hbuf, tap, half, stage, ks, a_addr, b_addr);
+        frag_read(a_addr, b_addr, b_);
     };
     auto mfmas = [&](auto b_) {
         constexpr int b = decltype(b_)::value;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
     // that phase is passed by the time this group is behind the second barrier of phase (q, 0)).  The counted wait in the same
     // phase leaves only the W group just issued in flight: W(q + 1), read from the next phase on, has landed.  Same K order
     // and MFMA order per accumulator: bit-identical to the pipeline below.
-    if (stagger) {
+    if (stagger == 1) {
         const int grp = wave >> 2;
 #pragma unroll
         for (int i = 0; i < H_IT; ++i)
@@ -276,18 +284,28 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
     issue_w(2, 2);
     if (wave_on) frags(0, 0, 0, 0, 0, B0);
     int st = 0, gs = 0, r = 0, w3 = 3;              // w3 = (q + 3) mod nq1: the W half tile issued in iteration q
+    // Round 6: the fragment ADDRESSES are computed one batch ahead of the reads (ta / tb: the reads at the top of the next iteration, under
+    // the second MFMA batch; na / nb: the reads behind the barrier, under the first), so that only the ds_reads themselves sit between
+    // two MFMA batches: 3-5 % on every level-0 / level-1 shape (profiles/round6/stencil_dma_late_r6.log; requesting the DMA behind the
+    // second batch instead of in front of it bought 2-3 % alone and nothing on top of this).  stagger & 2 (A/B): the round-5 placement
+    const bool addr_late = (stagger & 2) != 0;
+    unsigned ta[MI], tb, na[MI], nb;
+    if (!addr_late) frag_addr(0, 0, 0, 0, 1, ta, tb);
     for (int q = 0; q < nq; ++q) {
-        if (wave_on) {
-            frags(gs & 1, r >> 1, r & 1, st, 1, B1);
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI + NI) : "memory");   // buffer 0 (the older reads) is in
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(B0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         // next half tile's coordinates
         int r1 = r + 1, gs1 = gs;
         if (r1 == IPS) { r1 = 0; ++gs1; }
         const int st1 = (st == 2) ? 0 : st + 1;
+        if (wave_on) {
+            if (addr_late) frags(gs & 1, r >> 1, r & 1, st, 1, B1);
+            else frag_read(ta, tb, B1);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI + NI) : "memory");   // buffer 0 (the older reads) is in
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(B0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!addr_late) frag_addr(gs1 & 1, r1 >> 1, r1 & 1, st1, 0, na, nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (q + 2 < nq) wait_all_but_last_w();                 // in flight: W(q+1), [halo piece, W(q+2)]
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave has read everything it needs of stage st
@@ -298,9 +316,14 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
         if (q + 3 < nq) issue_w(w3, st);
         w3 = (w3 + 1 == nq1) ? 0 : w3 + 1;
         if (wave_on) {
-            if (q + 1 < nq) frags(gs1 & 1, r1 >> 1, r1 & 1, st1, 0, B0);
+            if (q + 1 < nq) {
+                if (addr_late) frags(gs1 & 1, r1 >> 1, r1 & 1, st1, 0, B0);
+                else frag_read(na, nb, B0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             mfmas(B1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!addr_late) frag_addr(gs1 & 1, r1 >> 1, r1 & 1, st1, 1, ta, tb);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (A_lo && q + 1 == nq1) {
@@ -348,7 +371,9 @@ static int launch_stencil(const PncGemmParams& p, hipStream_t st) {
     int nfull = tiles_m * tiles_n, tail_f = 1;
     tail_split<256, 4, lds>(tiles_m * tiles_n, nfull, tail_f);            // one workgroup per CU: 256 slots per round
     hipLaunchKernelGGL(kern, dim3(nfull + (tiles_m * tiles_n - nfull) * tail_f), dim3(512), lds, st, p, group_m, nfull, tail_f,
-                       pnc_get_option(PNC_OPT_GEMM_STAGGER) == 1 ? 1 : 0);     // (measured 5-15 % slower than the pipeline: only on request)
+                       pnc_get_option(PNC_OPT_GEMM_STAGGER) == 1 ? 1 : ((pnc_get_option(PNC_OPT_STENCIL_TILES) & 4) ? 2 : 0));
+    // (stagger = 1: the staggered schedule, measured 5-15 % slower than the pipeline, only on request; 2: the pipeline with the fragment
+    // addresses computed next to the reads, as in round 5)
     return pnc_launch_status();
 }
 
@@ -369,7 +394,7 @@ static int dispatch_epi(const PncGemmParams& p, unsigned epi, hipStream_t st) {
 // PNC_OPT_STENCIL_TILES = 2: tests) grids of fewer than 160 tiles: the per-tap kernels have split K for those (level 2, 192 tiles:
 // +8 % on the tile kernel; a sparse last round — level 1: 384 tiles = 1.5 rounds — is tail-split here as there).
 int conv3x3_tile_geometry(const PncGemmParams& p, unsigned epi) {
-    const int opt = pnc_get_option(PNC_OPT_STENCIL_TILES);       // 0 off, 1 auto, 2 wherever the shape allows
+    const int opt = pnc_get_option(PNC_OPT_STENCIL_TILES) & 3;   // 0 off, 1 auto, 2 wherever the shape allows
     if (!opt) return 0;
     if (p.stride != 1 || p.upsample || p.conv_pad_br || (p.Cin & 63) || p.Hin != p.Hout || p.Win != p.Wout) return 0;
     if (p.K != 9 * p.Cin || p.M % (p.Hout * p.Wout)) return 0;

@@ -825,8 +825,9 @@ def test_gemm_conv3x3_stencil_tiles_are_bit_identical(F, H, W, Cin, N, epi):
     tol = (2e-5, 1e-5) if lo is not None else (2e-3, 2e-3)
     check("per-tap gather vs emu (fp32)", plain["o32"], e["o32"], *tol)
     check("per-tap gather vs emu (fp16)", plain["o16"], e["o16"], 4e-3)
-    # small grids are one sparse round: with the tail split every tile runs as 4 quarter-tile workgroups, without as one
-    for tail, forced in ((1, 2), (0, 2)):
+    # small grids are one sparse round: with the tail split every tile runs as 4 quarter-tile workgroups, without as one;
+    # + 4: the fragment addresses next to the reads (round 5) instead of one MFMA batch ahead of them (round 6's default)
+    for tail, forced in ((1, 2), (0, 2), (1, 6)):
         tiles = outs()
         prev = hip.set_option(hip.OPT_GEMM_TAIL_SPLIT, tail)
         try:

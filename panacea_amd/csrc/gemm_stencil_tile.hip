@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
     // ---- halo DMA: piece b = halo rows 8b .. 8b+7; lane l fills slot (l&7) of row 8b + (l>>3) with the source chunk
     // slot ^ ((hx>>1)&7), hx = the row's halo COLUMN.  The 16 lanes of a ds_read_b128 group read 16 consecutive pixels of
     // one or two tile rows = 16 consecutive halo columns (whatever the tap), i.e. all 16 (parity, hx>>1) pairs.
-    auto issue_halo = [&](bool lo_plane, int cc, int buf, int b) {
+    auto halo_off = [&](int b) -> unsigned {            // this lane's byte offset of piece b inside the frame (the same for every slice)
         const int hr = b * 8 + (lane >> 3);
         const int hy = hr / HW2, hx = hr - hy * HW2;
         const int c8 = (lane & 7) ^ ((hx >> 1) & 7);
@@ -112,8 +112,12 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
         const bool ok = yok && (xin || (xh && ix >= -1 && ix <= p.Win));
         unsigned off = ok ? (unsigned)((iy * p.Win + ix) * p.Cin + c8 * 8) * 2u : PNC_BUF_OOB;           // out of the image: zeros
         if (ok && !xin) off = (unsigned)(xh_rel + (ix < 0 ? 0 : xh_side) + iy * p.Cin + c8 * 8) * 2u;
+        return off;
+    };
+    auto request_halo = [&](bool lo_plane, int cc, int buf, int b, unsigned off) {
         glds16_buf(lo_plane ? rs_lo : rs_a, off, (unsigned)cc << 7, halo + buf * HBYTES + b * 1024);
     };
+    auto issue_halo = [&](bool lo_plane, int cc, int buf, int b) { request_halo(lo_plane, cc, buf, b, halo_off(b)); };
     // ---- W DMA: half tile k = 32 channels of K tile k/2 = k offset 32 k of the packed [N][(ci/64, tap, ci%64)] weights.
     // LDS row R (128 B) = W rows 2R, 2R+1; slot = (n&1)*4 + (c ^ ((R>>1)&3)), c = 16-byte chunk of the 64-byte half row.
     const int nW = WBLK / NW + (wave < (WBLK % NW) ? 1 : 0);      // DMA instructions of this wave per half tile
@@ -305,14 +309,20 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
             __builtin_amdgcn_sched_barrier(0);
             if (!addr_late) frag_addr(gs1 & 1, r1 >> 1, r1 & 1, st1, 0, na, nb);
         }
+        // (the halo piece's offset arithmetic — a division, the image-edge tests — under the batch too)
+        const bool halo_on = r < H_IT && gs + 1 < ns_tot && wave + NW * r >= pc_lo && wave + NW * r < pc_hi && wave + NW * r < HBLK;
+        unsigned hoff = 0;
+        if (halo_on && !addr_late) hoff = halo_off(wave + NW * r);
         __builtin_amdgcn_sched_barrier(0);
         if (q + 2 < nq) wait_all_but_last_w();                 // in flight: W(q+1), [halo piece, W(q+2)]
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave has read everything it needs of stage st
         __builtin_amdgcn_s_barrier();
         // halo buffer (gs+1)&1 was last read in slice gs-1; stage st by half tile q (all waves are past their reads of it)
-        if (r < H_IT && gs + 1 < ns_tot && wave + NW * r >= pc_lo && wave + NW * r < pc_hi && wave + NW * r < HBLK)
-            issue_halo(slice_plane(gs + 1), slice_cc(gs + 1), (gs + 1) & 1, wave + NW * r);
+        if (halo_on) {
+            if (addr_late) issue_halo(slice_plane(gs + 1), slice_cc(gs + 1), (gs + 1) & 1, wave + NW * r);
+            else request_halo(slice_plane(gs + 1), slice_cc(gs + 1), (gs + 1) & 1, wave + NW * r, hoff);
+        }
         if (q + 3 < nq) issue_w(w3, st);
         w3 = (w3 + 1 == nq1) ? 0 : w3 + 1;
         if (wave_on) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: stencil_tile_kernel fragment addresses one batch ahead (and, first version, the DMA order) — per-shape A/B on the rebuilt library, the stencil bit-identity tests, whole-step A/B (interleaved)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r6l
+O=gpurun_out/r6m
 mkdir -p $O
 timeout 300 python tools/exp/stencil_dma_late_ab.py 2>&1 | grep -v amdgpu > $O/stencil_dma_late_ab.log; cat $O/stencil_dma_late_ab.log
 timeout 600 python -m pytest tests -m gpu -q -x -k "stencil or conv3x3 or tile" 2>&1 | tail -3

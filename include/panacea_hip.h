@@ -59,8 +59,10 @@ enum {
     PNC_OPT_ATTN_DMA = 3,         /* 1 (default): LDS-DMA staging of K / V^T tiles where alignment allows, tile addresses kept as lane constant +
                                      wave-uniform offset; 2 = LDS-DMA with per-tile recomputed addresses (A/B); 0 = register staging.  Same results.
                                      + 4 (round 6, A/B): the few-key launches stay on attn_views_kernel instead of attn_text_kernel */
-    PNC_OPT_GEMM_FUSE_LN = 4,     /* 1 (default): PncGemmParams.ln_* is reduced in the GEMM epilogue where a workgroup owns whole
-                                     rows; 0 = always the LayerNorm kernel after the GEMM (A/B measurements; same result) */
+    PNC_OPT_GEMM_FUSE_LN = 4,     /* bit 0, 1 (default): PncGemmParams.ln_* is reduced in the GEMM epilogue where a workgroup owns whole
+                                     rows; 0 = always the LayerNorm kernel after the GEMM (A/B measurements; same result).
+                                     + 2 (round 6, A/B): fp32-only epilogues (out32 = acc + bias [+ res1]) of full 256-row tiles go through
+                                     the LDS staging, as in round 5, instead of straight from the accumulators.  Bit-identical */
     PNC_OPT_GEMM_GROUP_M = 5,     /* 0 (default): tiles of a GEMM with more than 8 column tiles are walked in groups of 4 row panels
                                      (L2 reuse of W where it exceeds the cache); k > 1 forces groups of k; 1 = plain order.  Results
                                      do not depend on it (same tiles, same arithmetic) */

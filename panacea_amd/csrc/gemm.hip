@@ -223,7 +223,7 @@ static unsigned epilogue_with_ln(const PncGemmParams& p) {
     unsigned epi = select_epilogue(p);
     // LayerNorm fused into the epilogue: plain A, fp32 output only, at most one added stream, 16-byte aligned fp16 rows
     if (p.ln_out16 && p.a_mode == PNC_A_PLAIN && (epi == E_O32 || epi == (E_RB | E_O32) || epi == (E_R1 | E_O32)) &&
-        (p.ldln % 8 == 0) && al16(p.ln_out16) && pnc_get_option(PNC_OPT_GEMM_FUSE_LN))
+        (p.ldln % 8 == 0) && al16(p.ln_out16) && (pnc_get_option(PNC_OPT_GEMM_FUSE_LN) & 1))
         epi |= E_LN;
     return epi;
 }

@@ -673,6 +673,52 @@ __device__ __forceinline__ void epi_vt(const PncGemmParams& p, f32x16 (&acc)[MI]
     });
 }
 
+// DIRECT fp32 epilogue of a full wave tile (round 6): out32 = acc + bias (+ res1), straight from the accumulators.  Lane (column c, half h)
+// of a 32x32 block holds rows 8 q + 4 h + e of column c: one four-byte store / load instruction moves two whole 128-byte row pieces, so the
+// accesses are as wide as the staged epilogue's at the memory side, and the LDS round trip (160 four-byte staging writes + 40 reads per wave)
+// is gone.  The residual of block b + 1 is requested before block b is combined.  Same additions in the same order as epi_fast
+// ((acc + bias) + res1): bit-identical.  The caller guarantees: every row / column inside the matrix, no activation.
+template <int MI, int NI, bool R1, class RM>
+__device__ __forceinline__ void epi_direct_o32(const PncGemmParams& p, f32x16 (&acc)[MI][NI], int lane, RM rmap, int nw) {
+    // Addressing through buffer resources: base = the wave tile's first row, per-lane byte offset of (row block i, this lane's half, its
+    // column) + the column block as the instruction offset + the row's offset inside the block as the SCALAR offset — no vector
+    // arithmetic per access.  rmap is additive over (block, half, row) for both row maps (RowLinear; RowHalo: 4 h + (r & 3) stays inside
+    // a 16- / 32-pixel tile row).
+    const int col = lane & 31, h4 = 4 * (lane >> 5);
+    const int m00 = rmap(0);
+    const buffer_rsrc_t ro = make_rsrc(p.out32 + (int64_t)m00 * p.ldc32, 0x7FFFFF00u);
+    const buffer_rsrc_t rr = make_rsrc(R1 ? p.res1 + (int64_t)m00 * p.ldr1 : p.out32, 0x7FFFFF00u);
+    int vo[MI], vr[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int dm = rmap(i * 32 + h4) - m00;
+        vo[i] = (dm * p.ldc32 + nw + col) * 4;
+        vr[i] = R1 ? (dm * p.ldr1 + nw + col) * 4 : 0;
+    }
+    unsigned x[2][16];
+    auto load_res = [&](auto b_) {
+        constexpr int b = decltype(b_)::value, i = b / NI, j = b % NI;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int so = (rmap((r & 3) + 8 * (r >> 2)) - m00) * p.ldr1 * 4;          // (uniform)
+            x[b & 1][r] = __builtin_amdgcn_raw_buffer_load_b32(rr, vr[i] + j * 128, so, 0);
+        }
+    };
+    if constexpr (R1) load_res(std::integral_constant<int, 0>{});
+    static_for<MI * NI>([&](auto b_) {
+        constexpr int b = decltype(b_)::value, i = b / NI, j = b % NI;
+        const float bn = p.bias ? p.bias[nw + j * 32 + col] : 0.0f;
+        if constexpr (R1 && b + 1 < MI * NI) load_res(std::integral_constant<int, b + 1>{});
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r] + bn;
+            if constexpr (R1) v += __builtin_bit_cast(float, x[b & 1][r]);
+            const int so = (rmap((r & 3) + 8 * (r >> 2)) - m00) * p.ldc32 * 4;         // (uniform)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, vo[i] + j * 128, so, 0);
+        }
+    });
+}
+
 // Generic epilogue: every option is a run-time flag, every access scalar and predicated.  Correct for any N, leading
 // dimension and alignment; used by the few ragged launches of the path (the 4-channel output head) and by callers
 // outside the vector contract.  No prefetch arrays: it must not need scratch either.
@@ -722,7 +768,7 @@ template <int AMODE, int BM, int BN, int WGM, int WGN, int STAGES, bool PIPE, un
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemmParams pin, const int ksplit,
                                                                    const int nfull, const int tail_f,
                                                                    const float* __restrict__ phi_g, const int group_m,
-                                                                   const int stagger_min) {
+                                                                   const int stagger_min_in) {
     PncGemmParams p = pin;
     constexpr int NW = WGM * WGN;                          // waves per workgroup
     constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
@@ -1047,6 +1093,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     // Where it can run: plain A (the gathers' per-piece address arithmetic sits on the critical path of a phase: the per-tap conv3x3 /
     // temporal conv launches measured 4-20 % SLOWER staggered, profiles/round5/stagger_kbench_r5c_generic_issue_path.log), K a
     // multiple of 64, no fp16 lo plane, and not in the row-split workgroups of a sparse last round (one of the two groups idles there).
+    const bool direct_epi = (stagger_min_in & 0x100) != 0;
+    const int stagger_min = stagger_min_in & 0xFF;
     bool staggered = false;
     if constexpr (STAGES == 2 && NW == 8 && AMODE == PNC_A_PLAIN)
         staggered = stagger_min == 1 && kt_tail < 0 && (!A_lo || lo8) && !split_rows && ksplit == 1;
@@ -1225,6 +1273,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(const PncGemm
     } else {
         if constexpr ((EPI & E_VT) != 0) {
             if (n0 >= p.n_split) { epi_vt<MI, NI>(p, acc, lane, mw, nw); return; }
+        }
+        if constexpr (EPI == (E_R1 | E_O32) || EPI == E_O32) {
+            // (uniform) full tile, no activation: the direct epilogue (round 6; PNC_OPT_GEMM_FUSE_LN + 2, A/B: the staged one)
+            if (direct_epi && p.act == PNC_ACT_NONE && m0 + BM <= p.M && n0 + BN <= p.N && !split_rows && ksplit == 1) {
+                epi_direct_o32<MI, NI, (EPI & E_R1) != 0>(p, acc, lane, RowLinear{mw}, nw);
+                return;
+            }
         }
         float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EPITCH);
         __syncthreads();                        // every wave is done reading operand tiles from LDS
@@ -1769,8 +1824,9 @@ __device__ __forceinline__ void epi_fast_alds(const PncGemmParams& p, f32x16 (&a
 }
 
 template <unsigned EPI>
-__global__ __launch_bounds__(512) void gemm_persist_kernel(const PncGemmParams pin, const int group_m) {
+__global__ __launch_bounds__(512) void gemm_persist_kernel(const PncGemmParams pin, const int group_m_in) {
     PncGemmParams p = pin;
+    const int group_m = group_m_in & 0xFFFF;
     constexpr int BM = 256, BN = 320, WGM = 4, WGN = 2;
     constexpr int NW = WGM * WGN, MI = BM / WGM / 32, NI = BN / WGN / 32, RPI = NW * 8, A_IT = BM / RPI, B_IT = BN / RPI;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -1943,6 +1999,13 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(const PncGemmParams p
             // column tiles at or beyond n_split go channel-major straight from the accumulators (no LDS at all)
             if (n0 >= p.n_split) epi_vt<MI, NI>(p, acc, lane, m0 + wm * (MI * 32), n0 + wn * (NI * 32));
             else epi_fast_alds<MI, NI, (EPI & ~E_VT)>(p, acc, ep, lane, m0 + wm * (MI * 32), n0 + wn * (NI * 32), 0u, 0u);
+        } else if constexpr (EPI == E_O32 || EPI == (E_R1 | E_O32)) {
+            // fp32 output (+ residual in place) straight from the accumulators (round 6, epi_direct_o32; group_m bit 16, A/B: staged)
+            if (!(group_m_in & 0x10000) && p.act == PNC_ACT_NONE)
+                epi_direct_o32<MI, NI, (EPI & E_R1) != 0>(p, acc, lane, RowLinear{m0 + wm * (MI * 32)}, n0 + wn * (NI * 32));
+            else
+                epi_fast_alds<MI, NI, EPI>(p, acc, ep, lane, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lnb + (unsigned)wave * 512u,
+                                           lnb + (unsigned)(wave ^ 1) * 512u);
         } else {
             epi_fast_alds<MI, NI, EPI>(p, acc, ep, lane, m0 + wm * (MI * 32), n0 + wn * (NI * 32), lnb + (unsigned)wave * 512u,
                                        lnb + (unsigned)(wave ^ 1) * 512u);
@@ -1987,7 +2050,7 @@ int launch_plain_persist(const PncGemmParams& p, hipStream_t st) {
         ncu_of[dev & 63].store(ncu, std::memory_order_relaxed);
     }
     const int blocks = tiles < ncu ? tiles : ncu;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, p, group_m);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, p, group_m | ((pnc_get_option(PNC_OPT_GEMM_FUSE_LN) & 2) ? 0x10000 : 0));
     return pnc_launch_status();
 }
 
@@ -2030,7 +2093,7 @@ int launch(const PncGemmParams& p, hipStream_t st, int ksplit = 1) {
     if (group_m > tiles_m) group_m = tiles_m;
     if (tiles_n < 2) group_m = 0;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds + (GEGLU ? PHI_BYTES : 0), st, q, ksplit, nfull, tail_f, phi,
-                       group_m, pnc_get_option(PNC_OPT_GEMM_STAGGER));
+                       group_m, (pnc_get_option(PNC_OPT_GEMM_STAGGER) & 0xFF) | ((pnc_get_option(PNC_OPT_GEMM_FUSE_LN) & 2) ? 0 : 0x100));
     if (ksplit > 1) return launch_splitk_reduce(p, ksplit, st);
     return pnc_launch_status();
 }

@@ -351,6 +351,16 @@ __global__ __launch_bounds__(512) void stencil_tile_kernel(const PncGemmParams p
     if (!wave_on) return;                       // rows of another workgroup (tail split)
 
     // ------------------------------ epilogue ------------------------------
+    if constexpr (EPI == E_O32) {
+        if (!(stagger & 4) && p.act == PNC_ACT_NONE && n0 + BN <= p.N) {
+            // fp32 output straight from the accumulators (round 6): lane (column c, half h) of a 32x32 block holds rows 8 q + 4 h + e of column
+            // c, so one store instruction writes two whole 128-byte row pieces — no LDS round trip (160 four-byte staging writes + 40 reads
+            // per wave), same bytes to memory.  1.4-3.3 % per launch (profiles/round6/stencil_direct_epilogue_r6.log); acc + bias as in
+            // epi_fast: bit-identical.  stagger & 4 (A/B, PNC_OPT_GEMM_FUSE_LN + 2): the staged epilogue
+            epi_direct_o32<MI, NI, false>(p, acc, lane, RowHalo<TWS>{base_m, p.Wout, wm * 64}, n0 + wn * (NI * 32));
+            return;
+        }
+    }
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EPITCH);
     epi_fast<MI, NI, EPI>(p, acc, ep, lane, RowHalo<TWS>{base_m, p.Wout, wm * 64}, n0 + wn * (NI * 32), p.N);
 }
@@ -381,9 +391,9 @@ static int launch_stencil(const PncGemmParams& p, hipStream_t st) {
     int nfull = tiles_m * tiles_n, tail_f = 1;
     tail_split<256, 4, lds>(tiles_m * tiles_n, nfull, tail_f);            // one workgroup per CU: 256 slots per round
     hipLaunchKernelGGL(kern, dim3(nfull + (tiles_m * tiles_n - nfull) * tail_f), dim3(512), lds, st, p, group_m, nfull, tail_f,
-                       pnc_get_option(PNC_OPT_GEMM_STAGGER) == 1 ? 1 : ((pnc_get_option(PNC_OPT_STENCIL_TILES) & 4) ? 2 : 0));
-    // (stagger = 1: the staggered schedule, measured 5-15 % slower than the pipeline, only on request; 2: the pipeline with the fragment
-    // addresses computed next to the reads, as in round 5)
+                       pnc_get_option(PNC_OPT_GEMM_STAGGER) == 1 ? 1 : (((pnc_get_option(PNC_OPT_STENCIL_TILES) & 4) ? 2 : 0) | ((pnc_get_option(PNC_OPT_GEMM_FUSE_LN) & 2) ? 4 : 0)));
+    // (stagger = 1: the staggered schedule, measured 5-15 % slower than the pipeline, only on request; + 2: the pipeline with the fragment
+    // addresses computed next to the reads, as in round 5; + 4: the fp32-only epilogue staged through LDS, as in round 5)
     return pnc_launch_status();
 }
 

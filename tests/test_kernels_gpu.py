@@ -222,6 +222,56 @@ def test_gemm_persistent_kernel_is_bit_identical(variant):
         assert ref[k].float().abs().max().item() > 0.1
 
 
+@pytest.mark.parametrize("kind,M,N,K", [
+    ("plain", 1024, 640, 192), ("plain", 768, 1280, 128), ("plain", 1000, 640, 128),      # 256x320 / 256x256 tiles; a ragged last row tile
+    ("plain_lo8", 1024, 320, 320), ("persist", 256 * 512, 320, 128), ("persist_lo8", 256 * 512, 320, 320),
+    ("conv3x3", 2 * 16 * 32, 320, 9 * 64), ("stencil", 2 * 16 * 32, 320, 9 * 64),
+])
+@pytest.mark.parametrize("res", [False, True])
+def test_gemm_direct_fp32_epilogue_is_bit_identical(kind, M, N, K, res):
+    """Round 6: fp32-only epilogues (out32 = acc + bias [+ res1, in place]) of full 256-row tiles leave the accumulators through buffer
+    stores (and the residual comes in through buffer loads) instead of through the LDS staging — epi_direct_o32 in gemm_glds_kernel,
+    gemm_persist_kernel and stencil_tile_kernel.  Same additions in the same order: bit-identical to the staged epilogue
+    (PNC_OPT_GEMM_FUSE_LN + 2), incl. the tiles that fall back to it (ragged rows) and the e4m3 lo pass in front."""
+    from panacea_amd import engine
+    w = rnd(N, K, scale=K ** -0.5, dtype=torch.float16, seed=72)
+    bias = rnd(N, seed=73)
+    res0 = rnd(M, N, seed=74)
+    kw = dict(M=M, N=N, K=K, bias=bias)
+    if kind in ("conv3x3", "stencil"):
+        Cin = K // 9
+        x = rnd(2, 16, 32, Cin, dtype=torch.float16, seed=71)
+        kw.update(a16=x, a_mode=hip.A_CONV3X3, conv=dict(Cin=Cin, Hin=16, Win=32, Hout=16, Wout=32, stride=1, upsample=0))
+    else:
+        a32 = rnd(M, K, seed=71)
+        kw.update(a16=a32.half(), lda=K)
+        if "lo8" in kind:
+            alo = torch.zeros(M, K, device=DEV, dtype=torch.uint8)
+            hip.cast_f16(a32, M * K, torch.zeros(M, K, device=DEV, dtype=torch.float16), alo)
+            kw.update(a16_lo=alo, w_lo=engine.pk_lo8(w))
+
+    def run(fuse_opt):
+        o = res0.clone() if res else torch.zeros(M, N, device=DEV)
+        k2 = dict(kw, w16=w, out32=o, ldc32=N)
+        if res:
+            k2.update(res1=o, ldr1=N)
+        prev = hip.set_option(hip.OPT_GEMM_FUSE_LN, fuse_opt)
+        pst = hip.set_option(hip.OPT_STENCIL_TILES, 2 if kind == "stencil" else 0)
+        ppe = hip.set_option(hip.OPT_GEMM_PERSIST, 3 if kind.startswith("persist") else 1)
+        try:
+            hip.gemm(**k2)
+            torch.cuda.synchronize()
+        finally:
+            hip.set_option(hip.OPT_GEMM_FUSE_LN, prev)
+            hip.set_option(hip.OPT_STENCIL_TILES, pst)
+            hip.set_option(hip.OPT_GEMM_PERSIST, ppe)
+        return o
+    staged, direct, again = run(3), run(1), run(1)
+    assert torch.equal(direct, staged), (kind, res, (direct - staged).abs().max().item())
+    assert torch.equal(again, staged)
+    assert staged.abs().max().item() > 0.1
+
+
 @pytest.mark.parametrize("G,t_rows,C", [(2, 128, 64), (3, 96, 128), (2, 80, 64), (2, 192, 320)])
 def test_gemm_split_transposed_output(G, t_rows, C):
     # q|k row-major for n < 2C, V^T channel-major for n >= 2C  (QKV projection epilogue)

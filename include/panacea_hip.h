@@ -88,7 +88,9 @@ enum {
                                      waves 4-7 one barrier behind waves 0-3, so that on every SIMD one wave multiplies while the other
                                      reads (FF1 at levels 1-2: +5-6 %); 0 = never (round 4's loops); 1 = everywhere the schedule exists —
                                      also the plain-A 8-wave two-stage kernels and the stencil-tile conv kernel, where it measured no
-                                     faster (tests, A/B tools).  Same K and MFMA order per accumulator: bit-identical results */
+                                     faster (tests, A/B tools).  Same K and MFMA order per accumulator: bit-identical results.
+                                     + 256 (round 6, A/B): the persistent GEGLU kernel's products go through its LDS slab (round 3) instead
+                                     of straight from the registers through two-byte buffer stores.  Same values */
     PNC_OPT_ATTN_SUM_TRIGGER = 11, /* k (default 12; round 6): after a query block's first K/V tile pnc_attn_views_f16 forms the probabilities
                                      against the running maximum AS IT IS and lets the row sum (needed anyway) tell whether that was safe — a
                                      lane's probabilities are each <= their sum, so sum < 2^k bounds every P below 2^k (fp16-safe up to 14) —

@@ -1335,7 +1335,7 @@ const float* phi_table_device(hipStream_t st, int* rc);
 // level-0 FF1 472-540 -> 409-430 us, level 1 356 -> 334, level 2 316 -> 308.
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(const PncGemmParams pin, const float* __restrict__ phi_g,
-                                                                            const int group_m, const int stagger_min) {
+                                                                            const int group_m, const int stagger_min_in) {
     PncGemmParams p = pin;
     constexpr int NW = WGM * WGN, MI = BM / WGM / 32, NI = BN / WGN / 32, RPI = NW * 8, A_IT = BM / RPI, B_IT = BN / RPI;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, RING_BYTES = 2 * STAGE;
@@ -1424,6 +1424,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(cons
         }
     };
 
+    const bool direct16 = (stagger_min_in & 256) == 0;     // (+ 256, A/B: the round-3 epilogue through a 2 KB LDS slab per wave)
+    const int stagger_min = stagger_min_in & 255;
     if (NW == 8 && wave >= 4 && !(stagger_min > 0 && nk >= stagger_min)) __builtin_amdgcn_s_setprio(1);
     int v = blockIdx.x;
     if (v >= ntile) return;
@@ -1541,6 +1543,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(cons
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) e[r] = *reinterpret_cast<const float2*>(s_phi + 2 * ix[r]);
+                    if (direct16) {
+                        // round 6: the products leave through two-byte buffer stores straight from the registers (a lane holds one column of
+                        // rows 8 q + 4 h + e: two 64-byte row pieces per instruction, the row inside the block as the scalar offset) instead of
+                        // through the slab (16 two-byte staging writes — the kernel's LDS bank conflicts — + 2 reads + 2 sixteen-byte stores per
+                        // block): FF1 −0.5 … −1.7 % at every level, step −0.3 ms (profiles/round6/ff1_direct_stores_r6.log).  Same values.
+                        const buffer_rsrc_t ro = make_rsrc(out16 + (int64_t)(mw + i * 32) * p.ldc16, 0x7FFFFF00u);
+                        const int vo = (4 * (lane >> 5) * p.ldc16 + ncol0 + c) * 2;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float prod = (acc[i][jc][r] + bv) * (gx[r] * fmaf(fr[r], e[r].y, e[r].x));
+                            asm("" : "+v"(prod));
+                            const half_t hp = (half_t)prod;
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hp), ro, vo, ((r & 3) + 8 * (r >> 2)) * p.ldc16 * 2, 0);
+                        }
+                    } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float prod = (acc[i][jc][r] + bv) * (gx[r] * fmaf(fr[r], e[r].y, e[r].x));
@@ -1552,6 +1569,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(cons
                         const int row = ps * 16 + rl;
                         const int4 v4 = *reinterpret_cast<const int4_st*>(sb + row * 32 + cl * 8);
                         *reinterpret_cast<int4_st*>(out16 + (int64_t)(mw + i * 32 + row) * p.ldc16 + ncol0 + cl * 8) = v4;
+                    }
                     }
                 });
             });

@@ -22,6 +22,8 @@ def _ab(run, reps=3):
         ref = run()
         hip.set_option(hip.OPT_GEMM_STAGGER, 1)
         got = [run() for _ in range(reps)]
+        hip.set_option(hip.OPT_GEMM_STAGGER, 257)      # + 256 (round 6): the persistent GEGLU kernel's epilogue through its LDS slab
+        got.append(run())
         torch.cuda.synchronize()
     finally:
         hip.set_option(hip.OPT_GEMM_STAGGER, prev)

@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_geglu_persist_kernel(cons
                     if (direct16) {
                         // round 6: the products leave through two-byte buffer stores straight from the registers (a lane holds one column of
                         // rows 8 q + 4 h + e: two 64-byte row pieces per instruction, the row inside the block as the scalar offset) instead of
-                        // through the slab (16 two-byte staging writes — the kernel's LDS bank conflicts — + 2 reads + 2 sixteen-byte stores per
+                        // through the slab (16 two-byte staging writes + 2 reads + 2 sixteen-byte stores per
                         // block): FF1 −0.5 … −1.7 % at every level, step −0.3 ms (profiles/round6/ff1_direct_stores_r6.log).  Same values.
                         const buffer_rsrc_t ro = make_rsrc(out16 + (int64_t)(mw + i * 32) * p.ldc16, 0x7FFFFF00u);
                         const int vo = (4 * (lane >> 5) * p.ldc16 + ncol0 + c) * 2;
